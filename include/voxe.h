@@ -1,0 +1,225 @@
+/*
+ * voxe.h -- C ABI of the MI355X-native voxel-grid volumetric renderer (libvoxe_hip.so)
+ *           and of its CPU twin, the test oracle (oracle/libvoxe_oracle.so, voxe_cpu_*).
+ *
+ * The reference (TAU-VAILab/Vox-E, thre3d_atom) has NO native ABI: its hot path is a chain of
+ * ATen ops reached through autograd.  This header is the boundary a maintainer would bind from
+ * Python (ctypes stub in INTEGRATION.md); each entry point names the reference code it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types: `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream); every pointer of a voxe_* function is a DEVICE pointer on the current HIP device,
+ *     every pointer of a voxe_cpu_* function is a HOST pointer;
+ *   - all buffers are caller-owned, contiguous, float32 unless stated; nothing is allocated inside;
+ *   - every function returns 0 on success or a negative VoxeStatus; nothing throws;
+ *   - functions are asynchronous w.r.t. the host (they enqueue on `stream`) and thread-safe for
+ *     distinct (stream, workspace) pairs.
+ *
+ * Grid memory layout (reference: thre3d_atom/thre3d_reprs/voxels.py:46-136)
+ *   densities [X,Y,Z,1], features [X,Y,Z,F]  (C innermost, Z fastest spatial axis);
+ *   element (ix,iy,iz,c) lives at ((ix*Y + iy)*Z + iz)*C + c.
+ */
+#ifndef VOXE_H_
+#define VOXE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOXE_ABI_VERSION 1
+
+typedef enum VoxeStatus {
+  VOXE_OK = 0,
+  VOXE_ERR_NULL_POINTER = -1,
+  VOXE_ERR_BAD_SHAPE = -2,       /* non-positive grid dims / R / S, F not 3*(deg+1)^2 ...        */
+  VOXE_ERR_UNSUPPORTED = -3,     /* activation / mode the HIP path does not implement            */
+  VOXE_ERR_WORKSPACE = -4,       /* workspace NULL or smaller than voxe_workspace_bytes()        */
+  VOXE_ERR_LAUNCH = -5,          /* hipGetLastError() after a launch was not hipSuccess          */
+  VOXE_ERR_NO_DEVICE = -6        /* no HIP device / wrong architecture                           */
+} VoxeStatus;
+
+/* density activations (voxels.py:55-57; CLI table train_sh_based_voxel_grid_with_posed_images.py:177-200) */
+typedef enum VoxeAct {
+  VOXE_ACT_IDENTITY = 0,
+  VOXE_ACT_ABS = 1,        /* torch.abs            (pre-activation of the non-softplus field)     */
+  VOXE_ACT_RELU = 2,       /* torch.nn.ReLU        (post)                                         */
+  VOXE_ACT_SOFTPLUS = 3    /* torch.nn.Softplus(beta=1, threshold=20) (post; the CLI default)     */
+} VoxeAct;
+
+/* What the "feature" channels are. */
+typedef enum VoxeFeatureKind {
+  VOXE_FEAT_SH = 0,    /* RGB spherical-harmonic coefficients, F = 3*(deg+1)^2; Cout = 3
+                          (process.py:20-96, accumulate.py:31-113)                                */
+  VOXE_FEAT_ATTN = 1   /* one attention channel, F = 1; Cout = 1; background multiplied by 0
+                          (voxels.py:344-406, process.py:98-174, accumulate.py:115-198)           */
+} VoxeFeatureKind;
+
+typedef struct VoxeGridDesc {
+  const float* densities;   /* [X,Y,Z,1]  VoxelGrid._densities (or .orig_densities)               */
+  const float* features;    /* [X,Y,Z,F]  VoxelGrid._features  (or .attn for VOXE_FEAT_ATTN)      */
+  int32_t X, Y, Z, F;
+  float aabb_lo[3];         /* float32(aabb.{x,y,z}_range[0])  voxels.py:196-223                  */
+  float aabb_hi[3];         /* float32(aabb.{x,y,z}_range[1])                                     */
+  float norm_scale[3];      /* adjust_dynamic_range(slack=True): np.float32(2)/(f32(hi)-f32(lo))  */
+  float norm_bias[3];       /*   np.float32(-1) - f32(lo)*scale   (imaging_utils.py:57-63)        */
+  float density_scale;      /* expected_density_scale (voxels.py:303-305)                         */
+  int32_t density_pre_act;  /* VoxeAct: IDENTITY | ABS                                            */
+  int32_t density_post_act; /* VoxeAct: IDENTITY | RELU | SOFTPLUS                                */
+  int32_t feature_kind;     /* VoxeFeatureKind                                                    */
+} VoxeGridDesc;
+
+typedef struct VoxeRenderCfg {
+  int32_t num_samples;        /* S   SHVoxGridRenderConfig.num_samples_per_ray (renderers.py:32)  */
+  float near, far;            /* CameraBounds (sample.py:38-41)                                   */
+  int32_t perturb;            /* stratified jitter (sample.py:55-64). jitter==NULL -> in-kernel
+                                 Philox4x32-10 keyed by (seed, rng_offset, ray, sample)            */
+  int32_t linear_disparity;   /* sample.py:48-51                                                  */
+  int32_t aabb_clip;          /* optimized_sampling: per-ray bounds from the ray/AABB slab test
+                                 (sample.py:71-202)                                               */
+  int32_t white_bkgd;         /* accumulate.py:77-81 (for VOXE_FEAT_ATTN the term is *0.0, :166)  */
+  int32_t sh_degree;          /* 0..3 ; F == 3*(sh_degree+1)^2 for VOXE_FEAT_SH                   */
+  int32_t render_diffuse;     /* use only the degree-0 coefficient (process.py:59-63)             */
+  float term_eps;             /* 0 = integrate all S samples exactly like the reference;
+                                 >0 = stop a ray once transmittance < term_eps (NOT in reference) */
+  uint64_t seed, rng_offset;  /* in-kernel jitter stream                                          */
+  int32_t reuse_packed_grid;  /* 1: workspace already holds this grid packed by a previous call
+                                 on the same workspace (grid values unchanged)                    */
+  int32_t image_width;        /* 0 = unknown. >0: rays are a row-major H x W image (ray r is
+                                 pixel (r / W, r % W)); lets the kernels use 2-D pixel tiles      */
+} VoxeRenderCfg;
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------------------- */
+int voxe_abi_version(void);
+const char* voxe_strerror(int status);
+/* 0 when a gfx950 device is current; VOXE_ERR_NO_DEVICE otherwise. Fills name (may be NULL). */
+int voxe_device_check(char* name, size_t name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray casting -- rendering/volumetric/utils/misc.py:12-50 (cast_rays)
+ *   rot[9] row-major 3x3, trans[3] : HOST pointers (12 floats, copied by value into the launch)
+ *   rays_o, rays_d : [H*W,3]
+ * ---------------------------------------------------------------------------------------------- */
+int voxe_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const float* trans,
+                   float* rays_o, float* rays_d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Volumetric render, forward -- replaces the whole chain
+ *   render_sh_voxel_grid(_attn)            thre3d_reprs/renderers.py:50-163
+ *   -> sample_uniform_points_on_rays       rendering/volumetric/sample.py:15-68 (+ :71-202)
+ *   -> process_points_with_sh_voxel_grid   rendering/volumetric/process.py:20-174
+ *      -> VoxelGrid.forward(_attn)         thre3d_reprs/voxels.py:287-406
+ *      -> evaluate_spherical_harmonics     rendering/volumetric/utils/spherical_harmonics.py:64-132
+ *   -> accumulate_radiance_density_on_rays rendering/volumetric/accumulate.py:31-198
+ *
+ *   rays_o, rays_d [R,3]; jitter [R,S] uniforms in [0,1) or NULL;
+ *   outputs colour [R,Cout] (Cout = 3 SH / 1 attn), depth [R], acc [R], disparity [R]
+ *   (any of depth/acc/disparity may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R);
+
+int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                    const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                    float* colour, float* depth, float* acc, float* disparity,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Volumetric render, backward -- replaces autograd through the chain above
+ * (loss.backward(): modules/trainers.py:350, modules/sds_trainer.py:332,
+ *  modules/attn_grid_trainer.py:372,376).
+ *
+ *   colour/depth/acc: the forward outputs for the same inputs (same jitter / seed);
+ *   d_colour [R,Cout]; d_depth [R] or NULL; d_acc [R] or NULL   (upstream gradients)
+ *   d_densities [X,Y,Z,1] or NULL (skip), d_features [X,Y,Z,F] or NULL (skip);
+ *   accumulate != 0: += into the outputs, else overwrite.
+ * ---------------------------------------------------------------------------------------------- */
+int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                    const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                    const float* colour, const float* depth, const float* acc,
+                    const float* d_colour, const float* d_depth, const float* d_acc,
+                    float* d_densities, float* d_features, int32_t accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-sample probe (test hook for the bit-exact index-math contract): for ray r, sample k writes
+ *   idx  [R,S,3] int32  floor() voxel index of the low trilinear corner (may be -1 or N-1.. out of range)
+ *   inside [R,S] uint8  strict AABB test (voxels.py:263-285)
+ *   zvals [R,S] float   sample depths (sample.py:46-64)
+ *   sigma [R,S] float   post-activated, masked density; rad [R,S,Cout] masked raw radiance (process.py:80-84;
+ *                       -1e10 outside)
+ * any output may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int voxe_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                      const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                      int32_t* idx, uint8_t* inside, float* zvals, float* sigma, float* rad,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-grid passes of the SDS / reconstruction step (HBM-streaming)
+ * ---------------------------------------------------------------------------------------------- */
+/* _density_correlation_loss  modules/sds_trainer.py:507-524
+ *   loss = 1 - mean((a-mean a)(b-mean b)) / (sqrt(var a * var b) + 1e-7)
+ *   a = sds densities (differentiated), b = regular densities (constant); n elements
+ *   loss_out: 1 float; d_a: n floats (d loss / d a * grad_scale), accumulate as above; d_a may be NULL.
+ *   scratch: >= voxe_dcl_scratch_bytes(n) bytes.                                                  */
+size_t voxe_dcl_scratch_bytes(int64_t n);
+int voxe_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale,
+                     float* loss_out, float* d_a, int32_t accumulate,
+                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* _tv_loss_on_grid  modules/sds_trainer.py:563-567 : grid [X,Y,Z,C]
+ *   loss = (mean|diff_x| + mean|diff_y| + mean|diff_z|)/3 ; d_grid accumulates grad_scale * dloss/dgrid */
+size_t voxe_tv_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t C);
+int voxe_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t C, float grad_scale,
+                    float* loss_out, float* d_grid, int32_t accumulate,
+                    void* scratch, size_t scratch_bytes, void* stream);
+
+/* torch.optim.Adam(betas, eps, weight_decay=0, amsgrad=False) single-tensor step
+ *   modules/sds_trainer.py:200-203, modules/trainers.py:247-255; `step` is the 1-based step count. */
+int voxe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+/* scale_voxel_grid_with_required_output_size  thre3d_reprs/voxels.py:409-447
+ *   F.interpolate(mode="trilinear", align_corners=False, recompute_scale_factor=False)
+ *   src [X,Y,Z,C] -> dst [X2,Y2,Z2,C]                                                            */
+int voxe_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, int32_t C,
+                            float* dst, int32_t X2, int32_t Y2, int32_t Z2, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CPU twin == the oracle (oracle/voxe_cpu.c). Same semantics, HOST pointers, no stream/workspace.
+ * TEST INFRASTRUCTURE ONLY: never linked into libvoxe_hip.so, never called by the product path.
+ * ---------------------------------------------------------------------------------------------- */
+int voxe_cpu_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const float* trans,
+                       float* rays_o, float* rays_d);
+int voxe_cpu_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                        const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                        float* colour, float* depth, float* acc, float* disparity);
+int voxe_cpu_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                        const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                        const float* d_colour, const float* d_depth, const float* d_acc,
+                        float* d_densities, float* d_features, int32_t accumulate);
+int voxe_cpu_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                          const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                          int32_t* idx, uint8_t* inside, float* zvals, float* sigma, float* rad);
+int voxe_cpu_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale,
+                         float* loss_out, float* d_a, int32_t accumulate);
+int voxe_cpu_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t C,
+                        float grad_scale, float* loss_out, float* d_grid, int32_t accumulate);
+int voxe_cpu_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                       int64_t n, float lr, float beta1, float beta2, float eps, int64_t step);
+int voxe_cpu_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, int32_t C,
+                                float* dst, int32_t X2, int32_t Y2, int32_t Z2);
+/* number of OpenMP threads the oracle will use (1 when built without OpenMP) */
+int voxe_cpu_num_threads(void);
+/* Philox jitter value the HIP kernels draw for (seed, offset, ray, sample): lets tests replay it */
+float voxe_cpu_philox_uniform(uint64_t seed, uint64_t rng_offset, int64_t ray, int32_t sample);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXE_H_ */

@@ -1,0 +1,207 @@
+"""Pins the CPU oracle (oracle/voxe_cpu.c) to the reference: every check compares the oracle with
+vectors produced by importing TAU-VAILab/Vox-E in the build container (tools/gen_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import KINDS, cfg_from_bounds, grid_from_golden, nan_equal, psnr, rel_l2
+from voxe_hip import abi
+from voxe_hip.desc import make_render_cfg
+
+from oracle import voxe_oracle as vo
+
+# float32 tolerances.  The oracle follows the reference's op order in float32; differences left are
+# libm exp/log vs torch's vectorised versions and the order of the per-ray sums (<= a few ulp).
+FWD_ATOL = 2e-6
+GRAD_REL_L2 = 2e-5
+
+
+def test_linspace_matches_torch():
+    """t_val() in voxe_cpu.c vs torch.linspace (thre3d_atom/rendering/volumetric/sample.py:44):
+    with near=0, far=1 the sample depths are exactly the linspace values."""
+    grid = vo.Grid(np.zeros((2, 2, 2, 1)), np.zeros((2, 2, 2, 3)), [(-1, 1)] * 3)
+    o = np.zeros((1, 3), np.float32)
+    d = np.array([[0, 0, 1]], np.float32)
+    for S in (1, 2, 3, 16, 17, 64, 100, 256, 416, 512, 1024):
+        cfg = make_render_cfg(S, 0.0, 1.0)
+        z = vo.sample_probe(grid, cfg, o, d)["z"][0]
+        ref = torch.linspace(0.0, 1.0, S, dtype=torch.float32).numpy()
+        assert np.array_equal(z, ref), S
+
+
+def test_cast_rays():
+    g = load_golden("cast_rays.npz")
+    tags = sorted({k.split("_")[0] for k in g.files})
+    assert len(tags) == 9
+    for t in tags:
+        h, w, f = g[t + "_hwf"]
+        o, d = vo.cast_rays(int(h), int(w), f, g[t + "_rot"], g[t + "_trans"])
+        np.testing.assert_array_equal(o.reshape(int(h), int(w), 3), g[t + "_origins"])
+        # torch evaluates R @ dirs with a BLAS-ordered dot product: float tolerance
+        np.testing.assert_allclose(d.reshape(int(h), int(w), 3), g[t + "_directions"], rtol=0, atol=3e-7)
+
+
+def _unit_grid():
+    return vo.Grid(np.zeros((2, 2, 2, 1)), np.zeros((2, 2, 2, 3)), [(-1, 1)] * 3)
+
+
+@pytest.mark.parametrize("S", [2, 16, 65, 256])
+@pytest.mark.parametrize("mode", ["uniform", "lindisp"])
+def test_sample_depths_bit_exact(S, mode):
+    g = load_golden("sampling.npz")
+    o, d, b = g["rays_o"], g["rays_d"], g["bounds"]
+    cfg = cfg_from_bounds(b, S, linear_disparity=(mode == "lindisp"))
+    z = vo.sample_probe(_unit_grid(), cfg, o, d)["z"]
+    np.testing.assert_array_equal(z, g[f"{mode}_S{S}_depths"])
+    cfg = cfg_from_bounds(b, S, linear_disparity=(mode == "lindisp"), perturb=True)
+    z = vo.sample_probe(_unit_grid(), cfg, o, d, jitter=g[f"{mode}_S{S}_jitter"])["z"]
+    np.testing.assert_array_equal(z, g[f"{mode}_S{S}_jdepths"])
+
+
+def test_ray_aabb_bounds():
+    g = load_golden("sampling.npz")
+    aabb = [tuple(r) for r in g["aabb"]]
+    grid = vo.Grid(np.zeros((5, 6, 7, 1)), np.zeros((5, 6, 7, 3)), aabb)
+    o, d, b = g["aabb_rays_o"], g["aabb_rays_d"], g["bounds"]
+    cfg = cfg_from_bounds(b, 2, aabb_clip=True)
+    z = vo.sample_probe(grid, cfg, o, d)["z"]  # S=2: z = (near', far') of each ray
+    ref = g["aabb_bounds"]
+    assert (g["aabb_hit"] == 0).sum() > 5 and (g["aabb_hit"] == 1).sum() > 5
+    np.testing.assert_array_equal(z, ref)
+
+
+@pytest.mark.parametrize("tag,kind", [("aniso", "softplus"), ("cube", "softplus"), ("abs", "abs"), ("relu", "relu")])
+def test_voxel_forward_index_math(tag, kind):
+    """VoxelGrid.forward / test_inside_volume (voxels.py:263-342): voxel indices and inside mask are
+    bit-exact, interpolated values agree to float32 rounding."""
+    g = load_golden("voxel_forward.npz")
+    grid = grid_from_golden(g, tag + "_", kind)
+    pts = g[tag + "_points"]
+    # probe the points as 1-sample rays: o = p, d = (0,0,1), near = far = 0  ->  p = o + d*0
+    cfg = make_render_cfg(1, 0.0, 0.0)
+    d = np.tile(np.array([[0, 0, 1]], np.float32), (len(pts), 1))
+    pr = vo.sample_probe(grid, cfg, pts, d)
+    np.testing.assert_array_equal(pr["idx"][:, 0], g[tag + "_i0"])
+    np.testing.assert_array_equal(pr["inside"][:, 0], g[tag + "_inside"])
+    val = g[tag + "_values"]  # [N, 3+1] = cat(features, density) un-masked
+    ins = g[tag + "_inside"]
+    assert 0.2 < ins.mean() < 0.8
+    np.testing.assert_allclose(pr["sigma"][ins, 0], val[ins, 3], rtol=2e-6, atol=2e-6)
+    np.testing.assert_array_equal(pr["sigma"][~ins, 0], 0.0)
+    c0 = np.float32(0.28209479177387814)
+    np.testing.assert_allclose(pr["rad"][ins, 0], c0 * val[ins, :3], rtol=2e-6, atol=2e-6)
+    assert np.all(pr["rad"][~ins] == np.float32(-1e10))
+
+
+def _render_cases():
+    g = load_golden("render_sh0.npz")
+    tags = sorted({k[: -len("colour")] for k in g.files if k.endswith("_colour") and not k.endswith("g_colour")})
+    return tags
+
+
+@pytest.mark.parametrize("tag", _render_cases())
+def test_render_forward_and_grads(tag):
+    g = load_golden("render_sh0.npz")
+    kind = next(k for k in sorted(KINDS, key=len, reverse=True) if tag.startswith(k + "_"))
+    grid = grid_from_golden(g, kind + "_", kind)
+    rest = tag[len(kind) + 1:]
+    kw = {}
+    if rest.startswith("S"):
+        S = int(rest.split("_")[0][1:])
+        kw["white_bkgd"] = rest.split("_")[1] == "w1"
+    else:
+        S = 64
+        kw["white_bkgd"] = True
+        if rest.startswith("jit"):
+            kw["perturb"] = True
+        elif rest.startswith("lindisp"):
+            kw["linear_disparity"] = True
+        elif rest.startswith("clip"):
+            kw["aabb_clip"] = True
+    cfg = cfg_from_bounds(g["bounds"], S, **kw)
+    jit = g[tag + "jitter"] if tag + "jitter" in g.files else None
+    o, d = g["rays_o"], g["rays_d"]
+    out = vo.render_fwd(grid, cfg, o, d, jitter=jit)
+    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["acc"], g[tag + "acc"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["depth"], g[tag + "depth"], rtol=2e-6, atol=FWD_ATOL)
+    nan_equal(out["disparity"], g[tag + "disparity"], rtol=1e-5, atol=1e-6)
+    assert np.isnan(g[tag + "disparity"]).sum() >= 1  # the rays that miss (accumulate.py:85-88)
+    if tag + "grad_densities" in g.files:
+        gd, gf = vo.render_bwd(grid, cfg, o, d, g[tag + "g_colour"], jitter=jit)
+        assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+        assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
+        gd, gf = vo.render_bwd(grid, cfg, o, d, g[tag + "g_colour"], g[tag + "g_depth"], g[tag + "g_acc"], jitter=jit)
+        assert rel_l2(gd, g[tag + "grad2_densities"]) < GRAD_REL_L2
+        assert rel_l2(gf, g[tag + "grad2_features"]) < GRAD_REL_L2
+
+
+@pytest.mark.parametrize("kind", ["softplus", "softplus_soft"])
+@pytest.mark.parametrize("white", [0, 1])
+def test_render_attn(kind, white):
+    g = load_golden("render_attn.npz")
+    grid = grid_from_golden(g, kind + "_", kind, attn=True)
+    tag = f"{kind}_w{white}_"
+    cfg = cfg_from_bounds(g["bounds"], 48, white_bkgd=bool(white))
+    o, d = g["rays_o"], g["rays_d"]
+    out = vo.render_fwd(grid, cfg, o, d)
+    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["depth"], g[tag + "depth"], rtol=2e-6, atol=FWD_ATOL)
+    gd, gf = vo.render_bwd(grid, cfg, o, d, g[tag + "g_colour"])
+    assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+    assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2  # grad w.r.t. VoxelGrid.attn
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["full", "diffuse"])
+def test_render_sh_degrees(deg, mode):
+    g = load_golden("render_shdeg.npz")
+    grid = grid_from_golden(g, f"deg{deg}_", "softplus_soft")
+    tag = f"deg{deg}_{mode}_"
+    cfg = cfg_from_bounds(g["bounds"], 32, white_bkgd=True, sh_degree=deg, render_diffuse=(mode == "diffuse"))
+    o, d = g["rays_o"], g["rays_d"]
+    out = vo.render_fwd(grid, cfg, o, d)
+    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=3e-6)
+    gd, gf = vo.render_bwd(grid, cfg, o, d, g[tag + "g_colour"])
+    assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+    assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
+
+
+def test_grid_ops():
+    g = load_golden("grid_ops.npz")
+    for t in ("a", "b"):
+        loss, grad = vo.dcl_fwd_bwd(g[f"dcl_{t}_sds"], g[f"dcl_{t}_reg"])
+        assert abs(loss - float(g[f"dcl_{t}_loss"])) < 2e-6
+        assert rel_l2(grad, g[f"dcl_{t}_grad"]) < 1e-5
+        loss, grad = vo.tv_fwd_bwd(g[f"tv_{t}_grid"])
+        assert abs(loss - float(g[f"tv_{t}_loss"])) < 2e-6
+        assert rel_l2(grad, g[f"tv_{t}_grad"]) < 1e-6
+    p = g["adam_p0"].copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    for step in range(5):
+        vo.adam_step(p, np.ascontiguousarray(g["adam_grads"][step]), m, v, 0.03, 0.9, 0.999, 1e-8, step + 1)
+        np.testing.assert_allclose(p, g["adam_traj"][step], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("t", ["a", "b", "c", "d"])
+def test_upsample(t):
+    g = load_golden("upsample.npz")
+    src = np.concatenate([g[f"{t}_features"], g[f"{t}_densities"]], axis=-1)
+    ref = np.concatenate([g[f"{t}_up_features"], g[f"{t}_up_densities"]], axis=-1)
+    up = vo.upsample_trilinear(src, ref.shape[:3])
+    np.testing.assert_allclose(up, ref, rtol=0, atol=5e-7)
+
+
+def test_frames_psnr():
+    """cfg1-style image check: 8 cameras @ 64x64 on the 32^3 grid, PSNR >= 40 dB (north_star)."""
+    g = load_golden("frames32.npz")
+    grid = grid_from_golden(g, "", "softplus")
+    h, w, f = g["hwf"]
+    cfg = cfg_from_bounds(g["bounds"], 128, white_bkgd=True)
+    for i in range(8):
+        o, d = vo.cast_rays(int(h), int(w), f, g["rot"][i], g["trans"][i])
+        img = vo.render_fwd(grid, cfg, o, d)["colour"].reshape(int(h), int(w), 3)
+        assert psnr(img, g["frames"][i]) > 100.0  # i.e. identical to ~1e-6
+        assert np.linalg.norm(img - g["frames"][i]) / np.linalg.norm(g["frames"][i]) < 1e-5

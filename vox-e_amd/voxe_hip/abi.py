@@ -1,0 +1,136 @@
+"""ctypes mirror of include/voxe.h (structs, enums, function prototypes).
+
+No torch import here: this module only describes the C ABI.  `declare(lib, prefix)` installs the
+argtypes/restype of every entry point on a loaded library; prefix "voxe_" is the HIP product
+library (libvoxe_hip.so), prefix "voxe_cpu_" is the test oracle (oracle/libvoxe_oracle.so), which
+shares the same signatures minus (workspace, stream).
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+# VoxeStatus
+OK = 0
+ERR_NULL_POINTER = -1
+ERR_BAD_SHAPE = -2
+ERR_UNSUPPORTED = -3
+ERR_WORKSPACE = -4
+ERR_LAUNCH = -5
+ERR_NO_DEVICE = -6
+
+# VoxeAct
+ACT_IDENTITY = 0
+ACT_ABS = 1
+ACT_RELU = 2
+ACT_SOFTPLUS = 3
+
+# VoxeFeatureKind
+FEAT_SH = 0
+FEAT_ATTN = 1
+
+_f3 = C.c_float * 3
+
+
+class VoxeGridDesc(C.Structure):
+    _fields_ = [
+        ("densities", C.c_void_p),
+        ("features", C.c_void_p),
+        ("X", C.c_int32),
+        ("Y", C.c_int32),
+        ("Z", C.c_int32),
+        ("F", C.c_int32),
+        ("aabb_lo", _f3),
+        ("aabb_hi", _f3),
+        ("norm_scale", _f3),
+        ("norm_bias", _f3),
+        ("density_scale", C.c_float),
+        ("density_pre_act", C.c_int32),
+        ("density_post_act", C.c_int32),
+        ("feature_kind", C.c_int32),
+    ]
+
+
+class VoxeRenderCfg(C.Structure):
+    _fields_ = [
+        ("num_samples", C.c_int32),
+        ("near", C.c_float),
+        ("far", C.c_float),
+        ("perturb", C.c_int32),
+        ("linear_disparity", C.c_int32),
+        ("aabb_clip", C.c_int32),
+        ("white_bkgd", C.c_int32),
+        ("sh_degree", C.c_int32),
+        ("render_diffuse", C.c_int32),
+        ("term_eps", C.c_float),
+        ("seed", C.c_uint64),
+        ("rng_offset", C.c_uint64),
+        ("reuse_packed_grid", C.c_int32),
+        ("image_width", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_GD = C.POINTER(VoxeGridDesc)
+_RC = C.POINTER(VoxeRenderCfg)
+
+# name -> (restype, argtypes, takes_workspace, takes_stream); the oracle twin drops the last two groups
+_COMMON = {
+    "cast_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], False, True),
+    "render_fwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P], True, True),
+    "render_bwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32], True, True),
+    "sample_probe": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P], True, True),
+    "dcl_fwd_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P, C.c_int32], True, True),
+    "tv_fwd_bwd": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int32], True, True),
+    "adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64], False, True),
+    "upsample_trilinear": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32], False, True),
+}
+
+# the CPU twin's render_bwd does not take the forward outputs (colour, depth, acc): it recomputes
+_CPU_RENDER_BWD = [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32]
+
+HIP_ONLY = {
+    "abi_version": (C.c_int, []),
+    "strerror": (C.c_char_p, [C.c_int]),
+    "device_check": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "workspace_bytes": (C.c_size_t, [_GD, _RC, C.c_int64]),
+    "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+}
+
+CPU_ONLY = {
+    "num_threads": (C.c_int, []),
+    "philox_uniform": (C.c_float, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32]),
+}
+
+
+def hip_symbols():
+    """Every symbol include/voxe.h declares for libvoxe_hip.so."""
+    return ["voxe_" + n for n in list(_COMMON) + list(HIP_ONLY)]
+
+
+def cpu_symbols():
+    """Every symbol include/voxe.h declares for the oracle."""
+    return ["voxe_cpu_" + n for n in list(_COMMON) + list(CPU_ONLY)]
+
+
+def declare(lib, prefix):
+    """Install prototypes on `lib` for the given family ("voxe_" or "voxe_cpu_")."""
+    cpu = prefix == "voxe_cpu_"
+    for name, (res, args, ws, st) in _COMMON.items():
+        fn = getattr(lib, prefix + name)
+        a = list(args)
+        if cpu and name == "render_bwd":
+            a = list(_CPU_RENDER_BWD)
+        if not cpu:
+            if ws:
+                a += [_P, C.c_size_t]
+            if st:
+                a += [_P]
+        fn.restype = res
+        fn.argtypes = a
+    extra = CPU_ONLY if cpu else HIP_ONLY
+    for name, (res, args) in extra.items():
+        fn = getattr(lib, prefix + name)
+        fn.restype = res
+        fn.argtypes = list(args)
+    return lib
