@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered rays/s (fwd+bwd) of the voxel-grid volumetric render hot path on MI355X.
+
+Workload (BASELINE.json configs[1] / SURVEY.md 8d): 160^3 SH-0 softplus grid (U(-1,1) init, seed 42,
+expected_density_scale 100/3), one 400x400 synthetic camera per GPU, S = 256 samples per ray with the
+reference's always-on stratified jitter (in-kernel Philox), white background, upstream gradient
+d_colour ~ N(0,1) (seed 43).  One STEP = render forward + render backward through the C ABI
+(pack + forward kernel + gradient memset + backward kernel + unpack), the RCCL all-reduce of the
+voxel-grid gradient when N > 1, and the fused Adam update of both grid tensors (so the grid really
+changes every step and nothing is cached across steps).  Inputs are resident in HBM before timing.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel, HIP-event timed on the launch
+stream through voxe_profile_*) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded
+sample) objects described in DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=160)
+    ap.add_argument("--image", type=int, default=400)
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--scene", choices=["random", "sphere"], default="random")
+    ap.add_argument("--term-eps", type=float, default=0.0, help="early ray termination (NOT in the reference); 0 = off")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=200, help="side of the image the CPU oracle is timed on")
+    ap.add_argument("--no-adam", action="store_true")
+    ap.add_argument("--no-jitter", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    from synth import FAR, NEAR, RADIUS, focal_for, random_grid, sphere_grid, synth_pose_angles
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+    from voxe_hip import abi, ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    G, HW, S = args.grid, args.image, args.samples
+    dens_cpu, feat_cpu = random_grid(G) if args.scene == "random" else sphere_grid(G)
+    aabb = ((-1.5, 1.5),) * 3
+    spec = ops.GridSpec(aabb=aabb, density_scale=100.0 / 3.0, density_pre_act=abi.ACT_IDENTITY,
+                        density_post_act=abi.ACT_SOFTPLUS)
+    nvox = G ** 3
+    # one flat gradient / parameter buffer: features first, densities last -> ONE all-reduce message
+    flat_p = torch.empty(nvox * 4, dtype=torch.float32, device=dev)
+    flat_g = torch.zeros_like(flat_p)
+    feat = flat_p[: nvox * 3].view(G, G, G, 3)
+    dens = flat_p[nvox * 3:].view(G, G, G, 1)
+    feat.copy_(feat_cpu)
+    dens.copy_(dens_cpu)
+    d_feat = flat_g[: nvox * 3].view(G, G, G, 3)
+    d_dens = flat_g[nvox * 3:].view(G, G, G, 1)
+    exp_avg, exp_avg_sq = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
+
+    # weak scaling: every rank renders its own camera (cameras rank, rank + world, ... of the 100-view set)
+    yaw, pitch = synth_pose_angles(3 + rank, 100)
+    pose = pose_spherical(yaw, pitch, RADIUS)
+    rays_o, rays_d = ops.cast_rays(HW, HW, focal_for(HW), pose.rotation, pose.translation, dev)
+    R = rays_o.shape[0]
+    params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=not args.no_jitter, white_bkgd=True,
+                              term_eps=args.term_eps, image_width=HW)
+    gen = torch.Generator().manual_seed(43 + rank)
+    g_colour = torch.randn((R, 3), generator=gen).to(dev)
+    colour = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    disp = torch.empty((R, 1), dtype=torch.float32, device=dev)
+    ws = ops.Workspace()
+
+    # in-AABB sample count of this camera (un-jittered depths), outside the timed region
+    probe_params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=HW)
+    inside = ops.sample_probe(spec, probe_params, dens, feat, rays_o, rays_d, outputs=("inside",))["inside"]
+    s_in_total = int(inside.sum().item())
+    del inside
+
+    step_no = [0]
+
+    def step():
+        step_no[0] += 1
+        rng = (42, step_no[0])
+        ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
+        ops.render_bwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, g_colour, None,
+                            None, d_dens, d_feat, ws, rng)
+        if dist is not None:
+            dist.all_reduce(flat_g)  # sum over ranks (RCCL, xGMI)
+        if not args.no_adam:
+            ops.adam_step_(flat_p, flat_g, exp_avg, exp_avg_sq, step_no[0], lr=1e-4)
+        else:
+            ws.invalidate()  # without the optimiser the grid would look unchanged: force the re-pack
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_read()
+    ops.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    rays_per_s = world * R * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, voxe_profile_*) -------------
+    ms_fwd = prof["ms_fwd"] / max(prof["n_fwd"], 1)
+    ms_bwd = prof["ms_bwd"] / max(prof["n_bwd"], 1)
+    # algorithmic bytes: per in-AABB sample 8 corners x 4 ch x 4 B = 128 B read (fwd),
+    # 128 B re-read + 128 B gradient scatter (bwd); per ray 24 B rays + outputs/upstream I/O
+    bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
+    bytes_bwd = s_in_total * 256 + R * (24 + 12 + 20)
+    if ms_bwd >= ms_fwd:
+        kname, kbytes, kms = "render_bwd_kernel<3,1,1>", bytes_bwd, ms_bwd
+    else:
+        kname, kbytes, kms = "render_fwd_kernel<3,1,1>", bytes_fwd, ms_fwd
+    achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": kname, "alg_bytes_per_launch": int(kbytes), "launch_ms": round(kms, 4),
+        "phases_ms": {"pack": round(prof["ms_pack"] / max(prof["n_pack"], 1), 4), "fwd": round(ms_fwd, 4),
+                      "memset": round(prof["ms_memset"] / max(prof["n_memset"], 1), 4), "bwd": round(ms_bwd, 4),
+                      "unpack": round(prof["ms_unpack"] / max(prof["n_unpack"], 1), 4)},
+        "in_aabb_samples_per_ray": round(s_in_total / R, 2),
+        # whole-step figure in BASELINE.md's convention: rays/s x (S_in*384 + 72) B, per GPU
+        "step_alg_gbs_per_gpu": round(rays_per_s / world * (s_in_total / R * 384 + 72) / 1e9, 2),
+    }
+
+    # ---- CPU baseline: the oracle (a C port of the reference path) on the host cores, bounded sample ----
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import voxe_oracle as vo
+        from voxe_hip.desc import make_render_cfg
+
+        hw = args.cpu_sample
+        grid = vo.Grid(dens_cpu.numpy(), feat_cpu.numpy(), aabb, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+        o, d = vo.cast_rays(hw, hw, focal_for(hw), pose.rotation.numpy(), pose.translation.numpy())
+        cfg = make_render_cfg(S, NEAR, FAR, perturb=not args.no_jitter, white_bkgd=True, seed=42, rng_offset=1)
+        gc = np.random.default_rng(43).standard_normal((hw * hw, 3)).astype(np.float32)
+        t1 = time.perf_counter()
+        vo.render_fwd(grid, cfg, o, d)
+        vo.render_bwd(grid, cfg, o, d, gc)
+        dt = time.perf_counter() - t1
+        cpu_baseline = {
+            "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": vo.num_threads(), "kind": "port",
+            "sample": f"{hw}x{hw} rays of camera 3 (same {G}^3 grid, S={S}, jitter on), 1 forward + 1 backward "
+                      f"of oracle/voxe_cpu.c with OpenMP, {dt:.1f} s",
+        }
+
+    if rank == 0:
+        out = {
+            "metric": "rendered rays/sec (fwd+bwd)", "value": round(rays_per_s, 1), "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{G}^3 SH-0 softplus ReLU-field grid ({args.scene}), one {HW}x{HW} camera per GPU, "
+                            f"S={S}, jitter {'off' if args.no_jitter else 'on'}, white bkgd; step = render fwd + bwd"
+                            f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
+                            f"{'' if args.no_adam else ' + Adam'}",
+                "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
+                "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
+                "term_eps": args.term_eps,
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,6 +101,20 @@ const char* voxe_strerror(int status);
 int voxe_device_check(char* name, size_t name_len);
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-phase device timing (measurement hook used by bench.py; no reference counterpart).
+ * While enabled, every render call brackets its phases with hipEvents ON THE CALLER'S STREAM
+ * (pack, forward kernel, gradient memset, backward kernel, unpack).  voxe_profile_read() waits for
+ * the recorded events and returns the summed milliseconds / launch counts since voxe_profile_enable(1).
+ * At most 512 phase records are kept between enable and read; later ones are dropped (n_dropped).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct VoxeProfile {
+  double ms_pack, ms_fwd, ms_memset, ms_bwd, ms_unpack;
+  int32_t n_pack, n_fwd, n_memset, n_bwd, n_unpack, n_dropped;
+} VoxeProfile;
+int voxe_profile_enable(int32_t on);
+int voxe_profile_read(VoxeProfile* out);
+
+/* ------------------------------------------------------------------------------------------------
  * Ray casting -- rendering/volumetric/utils/misc.py:12-50 (cast_rays)
  *   rot[9] row-major 3x3, trans[3] : HOST pointers (12 floats, copied by value into the launch)
  *   rays_o, rays_d : [H*W,3]

@@ -1,0 +1,284 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle and the golden vectors.
+
+Bars (BASELINE.json north_star): voxel-index math bit-exact; float outputs within the tolerances
+written below; frames PSNR >= 40 dB.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import KINDS, cfg_from_bounds, grid_from_golden, nan_equal, psnr, rel_l2
+from voxe_hip import abi
+from voxe_hip.desc import make_render_cfg
+
+from oracle import voxe_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import gpu_helpers as gh
+
+# float32 tolerances HIP vs oracle: device expf/log1pf vs glibc (<= 2 ulp each) and float vs double
+# accumulation of <= 1024 terms
+FWD_ATOL = 5e-6
+GRAD_REL_L2 = 1e-4
+
+
+def _golden_render_case(tag):
+    g = load_golden("render_sh0.npz")
+    kind = next(k for k in sorted(KINDS, key=len, reverse=True) if tag.startswith(k + "_"))
+    grid = grid_from_golden(g, kind + "_", kind)
+    rest = tag[len(kind) + 1:]
+    kw = {}
+    if rest.startswith("S"):
+        S = int(rest.split("_")[0][1:])
+        kw["white_bkgd"] = rest.split("_")[1] == "w1"
+    else:
+        S = 64
+        kw["white_bkgd"] = True
+        if rest.startswith("jit"):
+            kw["perturb"] = True
+        elif rest.startswith("lindisp"):
+            kw["linear_disparity"] = True
+        elif rest.startswith("clip"):
+            kw["aabb_clip"] = True
+    cfg = cfg_from_bounds(g["bounds"], S, **kw)
+    jit = g[tag + "jitter"] if tag + "jitter" in g.files else None
+    return g, grid, cfg, jit
+
+
+def _render_tags():
+    g = load_golden("render_sh0.npz")
+    return sorted({k[: -len("colour")] for k in g.files if k.endswith("_colour") and not k.endswith("g_colour")})
+
+
+def test_library_and_device():
+    from voxe_hip import runtime
+
+    L = runtime.lib()
+    assert L.voxe_abi_version() == abi.ABI_VERSION
+    runtime.ensure_gfx950(gh.DEV)
+
+
+@pytest.mark.parametrize("tag", _render_tags())
+def test_probe_bit_exact_and_render_vs_golden(tag):
+    """Index math bit-exact vs the oracle; forward/backward vs the reference goldens."""
+    g, grid, cfg, jit = _golden_render_case(tag)
+    o, d = g["rays_o"], g["rays_d"]
+    ref = vo.sample_probe(grid, cfg, o, d, jitter=jit)
+    got = gh.hip_probe(grid, cfg, o, d, jitter=jit)
+    np.testing.assert_array_equal(got["z"], ref["z"])
+    np.testing.assert_array_equal(got["idx"], ref["idx"])
+    np.testing.assert_array_equal(got["inside"], ref["inside"])
+    np.testing.assert_allclose(got["sigma"], ref["sigma"], rtol=3e-6, atol=3e-6)
+    np.testing.assert_allclose(got["rad"], ref["rad"], rtol=3e-6, atol=3e-6)
+
+    out = gh.hip_forward(grid, cfg, o, d, jitter=jit)
+    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["acc"], g[tag + "acc"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["depth"], g[tag + "depth"], rtol=3e-6, atol=FWD_ATOL)
+    nan_equal(out["disparity"], g[tag + "disparity"], rtol=2e-5, atol=1e-6)
+    if tag + "grad_densities" in g.files:
+        gd, gf = gh.hip_backward(grid, cfg, o, d, g[tag + "g_colour"], jitter=jit)
+        assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+        assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
+        gd, gf = gh.hip_backward(grid, cfg, o, d, g[tag + "g_colour"], g[tag + "g_depth"], g[tag + "g_acc"], jitter=jit)
+        assert rel_l2(gd, g[tag + "grad2_densities"]) < GRAD_REL_L2
+        assert rel_l2(gf, g[tag + "grad2_features"]) < GRAD_REL_L2
+
+
+@pytest.mark.parametrize("kind", ["softplus", "softplus_soft"])
+@pytest.mark.parametrize("white", [0, 1])
+def test_attn_variant(kind, white):
+    g = load_golden("render_attn.npz")
+    grid = grid_from_golden(g, kind + "_", kind, attn=True)
+    tag = f"{kind}_w{white}_"
+    cfg = cfg_from_bounds(g["bounds"], 48, white_bkgd=bool(white))
+    o, d = g["rays_o"], g["rays_d"]
+    out = gh.hip_forward(grid, cfg, o, d)
+    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["depth"], g[tag + "depth"], rtol=3e-6, atol=FWD_ATOL)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, g[tag + "g_colour"])
+    assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+    assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["full", "diffuse"])
+def test_sh_degrees(deg, mode):
+    g = load_golden("render_shdeg.npz")
+    grid = grid_from_golden(g, f"deg{deg}_", "softplus_soft")
+    tag = f"deg{deg}_{mode}_"
+    cfg = cfg_from_bounds(g["bounds"], 32, white_bkgd=True, sh_degree=deg, render_diffuse=(mode == "diffuse"))
+    o, d = g["rays_o"], g["rays_d"]
+    out = gh.hip_forward(grid, cfg, o, d)
+    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=1e-5)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, g[tag + "g_colour"])
+    assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+    assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
+
+
+def test_philox_jitter_matches_oracle_stream():
+    """perturb with no jitter tensor: the in-kernel Philox stream equals the oracle's, depths bit-exact."""
+    g = load_golden("render_sh0.npz")
+    grid = grid_from_golden(g, "softplus_soft_", "softplus_soft")
+    o, d = g["rays_o"], g["rays_d"]
+    seed, off = 0x1234_5678_9ABC_DEF0, (7 << 32) + 99
+    cfg = make_render_cfg(64, 1.8, 6.6, perturb=True, white_bkgd=True, seed=seed, rng_offset=off)
+    ref = vo.sample_probe(grid, cfg, o, d)
+    got = gh.hip_probe(grid, cfg, o, d, rng=(seed, off))
+    np.testing.assert_array_equal(got["z"], ref["z"])
+    np.testing.assert_array_equal(got["idx"], ref["idx"])
+    out = gh.hip_forward(grid, cfg, o, d, rng=(seed, off))
+    np.testing.assert_allclose(out["colour"], vo.render_fwd(grid, cfg, o, d)["colour"], rtol=0, atol=FWD_ATOL)
+    # a different offset gives a different stream
+    got2 = gh.hip_probe(grid, cfg, o, d, rng=(seed, off + 1))
+    assert not np.array_equal(got["z"], got2["z"])
+
+
+def test_edge_cases_empty_single_and_s1():
+    g = load_golden("render_sh0.npz")
+    grid = grid_from_golden(g, "relu_", "relu")
+    cfg = make_render_cfg(16, 1.8, 6.6, white_bkgd=True)
+    out = gh.hip_forward(grid, cfg, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert out["colour"].shape == (0, 3)
+    o, d = g["rays_o"][100:101], g["rays_d"][100:101]
+    np.testing.assert_allclose(gh.hip_forward(grid, cfg, o, d)["colour"], vo.render_fwd(grid, cfg, o, d)["colour"],
+                               rtol=0, atol=FWD_ATOL)
+    cfg1 = make_render_cfg(1, 3.9, 6.6, white_bkgd=False)  # single sample: its delta is the 1e10 tail
+    o, d = g["rays_o"], g["rays_d"]
+    a, b = gh.hip_forward(grid, cfg1, o, d), vo.render_fwd(grid, cfg1, o, d)
+    np.testing.assert_allclose(a["colour"], b["colour"], rtol=0, atol=FWD_ATOL)
+    nan_equal(a["disparity"], b["disparity"], rtol=2e-5, atol=1e-6)
+
+
+def test_image_tiles_equal_linear_order():
+    """image_width (2-D pixel tiles) changes the thread->ray mapping only: per-ray results are
+    bit-identical to the linear mapping; non-multiple-of-16 image sizes are covered."""
+    g = load_golden("frames32.npz")
+    grid = grid_from_golden(g, "", "softplus")
+    for (h, w) in ((40, 56), (33, 47)):
+        o, d = vo.cast_rays(h, w, 0.5 * w / np.tan(0.5 * 0.6911112), g["rot"][2], g["trans"][2])
+        cfg = cfg_from_bounds(g["bounds"], 96, white_bkgd=True)
+        lin = gh.hip_forward(grid, cfg, o, d)
+        til = gh.hip_forward(grid, cfg, o, d, image_width=w)
+        for k in ("colour", "depth", "acc"):
+            np.testing.assert_array_equal(lin[k], til[k])
+        gc = np.random.default_rng(0).standard_normal((h * w, 3)).astype(np.float32)
+        gd0, gf0 = gh.hip_backward(grid, cfg, o, d, gc)
+        gd1, gf1 = gh.hip_backward(grid, cfg, o, d, gc, image_width=w)
+        assert rel_l2(gd1, gd0) < 1e-5 and rel_l2(gf1, gf0) < 1e-5  # atomic order differs only
+
+
+def test_frames_psnr_through_volumetric_model():
+    """cfg1: 8 synthetic cameras @ 64x64 on the 32^3 grid through the thre3d_atom API; PSNR >= 40 dB
+    and L2 <= 1e-3 vs the reference frames (north_star)."""
+    from thre3d_atom.modules.volumetric_model import VolumetricModel
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelSize
+    from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics, CameraPose
+
+    g = load_golden("frames32.npz")
+    vg = VoxelGrid(torch.from_numpy(g["densities"]), torch.from_numpy(g["features"]),
+                   VoxelSize(*[float(v) for v in g["voxel_size"]]),
+                   density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.Softplus(),
+                   expected_density_scale=100.0 / 3.0, tunable=True)
+    vm = VolumetricModel(vg, render_sh_voxel_grid,
+                         SHVoxGridRenderConfig(128, CameraBounds(*[float(v) for v in g["bounds"]]), white_bkgd=True),
+                         device=gh.DEV)
+    h, w, f = g["hwf"]
+    intr = CameraIntrinsics(int(h), int(w), float(f))
+    for i in range(8):
+        pose = CameraPose(torch.from_numpy(g["rot"][i]), torch.from_numpy(g["trans"][i]))
+        out = vm.render(pose, intr, perturb_sampled_points=False)
+        img = out.colour.cpu().numpy()
+        assert img.shape == (64, 64, 3) and out.depth.shape == (64, 64, 1)
+        assert psnr(img, g["frames"][i]) >= 40.0
+        assert np.linalg.norm(img - g["frames"][i]) / np.linalg.norm(g["frames"][i]) < 1e-3
+        assert psnr(img, g["frames"][i]) > 90.0  # in fact equal to float rounding
+
+
+def test_checkpoint_roundtrip_and_autograd_api():
+    """Load a checkpoint WRITTEN BY THE REFERENCE, render it, and check autograd through render_rays."""
+    import os
+
+    from conftest import GOLDEN
+    from thre3d_atom.modules.volumetric_model import create_volumetric_model_from_saved_model
+    from thre3d_atom.rendering.volumetric.render_interface import Rays
+    from thre3d_atom.thre3d_reprs.voxels import create_voxel_grid_from_saved_info_dict
+
+    vm, extra = create_volumetric_model_from_saved_model(
+        os.path.join(GOLDEN, "ref_checkpoint.pth"), create_voxel_grid_from_saved_info_dict, device=gh.DEV)
+    r = load_golden("ref_checkpoint_render.npz")
+    rays = Rays(gh.t(r["rays_o"]), gh.t(r["rays_d"]))
+    out = vm.render_rays(rays, perturb_sampled_points=False)
+    np.testing.assert_allclose(out.colour.detach().cpu().numpy(), r["colour"], rtol=0, atol=FWD_ATOL)
+    out.colour.sum().backward()
+    assert vm.thre3d_repr.densities.grad is not None and vm.thre3d_repr.features.grad.abs().sum() > 0
+    with pytest.raises(ValueError):
+        vm.render_rays(rays, not_a_field=1)
+    # default config has perturb_sampled_points=True: in-kernel jitter, reproducible under manual_seed
+    torch.manual_seed(5)
+    a = vm.render_rays(rays).colour
+    torch.manual_seed(5)
+    b = vm.render_rays(rays).colour
+    c = vm.render_rays(rays).colour
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_grid_ops_vs_golden_and_oracle():
+    from voxe_hip import ops
+
+    g = load_golden("grid_ops.npz")
+    for tname in ("a", "b"):
+        sds = gh.t(g[f"dcl_{tname}_sds"], True)
+        loss = ops.density_correlation_loss(sds, gh.t(g[f"dcl_{tname}_reg"]))
+        (loss * 200.0).backward()
+        assert abs(float(loss) - float(g[f"dcl_{tname}_loss"])) < 2e-6
+        assert rel_l2(gh.n(sds.grad) / 200.0, g[f"dcl_{tname}_grad"]) < 1e-5
+        grid = gh.t(g[f"tv_{tname}_grid"], True)
+        tv = ops.tv_loss_on_grid(grid)
+        tv.backward()
+        assert abs(float(tv) - float(g[f"tv_{tname}_loss"])) < 2e-6
+        assert rel_l2(gh.n(grid.grad), g[f"tv_{tname}_grad"]) < 1e-6
+    p = gh.t(g["adam_p0"].copy())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(5):
+        ver = p._version
+        ops.adam_step_(p, gh.t(g["adam_grads"][step]), m, v, step + 1, lr=0.03)
+        assert p._version > ver
+        np.testing.assert_allclose(gh.n(p), g["adam_traj"][step], rtol=1e-6, atol=1e-7)
+    u = load_golden("upsample.npz")
+    for tname in ("a", "b", "c", "d"):
+        src = np.concatenate([u[f"{tname}_features"], u[f"{tname}_densities"]], axis=-1)
+        ref = np.concatenate([u[f"{tname}_up_features"], u[f"{tname}_up_densities"]], axis=-1)
+        up = ops.upsample_trilinear(gh.t(src), ref.shape[:3])
+        np.testing.assert_allclose(gh.n(up), ref, rtol=0, atol=5e-7)
+    c = load_golden("cast_rays.npz")
+    for tag in sorted({k.split("_")[0] for k in c.files}):
+        h, w, f = c[tag + "_hwf"]
+        ro, rd = ops.cast_rays(int(h), int(w), float(f), c[tag + "_rot"], c[tag + "_trans"], gh.DEV)
+        np.testing.assert_array_equal(gh.n(ro).reshape(int(h), int(w), 3), c[tag + "_origins"])
+        np.testing.assert_allclose(gh.n(rd).reshape(int(h), int(w), 3), c[tag + "_directions"], rtol=0, atol=3e-7)
+        o_ro, o_rd = vo.cast_rays(int(h), int(w), f, c[tag + "_rot"], c[tag + "_trans"])
+        np.testing.assert_array_equal(gh.n(rd), o_rd)  # HIP == oracle bit for bit
+
+
+def test_large_grid_ops_vs_oracle():
+    """160^3-size whole-grid passes vs the oracle (DCL + TV on the density grid)."""
+    from voxe_hip import ops
+
+    rng = np.random.default_rng(3)
+    reg = rng.uniform(-1, 1, (96, 96, 96, 1)).astype(np.float32)
+    sds = (reg + 0.2 * rng.standard_normal(reg.shape)).astype(np.float32)
+    a = gh.t(sds, True)
+    loss = ops.density_correlation_loss(a, gh.t(reg))
+    loss.backward()
+    ref_loss, ref_grad = vo.dcl_fwd_bwd(sds, reg)
+    assert abs(float(loss) - ref_loss) < 2e-6 and rel_l2(gh.n(a.grad), ref_grad) < 1e-5
+    grid = gh.t(sds, True)
+    tv = ops.tv_loss_on_grid(grid)
+    tv.backward()
+    ref_tv, ref_tvg = vo.tv_fwd_bwd(sds)
+    assert abs(float(tv) - ref_tv) < 2e-6 and rel_l2(gh.n(grid.grad), ref_tvg) < 1e-6

@@ -1,0 +1,171 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/voxe.h
+declares, descriptor construction, API containers, config override rules, checkpoint loading.
+No compute call is made (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from voxe_hip import abi
+from voxe_hip.desc import make_grid_desc, make_render_cfg, norm_constants
+
+
+def _declared(prefix):
+    text = open(os.path.join(ROOT, "include", "voxe.h")).read()
+    names = set(re.findall(r"\b(voxe_[a-z0-9_]+)\s*\(", text))
+    if prefix == "voxe_cpu_":
+        return sorted(n for n in names if n.startswith("voxe_cpu_"))
+    return sorted(n for n in names if not n.startswith("voxe_cpu_"))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    from voxe_hip import build
+
+    path = build.build()
+    handle = ctypes.CDLL(path)
+    declared = _declared("voxe_")
+    assert set(declared) == set(abi.hip_symbols()), "abi.py and voxe.h disagree"
+    for name in declared:
+        assert hasattr(handle, name), f"{name} missing from libvoxe_hip.so"
+    abi.declare(handle, "voxe_")
+    assert handle.voxe_abi_version() == abi.ABI_VERSION
+    assert handle.voxe_strerror(-4).decode().startswith("workspace")
+    # argument validation happens before any device work
+    g = make_grid_desc(0, 0, (4, 4, 4), 3, [(-1, 1)] * 3, 1.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    c = make_render_cfg(8, 1.0, 2.0)
+    assert handle.voxe_render_fwd(ctypes.byref(g), ctypes.byref(c), None, None, 4, None, None, None, None, None, None, 0, None) == abi.ERR_NULL_POINTER
+    g.densities, g.features = 8, 8
+    g.F = 5
+    assert handle.voxe_render_fwd(ctypes.byref(g), ctypes.byref(c), 8, 8, 4, None, 8, None, None, None, 8, 1 << 20, None) == abi.ERR_BAD_SHAPE
+    g.F = 3
+    g.density_post_act = 9
+    assert handle.voxe_render_fwd(ctypes.byref(g), ctypes.byref(c), 8, 8, 4, None, 8, None, None, None, 8, 1 << 20, None) == abi.ERR_UNSUPPORTED
+    g.density_post_act = abi.ACT_RELU
+    assert handle.voxe_render_fwd(ctypes.byref(g), ctypes.byref(c), 8, 8, 4, None, 8, None, None, None, None, 0, None) == abi.ERR_WORKSPACE
+    assert handle.voxe_workspace_bytes(ctypes.byref(g), ctypes.byref(c), 4) == 2 * 4 * 4 * 4 * 4 * 4
+
+
+def test_oracle_library_exports_every_declared_symbol():
+    from oracle import voxe_oracle as vo
+
+    handle = ctypes.CDLL(vo.build())
+    declared = _declared("voxe_cpu_")
+    assert set(declared) == set(abi.cpu_symbols())
+    for name in declared:
+        assert hasattr(handle, name)
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirror vs the C compiler's view of include/voxe.h (sizes and a few offsets)."""
+    import subprocess
+    import tempfile
+
+    src = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "voxe.h"
+    int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(VoxeGridDesc), offsetof(VoxeGridDesc, aabb_lo),
+             offsetof(VoxeGridDesc, density_scale), sizeof(VoxeRenderCfg), offsetof(VoxeRenderCfg, seed),
+             offsetof(VoxeRenderCfg, reuse_packed_grid), offsetof(VoxeRenderCfg, image_width));
+      return 0; }'''
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "t.c")
+        open(p, "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
+        vals = [int(v) for v in subprocess.check_output([exe]).split()]
+    G, R = abi.VoxeGridDesc, abi.VoxeRenderCfg
+    assert vals == [ctypes.sizeof(G), G.aabb_lo.offset, G.density_scale.offset, ctypes.sizeof(R), R.seed.offset,
+                    R.reuse_packed_grid.offset, R.image_width.offset]
+
+
+def test_norm_constants_are_float32_like_reference():
+    scale, bias = norm_constants([(-1.5, 1.5), (-0.775, 0.775), (0.1, 0.9)])
+    for (lo, hi), s, b in zip([(-1.5, 1.5), (-0.775, 0.775), (0.1, 0.9)], scale, bias):
+        es = (np.float32(1) - np.float32(-1)) / (np.float32(hi) - np.float32(lo))
+        assert s == es and b == np.float32(-1) - np.float32(lo) * es and s.dtype == np.float32
+
+
+def test_api_containers_and_config_rules():
+    from thre3d_atom.modules.volumetric_model import VolumetricModel
+    from thre3d_atom.rendering.volumetric.render_interface import Rays, RenderOut, RenderOutAttn
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig
+    from thre3d_atom.utils.imaging_utils import CameraBounds
+
+    r = Rays(torch.zeros(10, 3), torch.ones(10, 3), image_shape=(2, 5))
+    assert len(r) == 10 and len(r[2:5]) == 3 and r[2:5].image_shape is None
+    with pytest.raises(AssertionError):
+        Rays(torch.zeros(10, 3), torch.zeros(9, 3))
+    with pytest.raises(AssertionError):
+        Rays(torch.zeros(10, 2), torch.zeros(10, 2))
+    out = RenderOut(torch.zeros(4, 3, requires_grad=True), torch.zeros(4, 1))
+    assert out.extra == {} and not out.detach().colour.requires_grad
+    with pytest.raises(AssertionError):
+        RenderOut(torch.zeros(4, 2), torch.zeros(4, 1))
+    with pytest.raises(AssertionError):
+        RenderOutAttn(torch.zeros(4, 3), torch.zeros(4, 1))
+    cfg = SHVoxGridRenderConfig(64, CameraBounds(1.0, 2.0))
+    assert cfg.perturb_sampled_points and cfg.parallel_rays_chunk_size == 32768 and cfg.render_num_samples_per_ray == 1024
+    upd = VolumetricModel._update_render_config(cfg, {"white_bkgd": True, "num_samples_per_ray": 8})
+    assert upd.white_bkgd and upd.num_samples_per_ray == 8 and not cfg.white_bkgd
+    with pytest.raises(ValueError):
+        VolumetricModel._update_render_config(cfg, {"no_such_field": 1})
+
+
+def test_voxel_grid_geometry_and_activation_mapping():
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelGridLocation, VoxelSize, density_activation_codes
+    from voxe_hip.runtime import VoxeError
+
+    vg = VoxelGrid(torch.zeros(5, 6, 7, 1), torch.zeros(5, 6, 7, 3), VoxelSize(0.31, 0.27, 0.23),
+                   VoxelGridLocation(0.5, 0.0, -0.25), tunable=True)
+    assert vg.grid_dims == (5, 6, 7)
+    assert vg.aabb.x_range == (0.5 - 5 * 0.31 / 2, 0.5 + 5 * 0.31 / 2)
+    assert set(vg.state_dict().keys()) == {"_densities", "_features"}
+    pts = torch.tensor([[0.5, 0.0, -0.25], [10.0, 0.0, 0.0], [vg.aabb.x_range[0], 0.0, -0.25]])
+    assert vg.test_inside_volume(pts)[:, 0].tolist() == [True, False, False]
+    assert density_activation_codes(torch.abs, torch.nn.Identity()) == (abi.ACT_ABS, abi.ACT_IDENTITY)
+    assert density_activation_codes(torch.nn.Identity(), torch.nn.Softplus()) == (abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    assert density_activation_codes(torch.nn.Identity(), torch.nn.ReLU()) == (abi.ACT_IDENTITY, abi.ACT_RELU)
+    with pytest.raises(VoxeError):
+        density_activation_codes(torch.nn.Identity(), torch.nn.Softplus(beta=2))
+    with pytest.raises(VoxeError):
+        density_activation_codes(torch.tanh, torch.nn.Identity())
+    spec = vg.voxe_grid_spec()
+    assert spec.density_pre_act == abi.ACT_ABS and spec.feature_kind == abi.FEAT_SH
+
+
+def test_reference_checkpoint_loads_and_product_refuses_cpu():
+    from thre3d_atom.modules.volumetric_model import create_volumetric_model_from_saved_model
+    from thre3d_atom.rendering.volumetric.render_interface import Rays
+    from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid
+    from thre3d_atom.thre3d_reprs.voxels import (
+        create_voxel_grid_from_saved_info_dict,
+        create_voxel_grid_from_saved_info_dict_attn,
+    )
+    from voxe_hip.runtime import VoxeError
+
+    path = os.path.join(GOLDEN, "ref_checkpoint.pth")
+    vm, extra = create_volumetric_model_from_saved_model(path, create_voxel_grid_from_saved_info_dict)
+    assert vm.render_procedure is render_sh_voxel_grid  # unpickled by qualified name onto this package
+    assert vm.thre3d_repr.grid_dims == (6, 6, 6) and extra["hemispherical_radius"] == 4.0311
+    data = torch.load(path, weights_only=False)
+    vg = create_voxel_grid_from_saved_info_dict_attn(data)
+    assert vg.attn is not None and float(vg.attn.mean()) == -20.0
+    # save -> load round trip of our own checkpoint
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        p2 = os.path.join(td, "m.pth")
+        torch.save(vm.get_save_info(extra), p2)
+        vm2, _ = create_volumetric_model_from_saved_model(p2, create_voxel_grid_from_saved_info_dict)
+        assert torch.equal(vm2.thre3d_repr.densities, vm.thre3d_repr.densities)
+    if not torch.cuda.is_available():
+        # no silent CPU fallback: the product path fails loudly without a GPU
+        rays = Rays(torch.zeros(4, 3), torch.ones(4, 3))
+        with pytest.raises(VoxeError):
+            vm.render_rays(rays)

@@ -1,0 +1,306 @@
+// voxe_api.hip -- the extern "C" boundary of libvoxe_hip.so (see include/voxe.h).
+// Validation + argument marshalling only; kernels live in voxe_render.hip / voxe_grid_ops.hip.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/voxe.h"
+#include "voxe_launch.hpp"
+
+using namespace voxe;
+
+namespace {
+
+struct Variant {
+  int cout, ncoef_mem, C;
+  bool attn;
+};
+
+int validate(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, Variant* v) {
+  if (!g || !c) return VOXE_ERR_NULL_POINTER;
+  if (!g->densities || !g->features) return VOXE_ERR_NULL_POINTER;
+  if (g->X <= 0 || g->Y <= 0 || g->Z <= 0 || g->F <= 0 || R < 0 || c->num_samples <= 0)
+    return VOXE_ERR_BAD_SHAPE;
+  if ((long long)g->X * g->Y * g->Z * (g->F + 1) >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
+  if (g->feature_kind == VOXE_FEAT_ATTN) {
+    if (g->F != 1) return VOXE_ERR_BAD_SHAPE;
+    v->cout = 1; v->ncoef_mem = 1; v->attn = true;
+  } else if (g->feature_kind == VOXE_FEAT_SH) {
+    if (c->sh_degree < 0 || c->sh_degree > 3) return VOXE_ERR_UNSUPPORTED;
+    const int nc = (c->sh_degree + 1) * (c->sh_degree + 1);
+    if (g->F != 3 * nc) return VOXE_ERR_BAD_SHAPE;
+    v->cout = 3; v->ncoef_mem = nc; v->attn = false;
+  } else {
+    return VOXE_ERR_UNSUPPORTED;
+  }
+  v->C = g->F + 1;
+  if (g->density_pre_act != VOXE_ACT_IDENTITY && g->density_pre_act != VOXE_ACT_ABS)
+    return VOXE_ERR_UNSUPPORTED;
+  if (g->density_post_act != VOXE_ACT_IDENTITY && g->density_post_act != VOXE_ACT_RELU &&
+      g->density_post_act != VOXE_ACT_SOFTPLUS)
+    return VOXE_ERR_UNSUPPORTED;
+  if (c->image_width < 0 || (c->image_width > 0 && R % c->image_width != 0))
+    return VOXE_ERR_BAD_SHAPE;
+  return VOXE_OK;
+}
+
+void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Variant& v, DevGrid* dg,
+              DevCfg* dc) {
+  dg->X = g->X; dg->Y = g->Y; dg->Z = g->Z;
+  for (int a = 0; a < 3; ++a) {
+    dg->lo[a] = g->aabb_lo[a]; dg->hi[a] = g->aabb_hi[a];
+    dg->scale[a] = g->norm_scale[a]; dg->bias[a] = g->norm_bias[a];
+  }
+  dg->density_scale = g->density_scale;
+  dg->pre_act = g->density_pre_act; dg->post_act = g->density_post_act;
+  dc->S = c->num_samples;
+  dc->near = c->near; dc->far = c->far;
+  dc->perturb = c->perturb; dc->lindisp = c->linear_disparity; dc->aabb_clip = c->aabb_clip;
+  dc->white = c->white_bkgd; dc->attn = v.attn ? 1 : 0;
+  dc->term_eps = c->term_eps;
+  dc->key0 = (uint32_t)c->seed;
+  dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32);
+  dc->ctr3 = (uint32_t)c->rng_offset;
+  dc->image_width = c->image_width;
+  dc->R = R;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// workspace = [ packed grid | packed gradient ]
+struct WsLayout {
+  size_t packed_off, grad_off, total;
+};
+WsLayout ws_layout(const VoxeGridDesc* g) {
+  const size_t nvox = (size_t)g->X * g->Y * g->Z;
+  const size_t bytes = align_up(nvox * (size_t)(g->F + 1) * sizeof(float), 256);
+  WsLayout l;
+  l.packed_off = 0;
+  l.grad_off = bytes;
+  l.total = 2 * bytes;
+  return l;
+}
+
+int finish() { return hipGetLastError() == hipSuccess ? VOXE_OK : VOXE_ERR_LAUNCH; }
+
+// ---- per-phase timing (voxe_profile_*) ----------------------------------------------------------
+enum Phase { PH_PACK = 0, PH_FWD, PH_MEMSET, PH_BWD, PH_UNPACK, PH_COUNT };
+struct Profiler {
+  static constexpr int kMax = 512;
+  bool on = false, created = false;
+  hipEvent_t ev[kMax][2];
+  int phase[kMax];
+  int count = 0, dropped = 0;
+} g_prof;
+
+struct PhaseTimer {  // records start/stop events around one phase when profiling is enabled
+  int slot = -1;
+  hipStream_t st;
+  PhaseTimer(Phase ph, hipStream_t s) : st(s) {
+    if (!g_prof.on) return;
+    if (g_prof.count >= Profiler::kMax) { ++g_prof.dropped; return; }
+    slot = g_prof.count++;
+    g_prof.phase[slot] = ph;
+    (void)hipEventRecord(g_prof.ev[slot][0], st);
+  }
+  ~PhaseTimer() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], st);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int voxe_abi_version(void) { return VOXE_ABI_VERSION; }
+
+const char* voxe_strerror(int status) {
+  switch (status) {
+    case VOXE_OK: return "ok";
+    case VOXE_ERR_NULL_POINTER: return "null pointer";
+    case VOXE_ERR_BAD_SHAPE: return "bad shape";
+    case VOXE_ERR_UNSUPPORTED: return "unsupported activation / mode";
+    case VOXE_ERR_WORKSPACE: return "workspace missing or too small";
+    case VOXE_ERR_LAUNCH: return "kernel launch failed";
+    case VOXE_ERR_NO_DEVICE: return "no gfx950 HIP device";
+    default: return "unknown voxe status";
+  }
+}
+
+int voxe_device_check(char* name, size_t name_len) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return VOXE_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return VOXE_ERR_NO_DEVICE;
+  if (name && name_len) {
+    strncpy(name, prop.gcnArchName, name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? VOXE_OK : VOXE_ERR_NO_DEVICE;
+}
+
+int voxe_profile_enable(int32_t on) {
+  if (on && !g_prof.created) {
+    for (int i = 0; i < Profiler::kMax; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (hipEventCreate(&g_prof.ev[i][j]) != hipSuccess) return VOXE_ERR_LAUNCH;
+    g_prof.created = true;
+  }
+  g_prof.on = on != 0;
+  g_prof.count = 0;
+  g_prof.dropped = 0;
+  return VOXE_OK;
+}
+
+int voxe_profile_read(VoxeProfile* out) {
+  if (!out) return VOXE_ERR_NULL_POINTER;
+  memset(out, 0, sizeof(*out));
+  double* ms[PH_COUNT] = {&out->ms_pack, &out->ms_fwd, &out->ms_memset, &out->ms_bwd, &out->ms_unpack};
+  int32_t* n[PH_COUNT] = {&out->n_pack, &out->n_fwd, &out->n_memset, &out->n_bwd, &out->n_unpack};
+  for (int i = 0; i < g_prof.count; ++i) {
+    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) return VOXE_ERR_LAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) return VOXE_ERR_LAUNCH;
+    *ms[g_prof.phase[i]] += (double)t;
+    *n[g_prof.phase[i]] += 1;
+  }
+  out->n_dropped = g_prof.dropped;
+  g_prof.count = 0;
+  g_prof.dropped = 0;
+  return VOXE_OK;
+}
+
+int voxe_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const float* trans,
+                   float* rays_o, float* rays_d, void* stream) {
+  if (!rot || !trans || !rays_o || !rays_d) return VOXE_ERR_NULL_POINTER;
+  if (H <= 0 || W <= 0) return VOXE_ERR_BAD_SHAPE;
+  launch_cast_rays(H, W, focal, rot, trans, rays_o, rays_d, (hipStream_t)stream);
+  return finish();
+}
+
+size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
+  (void)cfg; (void)R;
+  if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
+  return ws_layout(grid).total;
+}
+
+int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
+                    const float* rays_d, int64_t R, const float* jitter, float* colour, float* depth,
+                    float* acc, float* disparity, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  if (R > 0 && (!rays_o || !rays_d || !colour)) return VOXE_ERR_NULL_POINTER;
+  const WsLayout l = ws_layout(grid);
+  if (!workspace || workspace_bytes < l.grad_off) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* packed = (float*)((char*)workspace + l.packed_off);
+  if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
+  if (R == 0) return finish();
+  DevGrid dg; DevCfg dc;
+  make_dev(grid, cfg, R, v, &dg, &dc);
+  FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity};
+  { PhaseTimer t(PH_FWD, s); launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s); }
+  return finish();
+}
+
+int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
+                    const float* rays_d, int64_t R, const float* jitter, const float* colour,
+                    const float* depth, const float* acc, const float* d_colour, const float* d_depth,
+                    const float* d_acc, float* d_densities, float* d_features, int32_t accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  if (R > 0 && (!rays_o || !rays_d || !colour || !depth || !acc || !d_colour))
+    return VOXE_ERR_NULL_POINTER;
+  if (!d_densities && !d_features) return VOXE_OK;
+  const WsLayout l = ws_layout(grid);
+  if (!workspace || workspace_bytes < l.total) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* packed = (float*)((char*)workspace + l.packed_off);
+  float* gpacked = (float*)((char*)workspace + l.grad_off);
+  if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
+  {
+    PhaseTimer t(PH_MEMSET, s);
+    if (hipMemsetAsync(gpacked, 0, l.total - l.grad_off, s) != hipSuccess) return VOXE_ERR_LAUNCH;
+  }
+  if (R > 0) {
+    DevGrid dg; DevCfg dc;
+    make_dev(grid, cfg, R, v, &dg, &dc);
+    BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
+              d_densities != nullptr, d_features != nullptr};
+    PhaseTimer t(PH_BWD, s);
+    launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
+  }
+  {
+    PhaseTimer t(PH_UNPACK, s);
+    launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, s);
+  }
+  return finish();
+}
+
+int voxe_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
+                      const float* rays_d, int64_t R, const float* jitter, int32_t* idx,
+                      uint8_t* inside, float* zvals, float* sigma, float* rad, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  if (R > 0 && (!rays_o || !rays_d)) return VOXE_ERR_NULL_POINTER;
+  const WsLayout l = ws_layout(grid);
+  if (!workspace || workspace_bytes < l.grad_off) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* packed = (float*)((char*)workspace + l.packed_off);
+  if (!cfg->reuse_packed_grid) launch_pack_any(grid, packed, s);
+  if (R == 0) return finish();
+  DevGrid dg; DevCfg dc;
+  make_dev(grid, cfg, R, v, &dg, &dc);
+  ProbeArgs a{packed, rays_o, rays_d, jitter, idx, inside, zvals, sigma, rad};
+  launch_probe(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
+  return finish();
+}
+
+size_t voxe_dcl_scratch_bytes(int64_t n) { return dcl_scratch_bytes(n); }
+
+int voxe_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale, float* loss_out,
+                     float* d_a, int32_t accumulate, void* scratch, size_t scratch_bytes,
+                     void* stream) {
+  if (!a || !b || !loss_out) return VOXE_ERR_NULL_POINTER;
+  if (n <= 0) return VOXE_ERR_BAD_SHAPE;
+  if (!scratch || scratch_bytes < dcl_scratch_bytes(n)) return VOXE_ERR_WORKSPACE;
+  launch_dcl(a, b, n, grad_scale, loss_out, d_a, accumulate, scratch, (hipStream_t)stream);
+  return finish();
+}
+
+size_t voxe_tv_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t C) {
+  return tv_scratch_bytes(X, Y, Z, C);
+}
+
+int voxe_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t C, float grad_scale,
+                    float* loss_out, float* d_grid, int32_t accumulate, void* scratch,
+                    size_t scratch_bytes, void* stream) {
+  if (!grid || !loss_out) return VOXE_ERR_NULL_POINTER;
+  if (X <= 0 || Y <= 0 || Z <= 0 || C <= 0) return VOXE_ERR_BAD_SHAPE;
+  if (!scratch || scratch_bytes < tv_scratch_bytes(X, Y, Z, C)) return VOXE_ERR_WORKSPACE;
+  launch_tv(grid, X, Y, Z, C, grad_scale, loss_out, d_grid, accumulate, scratch, (hipStream_t)stream);
+  return finish();
+}
+
+int voxe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq) return VOXE_ERR_NULL_POINTER;
+  if (n < 0 || step < 1) return VOXE_ERR_BAD_SHAPE;
+  launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+  return finish();
+}
+
+int voxe_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, int32_t C, float* dst,
+                            int32_t X2, int32_t Y2, int32_t Z2, void* stream) {
+  if (!src || !dst) return VOXE_ERR_NULL_POINTER;
+  if (X <= 0 || Y <= 0 || Z <= 0 || C <= 0 || X2 <= 0 || Y2 <= 0 || Z2 <= 0) return VOXE_ERR_BAD_SHAPE;
+  launch_upsample(src, X, Y, Z, C, dst, X2, Y2, Z2, (hipStream_t)stream);
+  return finish();
+}
+
+}  // extern "C"

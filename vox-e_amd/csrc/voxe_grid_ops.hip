@@ -1,0 +1,282 @@
+// voxe_grid_ops.hip -- ray casting and the whole-grid (HBM-streaming) passes of an SDS /
+// reconstruction step: density-correlation loss, total-variation loss, Adam, trilinear upsampling.
+#include "voxe_device.hpp"
+#include "voxe_launch.hpp"
+
+namespace voxe {
+
+// ------------------------------------------------------------------------------------------------
+// cast_rays -- rendering/volumetric/utils/misc.py:12-50
+// ------------------------------------------------------------------------------------------------
+struct Pose {
+  float rot[9];
+  float trans[3];
+};
+
+__global__ __launch_bounds__(256) void cast_rays_kernel(int H, int W, float focal, Pose pose,
+                                                        float* __restrict__ rays_o,
+                                                        float* __restrict__ rays_d) {
+  const long long n = (long long)H * W;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int py = (int)(i / W), px = (int)(i - (long long)py * W);
+  const float x = (float)px + 0.5f, y = (float)py + 0.5f;  // linspace(0.5, W-0.5, W) (misc.py:29-33)
+  const float dx = (x - (float)W * 0.5f) / focal;            // misc.py:39-45
+  const float dy = -(y - (float)H * 0.5f) / focal;
+  const float dz = -1.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rays_d[3 * i + r] = pose.rot[3 * r + 0] * dx + pose.rot[3 * r + 1] * dy + pose.rot[3 * r + 2] * dz;
+    rays_o[3 * i + r] = pose.trans[r];
+  }
+}
+
+void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,
+                      float* rays_d, hipStream_t st) {
+  Pose p;
+  for (int i = 0; i < 9; ++i) p.rot[i] = rot[i];
+  for (int i = 0; i < 3; ++i) p.trans[i] = trans[i];
+  const long long n = (long long)H * W;
+  cast_rays_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(H, W, focal, p, rays_o, rays_d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block reduction helper (double): wave shuffle -> LDS -> lane 0
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* out /* NV doubles, global */) {
+  __shared__ double sm[NV][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) sm[i][wave] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int i = threadIdx.x;
+    out[i] = (sm[i][0] + sm[i][1]) + (sm[i][2] + sm[i][3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// _density_correlation_loss -- modules/sds_trainer.py:507-524 (+ autograd). Three launches:
+// moments (1 read of a and b), finalize (stats + loss), gradient (1 read of a and b, 1 write).
+// Deterministic: per-block partials, fixed-order final sum.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRedBlocks = 1024;
+
+__global__ __launch_bounds__(256) void dcl_moments_kernel(const float* __restrict__ a,
+                                                          const float* __restrict__ b, long long n,
+                                                          double* __restrict__ partial) {
+  double s[5] = {0, 0, 0, 0, 0};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double x = a[i], y = b[i];
+    s[0] += x; s[1] += y; s[2] += x * x; s[3] += y * y; s[4] += x * y;
+  }
+  block_sum<5>(s, partial + (long long)blockIdx.x * 5);
+}
+
+// stats: [0]=mean a, [1]=mean b, [2]=k1, [3]=k2
+__global__ __launch_bounds__(256) void dcl_finalize_kernel(const double* __restrict__ partial,
+                                                           int nblocks, long long n,
+                                                           double* __restrict__ stats,
+                                                           float* __restrict__ loss_out) {
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s[j] += partial[(long long)i * 5 + j];
+  __shared__ double tot[5];
+  block_sum<5>(s, tot);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double dn = (double)n;
+    const double ma = tot[0] / dn, mb = tot[1] / dn;
+    const double va = tot[2] / dn - ma * ma, vb = tot[3] / dn - mb * mb;
+    const double cov = tot[4] / dn - ma * mb;
+    const double eps = 0.0000001;
+    const double D = sqrt(fmax(va * vb, 0.0));
+    *loss_out = (float)(1.0 - cov / (D + eps));
+    stats[0] = ma; stats[1] = mb;
+    stats[2] = 1.0 / (dn * (D + eps));
+    stats[3] = (D > 0.0) ? cov * vb / (dn * D * (D + eps) * (D + eps)) : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void dcl_grad_kernel(const float* __restrict__ a,
+                                                       const float* __restrict__ b, long long n,
+                                                       const double* __restrict__ stats,
+                                                       float grad_scale, float* __restrict__ d_a,
+                                                       int accumulate) {
+  const float ma = (float)stats[0], mb = (float)stats[1];
+  const float k1 = (float)(stats[2] * (double)grad_scale), k2 = (float)(stats[3] * (double)grad_scale);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float A = a[i] - ma, B = b[i] - mb;
+    const float gv = A * k2 - B * k1;
+    d_a[i] = accumulate ? d_a[i] + gv : gv;
+  }
+}
+
+size_t dcl_scratch_bytes(long long) { return sizeof(double) * (kRedBlocks * 5 + 8); }
+
+void launch_dcl(const float* a, const float* b, long long n, float grad_scale, float* loss_out,
+                float* d_a, int accumulate, void* scratch, hipStream_t st) {
+  double* partial = (double*)scratch;
+  double* stats = partial + kRedBlocks * 5;
+  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  dcl_moments_kernel<<<nb, 256, 0, st>>>(a, b, n, partial);
+  dcl_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, n, stats, loss_out);
+  if (d_a) {
+    const int nbg = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    dcl_grad_kernel<<<nbg, 256, 0, st>>>(a, b, n, stats, grad_scale, d_a, accumulate);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// _tv_loss_on_grid -- modules/sds_trainer.py:563-567 (+ autograd), gather form (no atomics):
+// every element reads its 6 axis neighbours once.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ grid, int X, int Y, int Z,
+                                                 int C, float gx, float gy, float gz,
+                                                 double* __restrict__ partial,
+                                                 float* __restrict__ d_grid, int accumulate) {
+  const long long n = (long long)X * Y * Z * C;
+  const long long sx = (long long)Y * Z * C, sy = (long long)Z * C, sz = C;
+  double s[3] = {0, 0, 0};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long long vox = i / C;
+    const int z = (int)(vox % Z);
+    const int y = (int)((vox / Z) % Y);
+    const int x = (int)(vox / ((long long)Z * Y));
+    const float v = grid[i];
+    float g = 0.0f;
+    if (x + 1 < X) { const float df = grid[i + sx] - v; s[0] += fabsf(df); g -= sgnf(df) * gx; }
+    if (x > 0) { const float df = v - grid[i - sx]; g += sgnf(df) * gx; }
+    if (y + 1 < Y) { const float df = grid[i + sy] - v; s[1] += fabsf(df); g -= sgnf(df) * gy; }
+    if (y > 0) { const float df = v - grid[i - sy]; g += sgnf(df) * gy; }
+    if (z + 1 < Z) { const float df = grid[i + sz] - v; s[2] += fabsf(df); g -= sgnf(df) * gz; }
+    if (z > 0) { const float df = v - grid[i - sz]; g += sgnf(df) * gz; }
+    if (d_grid) d_grid[i] = accumulate ? d_grid[i] + g : g;
+  }
+  block_sum<3>(s, partial + (long long)blockIdx.x * 3);
+}
+
+__global__ __launch_bounds__(256) void tv_finalize_kernel(const double* __restrict__ partial,
+                                                          int nblocks, double cx, double cy, double cz,
+                                                          float* __restrict__ loss_out) {
+  double s[3] = {0, 0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) s[j] += partial[(long long)i * 3 + j];
+  __shared__ double tot[3];
+  block_sum<3>(s, tot);
+  __syncthreads();
+  // mean over an empty diff (dim of size 1) is NaN in torch
+  if (threadIdx.x == 0) *loss_out = (float)((tot[0] / cx + tot[1] / cy + tot[2] / cz) / 3.0);
+}
+
+size_t tv_scratch_bytes(int, int, int, int) { return sizeof(double) * (kRedBlocks * 3 + 8); }
+
+void launch_tv(const float* grid, int X, int Y, int Z, int C, float grad_scale, float* loss_out,
+               float* d_grid, int accumulate, void* scratch, hipStream_t st) {
+  const long long n = (long long)X * Y * Z * C;
+  const double cx = (double)(X - 1) * Y * Z * C, cy = (double)X * (Y - 1) * Z * C,
+               cz = (double)X * Y * (Z - 1) * C;
+  const float gx = cx > 0 ? (float)((double)grad_scale / (3.0 * cx)) : 0.f;
+  const float gy = cy > 0 ? (float)((double)grad_scale / (3.0 * cy)) : 0.f;
+  const float gz = cz > 0 ? (float)((double)grad_scale / (3.0 * cz)) : 0.f;
+  double* partial = (double*)scratch;
+  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  tv_kernel<<<nb, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
+  tv_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, cx, cy, cz, loss_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam (single tensor, no weight decay / amsgrad): one read-modify-write stream over
+// param, exp_avg, exp_avg_sq + one read of grad  (7 * n * 4 bytes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   long long n, float step_size, float bc2_sqrt,
+                                                   float beta1, float beta2, float eps) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const float omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * omb1;              // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + (omb2 * gi) * gi;        // mul_(beta2).addcmul_(g, g, 1-beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);                  // addcdiv_(exp_avg, denom, -step_size)
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+void launch_adam(float* param, const float* grad, float* m, float* v, long long n, float lr,
+                 float beta1, float beta2, float eps, long long step, hipStream_t st) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  if (n == 0) return;
+  const int nb = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  adam_kernel<<<nb, 256, 0, st>>>(param, grad, m, v, n, step_size, bc2_sqrt, beta1, beta2, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scale_voxel_grid_with_required_output_size -- voxels.py:409-447 (ATen upsample_trilinear3d,
+// align_corners=False, scale = in/out)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up_axis(int out_i, int in_n, int out_n, int& i0, int& i1, float& l0,
+                                        float& l1) {
+  const float scale = (float)in_n / (float)out_n;
+  float src = scale * ((float)out_i + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  int a = (int)src;
+  if (a > in_n - 1) a = in_n - 1;
+  i0 = a;
+  i1 = a + ((a < in_n - 1) ? 1 : 0);
+  l1 = src - (float)a;
+  l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ src, int X, int Y,
+                                                       int Z, int C, float* __restrict__ dst, int X2,
+                                                       int Y2, int Z2) {
+  const long long n = (long long)X2 * Y2 * Z2 * C;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int ch = (int)(i % C);
+  const long long vox = i / C;
+  const int z = (int)(vox % Z2), y = (int)((vox / Z2) % Y2), x = (int)(vox / ((long long)Z2 * Y2));
+  int x0, x1, y0, y1, z0, z1;
+  float lx0, lx1, ly0, ly1, lz0, lz1;
+  up_axis(x, X, X2, x0, x1, lx0, lx1);
+  up_axis(y, Y, Y2, y0, y1, ly0, ly1);
+  up_axis(z, Z, Z2, z0, z1, lz0, lz1);
+  auto S = [&](int ix, int iy, int iz) { return src[(((long long)ix * Y + iy) * Z + iz) * C + ch]; };
+  const float v = lx0 * (ly0 * (lz0 * S(x0, y0, z0) + lz1 * S(x0, y0, z1)) +
+                         ly1 * (lz0 * S(x0, y1, z0) + lz1 * S(x0, y1, z1))) +
+                  lx1 * (ly0 * (lz0 * S(x1, y0, z0) + lz1 * S(x1, y0, z1)) +
+                         ly1 * (lz0 * S(x1, y1, z0) + lz1 * S(x1, y1, z1)));
+  dst[i] = v;
+}
+
+void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, int X2, int Y2, int Z2,
+                     hipStream_t st) {
+  const long long n = (long long)X2 * Y2 * Z2 * C;
+  upsample_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
+}
+
+}  // namespace voxe

@@ -1,0 +1,52 @@
+// voxe_launch.hpp -- host-side launcher interface between voxe_api.hip and the kernel files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "voxe_device.hpp"
+
+namespace voxe {
+
+struct FwdArgs {
+  const float *packed, *rays_o, *rays_d, *jitter;
+  float *colour, *depth, *acc, *disparity;
+};
+struct BwdArgs {
+  const float *packed, *rays_o, *rays_d, *jitter, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc;
+  float* gpacked;
+  bool want_d, want_f;
+};
+struct ProbeArgs {
+  const float *packed, *rays_o, *rays_d, *jitter;
+  int32_t* idx;
+  uint8_t* inside;
+  float *zvals, *sigma, *rad;
+};
+
+
+// voxe_render.hip
+void launch_pack_any(const VoxeGridDesc* gd, float* packed, hipStream_t st);
+void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
+                       int accumulate, hipStream_t st);
+void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
+                hipStream_t st);
+void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a,
+                hipStream_t st);
+void launch_probe(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const ProbeArgs& a,
+                  hipStream_t st);
+
+// voxe_grid_ops.hip
+void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,
+                      float* rays_d, hipStream_t st);
+size_t dcl_scratch_bytes(long long n);
+void launch_dcl(const float* a, const float* b, long long n, float grad_scale, float* loss_out,
+                float* d_a, int accumulate, void* scratch, hipStream_t st);
+size_t tv_scratch_bytes(int X, int Y, int Z, int C);
+void launch_tv(const float* grid, int X, int Y, int Z, int C, float grad_scale, float* loss_out,
+               float* d_grid, int accumulate, void* scratch, hipStream_t st);
+void launch_adam(float* param, const float* grad, float* m, float* v, long long n, float lr,
+                 float beta1, float beta2, float eps, long long step, hipStream_t st);
+void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, int X2, int Y2, int Z2,
+                     hipStream_t st);
+
+}  // namespace voxe

@@ -1,0 +1,134 @@
+"""Render procedures of the SH voxel grid -- the drop-in boundary.
+
+`RenderProcedure = Callable[[Module, Rays, RenderConfig, Optional[int]], RenderOut]` and
+`SHVoxGridRenderConfig` keep the reference's contract (thre3d_atom/thre3d_reprs/renderers.py:23-47)
+so `VolumetricModel` and checkpoints are interchangeable.  Where the reference binds a sampler, a point
+processor and an accumulator with functools.partial and runs ~40 ATen ops under autograd
+(renderers.py:50-163), these procedures translate the config into one VoxeRenderCfg and call the fused
+HIP forward kernel; autograd sees a single node whose backward is the fused HIP backward kernel.
+"""
+import dataclasses
+from typing import Any, Callable, Optional
+
+import torch
+from torch import Tensor
+from torch.nn import Module
+
+from thre3d_atom.rendering.volumetric.accumulate import density2occupancy_pb
+from thre3d_atom.rendering.volumetric.render_interface import Rays, RenderOut, RenderOutAttn
+from thre3d_atom.thre3d_reprs.voxels import VoxelGrid
+from thre3d_atom.utils.constants import EXTRA_ACCUMULATED_WEIGHTS, EXTRA_DISPARITY, NUM_COLOUR_CHANNELS
+from thre3d_atom.utils.imaging_utils import CameraBounds
+from voxe_hip import ops as _ops
+from voxe_hip.runtime import VoxeError
+
+RenderConfig = Any
+RenderProcedure = Callable[[Module, Rays, RenderConfig, Optional[int]], RenderOut]
+
+# Early ray termination is NOT part of the reference (it integrates all S samples).  0.0 keeps exact
+# reference semantics; set_early_termination(eps) stops a ray once its transmittance drops below eps.
+_TERM_EPS = 0.0
+
+
+def set_early_termination(eps: float) -> None:
+    global _TERM_EPS
+    _TERM_EPS = float(eps)
+
+
+@dataclasses.dataclass
+class SHVoxGridRenderConfig:
+    # probing
+    num_samples_per_ray: int
+    camera_bounds: CameraBounds
+    perturb_sampled_points: bool = True
+    optimized_sampling: bool = False
+    linear_disparity_sampling: bool = False
+    # accumulation
+    density2occupancy: Callable[[Tensor, Tensor], Tensor] = density2occupancy_pb
+    radiance_hdr_tone_map: Callable[[Tensor], Tensor] = torch.sigmoid
+    stochastic_density_noise_std: float = 0.0
+    white_bkgd: bool = False
+    # render modes
+    render_diffuse: bool = False
+    render_num_samples_per_ray: int = 1024
+    parallel_rays_chunk_size: int = 32768
+
+
+def _sh_degree_of(voxel_grid: VoxelGrid) -> int:
+    per_channel = voxel_grid.features.shape[-1] / NUM_COLOUR_CHANNELS
+    degree = int(round(per_channel ** 0.5)) - 1
+    if NUM_COLOUR_CHANNELS * (degree + 1) ** 2 != voxel_grid.features.shape[-1] or not 0 <= degree <= 3:
+        raise VoxeError(f"feature channels {voxel_grid.features.shape[-1]} are not 3*(deg+1)^2 for deg in 0..3")
+    return degree
+
+
+def _render_params(voxel_grid: VoxelGrid, rays: Rays, cfg: SHVoxGridRenderConfig, attn: bool) -> _ops.RenderParams:
+    if cfg.density2occupancy is not density2occupancy_pb:
+        raise VoxeError("only density2occupancy_pb has a HIP path")
+    if cfg.radiance_hdr_tone_map is not torch.sigmoid:
+        raise VoxeError("only torch.sigmoid tone mapping has a HIP path")
+    if cfg.stochastic_density_noise_std != 0.0:
+        raise VoxeError("stochastic_density_noise_std != 0 is not supported by the HIP renderer")
+    num_rays = rays.origins.shape[0]
+    width = 0
+    if rays.image_shape is not None and rays.image_shape[0] * rays.image_shape[1] == num_rays:
+        width = int(rays.image_shape[1])
+    return _ops.RenderParams(
+        num_samples=int(cfg.num_samples_per_ray),
+        near=float(cfg.camera_bounds[0]),
+        far=float(cfg.camera_bounds[1]),
+        perturb=bool(cfg.perturb_sampled_points),
+        # the attention procedure of the reference does not forward linear_disparity (renderers.py:131-134)
+        linear_disparity=bool(cfg.linear_disparity_sampling) and not attn,
+        aabb_clip=bool(cfg.optimized_sampling),
+        white_bkgd=bool(cfg.white_bkgd),
+        sh_degree=0 if attn else _sh_degree_of(voxel_grid),
+        render_diffuse=bool(cfg.render_diffuse),
+        term_eps=_TERM_EPS,
+        image_width=width,
+    )
+
+
+def _check_flat(rays: Rays) -> None:
+    if rays.origins.dim() != 2 or rays.directions.dim() != 2:
+        raise AssertionError("Please note that the RENDER interface only works with FLAT RAYS!")
+
+
+def render_sh_voxel_grid(
+    voxel_grid: VoxelGrid,
+    rays: Rays,
+    render_config: SHVoxGridRenderConfig,
+    parallel_points_chunk_size: Optional[int] = None,
+) -> RenderOut:
+    """Render flat rays through an SH voxel grid.  `parallel_points_chunk_size` is accepted for API
+    parity and ignored: the fused kernel has no per-point temporaries to chunk."""
+    _check_flat(rays)
+    params = _render_params(voxel_grid, rays, render_config, attn=False)
+    colour, depth, acc, disparity = _ops.render(
+        voxel_grid.voxe_grid_spec(attn=False), params, voxel_grid.densities, voxel_grid.features,
+        rays.origins, rays.directions, workspace=voxel_grid.voxe_workspace("sh"),
+    )
+    return RenderOut(colour=colour, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})
+
+
+def render_sh_voxel_grid_attn(
+    voxel_grid: VoxelGrid,
+    rays: Rays,
+    render_config: SHVoxGridRenderConfig,
+    parallel_points_chunk_size: Optional[int] = None,
+    orig_densities=False,
+) -> RenderOutAttn:
+    """Render the 1-channel attention grid (VoxelGrid.attn) with the grid's densities (or the detached
+    `orig_densities` snapshot); background contributes 0 (accumulate.py:166)."""
+    _check_flat(rays)
+    if voxel_grid.attn is None:
+        raise VoxeError("this VoxelGrid has no attention grid (attn is None)")
+    params = _render_params(voxel_grid, rays, render_config, attn=True)
+    densities = voxel_grid.densities
+    if orig_densities:
+        densities = voxel_grid.orig_densities.detach().to(voxel_grid.attn.device)
+    attn, depth, acc, disparity = _ops.render(
+        voxel_grid.voxe_grid_spec(attn=True), params, densities, voxel_grid.attn,
+        rays.origins, rays.directions, workspace=voxel_grid.voxe_workspace("attn"),
+    )
+    return RenderOutAttn(attn=attn, depth=depth, extra={EXTRA_DISPARITY: disparity, EXTRA_ACCUMULATED_WEIGHTS: acc})

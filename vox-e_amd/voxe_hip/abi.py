@@ -69,6 +69,15 @@ class VoxeRenderCfg(C.Structure):
     ]
 
 
+class VoxeProfile(C.Structure):
+    _fields_ = [
+        ("ms_pack", C.c_double), ("ms_fwd", C.c_double), ("ms_memset", C.c_double), ("ms_bwd", C.c_double),
+        ("ms_unpack", C.c_double),
+        ("n_pack", C.c_int32), ("n_fwd", C.c_int32), ("n_memset", C.c_int32), ("n_bwd", C.c_int32),
+        ("n_unpack", C.c_int32), ("n_dropped", C.c_int32),
+    ]
+
+
 _P = C.c_void_p
 _GD = C.POINTER(VoxeGridDesc)
 _RC = C.POINTER(VoxeRenderCfg)
@@ -95,6 +104,8 @@ HIP_ONLY = {
     "workspace_bytes": (C.c_size_t, [_GD, _RC, C.c_int64]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "profile_enable": (C.c_int, [C.c_int32]),
+    "profile_read": (C.c_int, [C.POINTER(VoxeProfile)]),
 }
 
 CPU_ONLY = {

@@ -1,0 +1,68 @@
+"""Compile the HIP sources in vox-e_amd/csrc into vox-e_amd/voxe_hip/libvoxe_hip.so (in-tree).
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the build container; the
+.so travels to the GPU box with the repository snapshot.
+
+    python vox-e_amd/voxe_hip/build.py [--force] [--verbose]
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
+LIB = os.path.join(HERE, "libvoxe_hip.so")
+OBJ_DIR = os.path.join(HERE, "_obj")
+
+SOURCES = ["voxe_render.hip", "voxe_grid_ops.hip", "voxe_api.hip"]
+HEADERS = ["voxe_device.hpp", "voxe_launch.hpp"]
+
+# -ffp-contract=off : the voxel-index arithmetic must round like the reference (no implicit FMA)
+# -munsafe-fp-atomics: float atomicAdd -> global_atomic_add_f32 (no CAS loop)
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+    "-Wall", "-Wno-unused-function",
+]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "voxe.h"), os.path.abspath(__file__)]
+    objs = []
+    rebuilt = False
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not _newer(op, [sp] + hdrs):
+            cmd = [hipcc(), *FLAGS, *extra_flags, "-I", INCLUDE, "-c", sp, "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            rebuilt = True
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

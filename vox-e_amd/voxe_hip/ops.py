@@ -1,0 +1,368 @@
+"""torch-level operators over libvoxe_hip.so: the fused render (autograd.Function), ray casting and
+the whole-grid passes.  Tensors are plumbing (device memory + streams); all compute is in the HIP
+library.  Nothing here falls back to torch ops or to the CPU oracle."""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import abi
+from .desc import make_grid_desc, make_render_cfg
+from .runtime import VoxeError, check, ensure_gfx950, f32c, lib, ptr, require_device, stream_ptr
+
+
+@dataclass(frozen=True)
+class GridSpec:
+    """Static (non-tensor) description of a voxel grid: what VoxeGridDesc needs besides pointers."""
+    aabb: Tuple[Tuple[float, float], Tuple[float, float], Tuple[float, float]]
+    density_scale: float = 1.0
+    density_pre_act: int = abi.ACT_IDENTITY
+    density_post_act: int = abi.ACT_SOFTPLUS
+    feature_kind: int = abi.FEAT_SH
+
+
+@dataclass
+class RenderParams:
+    """Everything VoxeRenderCfg holds except the RNG stream and the packed-grid reuse flag."""
+    num_samples: int
+    near: float
+    far: float
+    perturb: bool = False
+    linear_disparity: bool = False
+    aabb_clip: bool = False
+    white_bkgd: bool = False
+    sh_degree: int = 0
+    render_diffuse: bool = False
+    term_eps: float = 0.0
+    image_width: int = 0
+
+
+class Workspace:
+    """Caller-owned scratch of the render entry points: [packed grid | packed gradient].
+    Remembers which grid values it holds packed so consecutive calls can skip the pack pass."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+        self.key = None
+
+    def ensure(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self.key = None
+        return self.buf
+
+    def invalidate(self):
+        self.key = None
+
+
+def _pack_key(spec: GridSpec, densities: torch.Tensor, features: torch.Tensor):
+    return (densities.data_ptr(), densities._version, features.data_ptr(), features._version,
+            tuple(features.shape), spec.density_scale, spec.density_pre_act, spec.feature_kind)
+
+
+def _descs(spec: GridSpec, params: RenderParams, densities, features, seed, rng_offset, reuse):
+    X, Y, Z, F = features.shape
+    g = make_grid_desc(densities.data_ptr(), features.data_ptr(), (X, Y, Z), F, spec.aabb,
+                       spec.density_scale, spec.density_pre_act, spec.density_post_act, spec.feature_kind)
+    c = make_render_cfg(params.num_samples, params.near, params.far, params.perturb,
+                        params.linear_disparity, params.aabb_clip, params.white_bkgd, params.sh_degree,
+                        params.render_diffuse, params.term_eps, seed, rng_offset, reuse, params.image_width)
+    return g, c
+
+
+def _validate_inputs(densities, features, rays_o, rays_d, jitter, params: RenderParams):
+    for name, t in (("densities", densities), ("features", features), ("rays_o", rays_o), ("rays_d", rays_d)):
+        require_device(t, f"voxe render ({name})")
+    if densities.dim() != 4 or features.dim() != 4 or densities.shape[:3] != features.shape[:3] or densities.shape[3] != 1:
+        raise VoxeError(f"grid tensors must be [X,Y,Z,1] and [X,Y,Z,F]; got {tuple(densities.shape)}, {tuple(features.shape)}")
+    if rays_o.dim() != 2 or rays_o.shape[1] != 3 or rays_o.shape != rays_d.shape:
+        raise VoxeError(f"rays must be flat [R,3]; got {tuple(rays_o.shape)}, {tuple(rays_d.shape)}")
+    if jitter is not None and tuple(jitter.shape) != (rays_o.shape[0], params.num_samples):
+        raise VoxeError(f"jitter must be [R,S]={rays_o.shape[0], params.num_samples}; got {tuple(jitter.shape)}")
+
+
+def _next_rng():
+    """(seed, offset) of the in-kernel Philox jitter stream, tied to torch's CPU generator so that
+    torch.manual_seed() makes renders reproducible (no device sync involved)."""
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    offset = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+    return seed, offset
+
+
+def render_fwd_into(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
+                    colour, depth, acc, disparity, workspace: Workspace, rng=(0, 0)) -> None:
+    """voxe_render_fwd on caller-provided output tensors (contiguous float32 on one device, no autograd)."""
+    device = densities.device
+    ensure_gfx950(device)
+    L = lib()
+    R = rays_o.shape[0]
+    key = _pack_key(spec, densities, features)
+    g, c = _descs(spec, params, densities, features, rng[0], rng[1], workspace.key == key)
+    with torch.cuda.device(device):
+        ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
+        c.reuse_packed_grid = int(workspace.key == key)
+        check(L.voxe_render_fwd(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
+                                ptr(depth), ptr(acc), ptr(disparity), ptr(ws), ws.numel(),
+                                stream_ptr(device)), "voxe_render_fwd")
+    workspace.key = key
+
+
+def render_bwd_into(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
+                    colour, depth, acc, g_colour, g_depth, g_acc, d_densities, d_features,
+                    workspace: Workspace, rng=(0, 0), accumulate: bool = False) -> None:
+    """voxe_render_bwd into caller-provided gradient tensors (either may be None to skip it)."""
+    device = densities.device
+    L = lib()
+    R = rays_o.shape[0]
+    key = _pack_key(spec, densities, features)
+    g, c = _descs(spec, params, densities, features, rng[0], rng[1], workspace.key == key)
+    with torch.cuda.device(device):
+        ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
+        c.reuse_packed_grid = int(workspace.key == key)
+        check(L.voxe_render_bwd(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
+                                ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
+                                ptr(d_densities), ptr(d_features), int(accumulate), ptr(ws), ws.numel(),
+                                stream_ptr(device)), "voxe_render_bwd")
+    workspace.key = key
+
+
+class _RenderFn(torch.autograd.Function):
+    """colour, depth, acc, disparity = render(densities, features | rays)  with the fused HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, densities, features, rays_o, rays_d, jitter, spec, params, workspace, rng):
+        ctx.set_materialize_grads(False)
+        device = densities.device
+        ensure_gfx950(device)
+        dens, feat = f32c(densities.detach()), f32c(features.detach())
+        ro, rd = f32c(rays_o.detach()), f32c(rays_d.detach())
+        jit = None if jitter is None else f32c(jitter.detach())
+        R = ro.shape[0]
+        cout = 1 if spec.feature_kind == abi.FEAT_ATTN else 3
+        colour = torch.empty((R, cout), dtype=torch.float32, device=device)
+        depth = torch.empty((R, 1), dtype=torch.float32, device=device)
+        acc = torch.empty((R, 1), dtype=torch.float32, device=device)
+        disp = torch.empty((R, 1), dtype=torch.float32, device=device)
+        render_fwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, disp, workspace, rng)
+        ctx.spec, ctx.params, ctx.workspace, ctx.rng = spec, params, workspace, rng
+        ctx.save_for_backward(densities, features, ro, rd, jit, colour, depth, acc)
+        return colour, depth, acc, disp
+
+    @staticmethod
+    def backward(ctx, g_colour, g_depth, g_acc, g_disp):
+        densities, features, ro, rd, jit, colour, depth, acc = ctx.saved_tensors
+        need_d, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not (need_d or need_f):
+            return (None,) * 9
+        device = densities.device
+        spec, params, workspace = ctx.spec, ctx.params, ctx.workspace
+        if g_disp is not None:
+            # disparity = 1 / max(1e-10, depth / acc)  (accumulate.py:85-88): chain into depth and acc
+            q = depth / acc
+            live = (q > 1e-10).to(g_disp.dtype)
+            dq = -g_disp / (q * q) * live
+            dq = torch.nan_to_num(dq, nan=0.0, posinf=0.0, neginf=0.0)
+            gd_extra = dq / acc
+            ga_extra = -dq * depth / (acc * acc)
+            gd_extra = torch.nan_to_num(gd_extra, nan=0.0, posinf=0.0, neginf=0.0)
+            ga_extra = torch.nan_to_num(ga_extra, nan=0.0, posinf=0.0, neginf=0.0)
+            g_depth = gd_extra if g_depth is None else g_depth + gd_extra
+            g_acc = ga_extra if g_acc is None else g_acc + ga_extra
+        if g_colour is None:
+            g_colour = torch.zeros_like(colour)
+        g_colour = f32c(g_colour)
+        g_depth = None if g_depth is None else f32c(g_depth)
+        g_acc = None if g_acc is None else f32c(g_acc)
+        dens, feat = f32c(densities.detach()), f32c(features.detach())
+        d_dens = torch.empty_like(dens) if need_d else None
+        d_feat = torch.empty_like(feat) if need_f else None
+        render_bwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, g_colour, g_depth, g_acc,
+                        d_dens, d_feat, workspace, ctx.rng)
+        return d_dens, d_feat, None, None, None, None, None, None, None
+
+
+def render(spec: GridSpec, params: RenderParams, densities: torch.Tensor, features: torch.Tensor,
+           rays_o: torch.Tensor, rays_d: torch.Tensor, jitter: Optional[torch.Tensor] = None,
+           workspace: Optional[Workspace] = None, rng: Optional[Tuple[int, int]] = None):
+    """Fused volumetric render.  Returns (colour [R,Cout], depth [R,1], acc [R,1], disparity [R,1]);
+    differentiable w.r.t. `densities` and `features` when they require grad."""
+    _validate_inputs(densities, features, rays_o, rays_d, jitter, params)
+    if workspace is None:
+        workspace = Workspace()
+    if rng is None:
+        rng = _next_rng() if (params.perturb and jitter is None) else (0, 0)
+    return _RenderFn.apply(densities, features, rays_o, rays_d, jitter, spec, params, workspace, rng)
+
+
+def sample_probe(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter=None,
+                 rng=(0, 0), outputs=("idx", "inside", "z", "sigma", "rad")):
+    """Per-sample probe (index math test hook): dict of the requested outputs
+    idx [R,S,3] int32, inside [R,S] bool, z [R,S], sigma [R,S], rad [R,S,Cout]."""
+    _validate_inputs(densities, features, rays_o, rays_d, jitter, params)
+    device = densities.device
+    ensure_gfx950(device)
+    L = lib()
+    dens, feat, ro, rd = f32c(densities.detach()), f32c(features.detach()), f32c(rays_o), f32c(rays_d)
+    jit = None if jitter is None else f32c(jitter)
+    R, S = ro.shape[0], params.num_samples
+    cout = 1 if spec.feature_kind == abi.FEAT_ATTN else 3
+    g, c = _descs(spec, params, dens, feat, rng[0], rng[1], False)
+    shapes = {"idx": ((R, S, 3), torch.int32), "inside": ((R, S), torch.uint8), "z": ((R, S), torch.float32),
+              "sigma": ((R, S), torch.float32), "rad": ((R, S, cout), torch.float32)}
+    with torch.cuda.device(device):
+        ws = torch.empty(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), dtype=torch.uint8, device=device)
+        out = {k: torch.empty(shapes[k][0], dtype=shapes[k][1], device=device) for k in outputs}
+        check(L.voxe_sample_probe(C.byref(g), C.byref(c), ptr(ro), ptr(rd), R, ptr(jit), ptr(out.get("idx")),
+                                  ptr(out.get("inside")), ptr(out.get("z")), ptr(out.get("sigma")),
+                                  ptr(out.get("rad")), ptr(ws), ws.numel(), stream_ptr(device)),
+              "voxe_sample_probe")
+    if "inside" in out:
+        out["inside"] = out["inside"].bool()
+    return out
+
+
+def cast_rays(height: int, width: int, focal: float, rotation, translation, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """rays_o, rays_d [H*W,3] on `device` (thre3d_atom/rendering/volumetric/utils/misc.py:12-50)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise VoxeError("cast_rays runs on the GPU only (no CPU fallback in the product path)")
+    ensure_gfx950(device)
+    rot = torch.as_tensor(rotation).detach().to("cpu", torch.float32).reshape(9).contiguous()
+    tr = torch.as_tensor(translation).detach().to("cpu", torch.float32).reshape(3).contiguous()
+    fp = C.POINTER(C.c_float)
+    n = int(height) * int(width)
+    with torch.cuda.device(device):
+        ro = torch.empty((n, 3), dtype=torch.float32, device=device)
+        rd = torch.empty((n, 3), dtype=torch.float32, device=device)
+        check(lib().voxe_cast_rays(int(height), int(width), float(focal), C.cast(rot.data_ptr(), fp),
+                                   C.cast(tr.data_ptr(), fp), ptr(ro), ptr(rd), stream_ptr(device)),
+              "voxe_cast_rays")
+    return ro, rd
+
+
+# ------------------------------------------------------------------------------------------------
+# whole-grid passes
+# ------------------------------------------------------------------------------------------------
+_scratch = {}
+
+
+def _scratch_for(device, nbytes: int) -> torch.Tensor:
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+class _DclFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sds_density, regular_density):
+        require_device(sds_density, "density_correlation_loss")
+        a, b = f32c(sds_density.detach()), f32c(regular_density.detach())
+        if a.numel() != b.numel():
+            raise VoxeError("density_correlation_loss: shape mismatch")
+        device = a.device
+        ensure_gfx950(device)
+        L = lib()
+        with torch.cuda.device(device):
+            sc = _scratch_for(device, L.voxe_dcl_scratch_bytes(a.numel()))
+            loss = torch.empty((), dtype=torch.float32, device=device)
+            d_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+            # gradient for upstream 1.0 is produced in the same launch sequence and scaled in backward
+            check(L.voxe_dcl_fwd_bwd(ptr(a), ptr(b), a.numel(), 1.0, ptr(loss), ptr(d_a), 0, ptr(sc),
+                                     sc.numel(), stream_ptr(device)), "voxe_dcl_fwd_bwd")
+        ctx.save_for_backward(d_a)
+        ctx.shape = sds_density.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_a,) = ctx.saved_tensors
+        if d_a is None:
+            return None, None
+        return (d_a * g).reshape(ctx.shape), None
+
+
+def density_correlation_loss(sds_density: torch.Tensor, regular_density: torch.Tensor) -> torch.Tensor:
+    """1 - corr(sds, regular)  (thre3d_atom/modules/sds_trainer.py:507-524); differentiable w.r.t. sds."""
+    return _DclFn.apply(sds_density, regular_density)
+
+
+class _TvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid):
+        require_device(grid, "tv_loss_on_grid")
+        gr = f32c(grid.detach())
+        if gr.dim() != 4:
+            raise VoxeError("tv_loss_on_grid expects [X,Y,Z,C]")
+        device = gr.device
+        ensure_gfx950(device)
+        L = lib()
+        X, Y, Z, Cn = gr.shape
+        with torch.cuda.device(device):
+            sc = _scratch_for(device, L.voxe_tv_scratch_bytes(X, Y, Z, Cn))
+            loss = torch.empty((), dtype=torch.float32, device=device)
+            d_g = torch.empty_like(gr) if ctx.needs_input_grad[0] else None
+            check(L.voxe_tv_fwd_bwd(ptr(gr), X, Y, Z, Cn, 1.0, ptr(loss), ptr(d_g), 0, ptr(sc), sc.numel(),
+                                    stream_ptr(device)), "voxe_tv_fwd_bwd")
+        ctx.save_for_backward(d_g)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_g,) = ctx.saved_tensors
+        return None if d_g is None else d_g * g
+
+
+def tv_loss_on_grid(grid: torch.Tensor) -> torch.Tensor:
+    """(mean|dx| + mean|dy| + mean|dz|)/3  (thre3d_atom/modules/sds_trainer.py:563-567)."""
+    return _TvFn.apply(grid)
+
+
+@torch.no_grad()
+def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor,
+               step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """In-place torch.optim.Adam update of one tensor (weight_decay=0, amsgrad=False)."""
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        require_device(t, f"adam_step_ ({name})")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != param.numel():
+            raise VoxeError(f"adam_step_: {name} must be contiguous float32 of the parameter's size")
+    device = param.device
+    ensure_gfx950(device)
+    with torch.cuda.device(device):
+        check(lib().voxe_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(),
+                                   float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                   stream_ptr(device)), "voxe_adam_step")
+    # the library wrote through raw pointers: tell autograd (and the packed-grid cache keyed on
+    # Tensor._version) that these tensors changed in place
+    for t in (param, exp_avg, exp_avg_sq):
+        torch.autograd.graph.increment_version(t)
+
+
+@torch.no_grad()
+def upsample_trilinear(src: torch.Tensor, out_size: Sequence[int]) -> torch.Tensor:
+    """[X,Y,Z,C] -> [X2,Y2,Z2,C], F.interpolate(trilinear, align_corners=False) semantics
+    (thre3d_atom/thre3d_reprs/voxels.py:409-447)."""
+    require_device(src, "upsample_trilinear")
+    s = f32c(src)
+    X, Y, Z, Cn = s.shape
+    X2, Y2, Z2 = (int(v) for v in out_size)
+    device = s.device
+    ensure_gfx950(device)
+    with torch.cuda.device(device):
+        dst = torch.empty((X2, Y2, Z2, Cn), dtype=torch.float32, device=device)
+        check(lib().voxe_upsample_trilinear(ptr(s), X, Y, Z, Cn, ptr(dst), X2, Y2, Z2, stream_ptr(device)),
+              "voxe_upsample_trilinear")
+    return dst
+
+
+def profile_enable(on: bool = True) -> None:
+    check(lib().voxe_profile_enable(int(on)), "voxe_profile_enable")
+
+
+def profile_read() -> dict:
+    p = abi.VoxeProfile()
+    check(lib().voxe_profile_read(C.byref(p)), "voxe_profile_read")
+    return {name: getattr(p, name) for name, _ in abi.VoxeProfile._fields_}
