@@ -156,7 +156,7 @@ def main():
     bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
     bytes_bwd = s_in_total * 256 + R * (24 + 12 + 20)
     if ms_bwd >= ms_fwd:
-        kname, kbytes, kms = "render_bwd_kernel<3,1,1>", bytes_bwd, ms_bwd
+        kname, kbytes, kms = "render_bwd_tile_kernel<3,true,true>", bytes_bwd, ms_bwd
     else:
         kname, kbytes, kms = "render_fwd_kernel<3,1,1>", bytes_fwd, ms_fwd
     achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0

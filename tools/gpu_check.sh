@@ -15,7 +15,7 @@ timeout 600 python bench.py 2>&1 | tail -3 | tee gpurun_out/bench.log
 timeout 300 python bench.py --scene sphere --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_sphere.log
 timeout 300 python bench.py --image 100 --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_100.log
 echo "== rocprofv3 =="
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof_bench.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/rocprof_bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof -name "*stats*" | head; 
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"

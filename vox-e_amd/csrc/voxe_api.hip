@@ -1,6 +1,7 @@
 // voxe_api.hip -- the extern "C" boundary of libvoxe_hip.so (see include/voxe.h).
 // Validation + argument marshalling only; kernels live in voxe_render.hip / voxe_grid_ops.hip.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/voxe.h"
@@ -78,6 +79,15 @@ WsLayout ws_layout(const VoxeGridDesc* g) {
   l.grad_off = bytes;
   l.total = 2 * bytes;
   return l;
+}
+
+// VOXE_BWD_MODE=scatter forces the plain global-atomic backward (A/B measurements, debugging)
+bool force_scatter_bwd() {
+  static const int mode = [] {
+    const char* e = getenv("VOXE_BWD_MODE");
+    return (e && strcmp(e, "scatter") == 0) ? 1 : 0;
+  }();
+  return mode == 1;
 }
 
 int finish() { return hipGetLastError() == hipSuccess ? VOXE_OK : VOXE_ERR_LAUNCH; }
@@ -231,7 +241,10 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               d_densities != nullptr, d_features != nullptr};
     PhaseTimer t(PH_BWD, s);
-    launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
+    if (tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd())
+      launch_bwd_tile(dg, dc, a, s);
+    else
+      launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
   }
   {
     PhaseTimer t(PH_UNPACK, s);

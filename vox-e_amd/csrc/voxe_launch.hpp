@@ -35,6 +35,10 @@ void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const B
 void launch_probe(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const ProbeArgs& a,
                   hipStream_t st);
 
+// voxe_render_tile.hip: LDS-window backward for image-ordered SH-0 / attention renders
+bool tile_bwd_supported(const DevCfg& c, int deg);
+void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st);
+
 // voxe_grid_ops.hip
 void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,
                       float* rays_d, hipStream_t st);

@@ -1,0 +1,142 @@
+// voxe_render_common.hpp -- per-ray device code shared by the render kernels (forward, the two
+// backward variants and the probe): thread->ray mapping, ray context, trilinear gather.
+#pragma once
+
+#include "voxe_device.hpp"
+
+namespace voxe {
+
+// ------------------------------------------------------------------------------------------------
+// Thread -> ray mapping.
+//   * XCD-aware: hardware places block b on XCD b % 8 (observed, not contractual; only speed depends
+//     on it).  Logical work item = (b % 8) * ceil(nb/8) + b / 8, so each XCD walks a contiguous
+//     band of the image and its private 4 MiB L2 sees a compact part of the frustum.
+//   * image_width > 0: a 256-thread block is a 16x16 pixel tile, each wave an 8x8 sub-tile, so the
+//     64 lanes of a wave touch a ~4x4x2 voxel neighbourhood per step (coalesced 16 B texel reads).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool map_ray(const DevCfg& c, long long& r) {
+  const int nb = gridDim.x;
+  const int per = nb >> 3;  // host launches a multiple of 8 blocks
+  const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int tid = threadIdx.x;
+  if (c.image_width > 0) {
+    const int W = c.image_width;
+    const int H = (int)(c.R / W);
+    const int ntx = (W + 15) >> 4;
+    const int ty = logical / ntx, tx = logical - ty * ntx;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = (tx << 4) + ((wave & 1) << 3) + (lane & 7);
+    const int py = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    if (px >= W || py >= H) return false;
+    r = (long long)py * W + px;
+    return true;
+  }
+  r = (long long)logical * 256 + tid;
+  return r < c.R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-ray state shared by forward / backward / probe
+// ------------------------------------------------------------------------------------------------
+template <int COUT, int NCM, int NCU>
+struct RayCtx {
+  static constexpr int C = COUT * NCM + 1;
+  float o[3], d[3], dnorm;
+  float basis[NCU];
+  DepthGen dg;
+  int k_lo, k_hi;
+
+  __device__ __forceinline__ void init(const DevGrid& g, const DevCfg& c, long long r,
+                                       const float* __restrict__ rays_o,
+                                       const float* __restrict__ rays_d,
+                                       const float* __restrict__ jitter) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o[a] = rays_o[3 * r + a]; d[a] = rays_d[3 * r + a]; }
+    // rays.directions.norm(dim=-1)  (accumulate.py:55, process.py:53)
+    dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if constexpr (NCU > 1) {
+      const float v[3] = {d[0] / dnorm, d[1] / dnorm, d[2] / dnorm};
+      sh_basis<NCU>(v, basis);
+    } else {
+      basis[0] = kC0;
+    }
+    dg.near = c.near; dg.far = c.far;
+    dg.lindisp = c.lindisp != 0;
+    if (c.aabb_clip) {  // sample.py:187-202 (linear_disparity is not forwarded there)
+      ray_aabb_bounds(g, o, d, dg.near, dg.far);
+      dg.lindisp = false;
+    }
+    dg.S = c.S; dg.half = c.S >> 1;
+    dg.step = 1.0f / (float)(c.S - 1);
+    dg.perturb = c.perturb != 0;
+    dg.jit = jitter ? jitter + r * c.S : nullptr;
+    dg.k0 = c.key0; dg.k1 = c.key1; dg.c3 = c.ctr3;
+    dg.c0 = (uint32_t)r; dg.c1 = (uint32_t)((unsigned long long)r >> 32);
+    dg.rnd_block = -1;
+    inside_range(g, c, dg, o, d, k_lo, k_hi);
+  }
+
+  __device__ __forceinline__ void point(float z, float (&p)[3]) const {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float dz = d[a] * z;  // sample.py:67: o + d * z (two roundings)
+      p[a] = o[a] + dz;
+    }
+  }
+};
+
+// Interpolate density + features at the 8 corners (ATen order, zero padding) and evaluate
+// sigma = post(v), rad_c = sum_j basis_j * coef_cj   (process.py:45-78, voxels.py:307-332)
+template <int COUT, int NCM, int NCU>
+__device__ __forceinline__ void gather(const float* __restrict__ packed, const Corners& cr,
+                                       const float (&basis)[NCU], float& v, float (&rad)[COUT]) {
+  constexpr int C = COUT * NCM + 1;
+  float f[COUT * NCU];
+#pragma unroll
+  for (int i = 0; i < COUT * NCU; ++i) f[i] = 0.0f;
+  v = 0.0f;
+  if constexpr (C == 4) {
+    float4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = reinterpret_cast<const float4*>(packed)[cr.vox[k]];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = cr.wgt[k];
+      f[0] = f[0] + t[k].x * w;
+      f[1] = f[1] + t[k].y * w;
+      f[2] = f[2] + t[k].z * w;
+      v = v + t[k].w * w;
+    }
+  } else if constexpr (C == 2) {
+    float2 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = reinterpret_cast<const float2*>(packed)[cr.vox[k]];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = cr.wgt[k];
+      f[0] = f[0] + t[k].x * w;
+      v = v + t[k].y * w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = cr.wgt[k];
+      const float* __restrict__ src = packed + (long long)cr.vox[k] * C;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch)
+#pragma unroll
+        for (int j = 0; j < NCU; ++j) f[ch * NCU + j] = f[ch * NCU + j] + src[ch * NCM + j] * w;
+      v = v + src[C - 1] * w;
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) {
+    float r = basis[0] * f[ch * NCU];
+#pragma unroll
+    for (int j = 1; j < NCU; ++j) r = r + basis[j] * f[ch * NCU + j];
+    rad[ch] = r;
+  }
+}
+
+
+}  // namespace voxe

@@ -1,0 +1,337 @@
+// voxe_render_tile.hip -- backward render kernel for image-ordered rays: LDS gradient window.
+//
+// Why: the memory side of MI355X retires ~20 G atomic cache-line requests/s chip-wide
+// (profiles/r01_microbench_atomics.md); scattering every trilinear corner with its own global
+// atomicAdd (render_bwd_kernel, 735 M per 400x400 image) is bound by exactly that (33.7 ms).
+// Neighbouring rays hit the same voxels (~2.6 rays per voxel width), so the adds are combined on chip:
+//
+//   * one WAVE (64 lanes) = one 8x8 pixel tile, one lane per ray, all lanes march in lock step over the
+//     sample index k (the per-ray math is identical to render_bwd_kernel);
+//   * the tile's gradient is accumulated in a per-wave LDS window that slides along the tile's dominant
+//     march axis m: a ring of 8 voxel layers x (8 x 8) lateral voxels x C channels, stored as DOUBLE
+//     and updated with ds_add_f64 (~10 clk per wave instruction; ds_add_f32 is a 193-clk serial path);
+//     the lateral origin of every layer follows the tile's reference ray (a sheared, ray-aligned box),
+//     so 8x8 suffices for any view direction;
+//   * lanes of one cell rotate through the 8 corners ((c + rot(lane)) & 7) so that the lanes of a wave
+//     instruction rarely target the same LDS address;
+//   * a layer is flushed once no lane can touch it again (wave-min of the lanes' next cell layer): 16
+//     voxels x 4 channels per global atomic instruction, i.e. 16-byte-dense requests (z-runs share lines);
+//   * anything that falls outside the window goes straight to a global float atomic, so correctness
+//     never depends on the window heuristics.
+//
+// Gradient formulas: see render_bwd_kernel (voxe_render.hip).  Reference: autograd through
+// thre3d_atom/rendering/volumetric/{sample,process,accumulate}.py and thre3d_reprs/voxels.py.
+#include <limits.h>
+
+#include "voxe_device.hpp"
+#include "voxe_launch.hpp"
+#include "voxe_render_common.hpp"
+
+namespace voxe {
+
+constexpr int kRing = 8;                 // live layers along the march axis
+constexpr int kLat = 8;                  // lateral window edge (voxels)
+constexpr int kLayerSlots = kLat * kLat; // 64
+constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
+
+// wave-wide integer min / max, result wave-uniform (DPP inside rows of 16, readlane across rows).
+// Must be called with all 64 lanes active.
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+__device__ __forceinline__ int wave_max_i32(int v) { return -wave_min_i32(-v); }
+
+__device__ __forceinline__ float readlane_f32(float x, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+
+// wave-uniform geometry of the sliding window
+struct Window {
+  int m, u, v;          // march axis and the two lateral axes (v = z whenever m != z)
+  int sgn;              // +1: keys grow with the voxel index along m, -1: they shrink
+  float Au, Bu, Av, Bv; // lateral position of the reference ray as a function of the m index
+  int stride_m, stride_u, stride_v;
+  int base;             // lowest live layer key
+
+  __device__ __forceinline__ int off_u(int im) const { return (int)floorf(Au + Bu * (float)im) - 3; }
+  __device__ __forceinline__ int off_v(int im) const { return (int)floorf(Av + Bv * (float)im) - 3; }
+  // storage position of lateral cell (a, b) inside its layer: rotated per layer so that the same (a, b)
+  // of neighbouring layers lands in different LDS banks
+  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + 21 * (key & 7)) & 63; }
+};
+// the channel planes are 512 doubles (a multiple of all 64 banks) apart: rotate the in-layer position
+// by 8 slots per channel so the 4 channels of one voxel (read together by the flush) use 4 bank groups
+__device__ __forceinline__ int chan_pos(int pos, int ch) { return (pos + 8 * ch) & 63; }
+
+template <int C>
+__device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
+                                            const Window& w, int key, int lane) {
+  const int im = w.sgn * key;
+  const int offu = w.off_u(im), offv = w.off_v(im);
+  const int lbase = (key & 7) * kLayerSlots;
+  constexpr int kPerInstr = 64 / C;  // voxels per wave instruction (C == 4 -> 16, C == 2 -> 32)
+#pragma unroll
+  for (int j = 0; j < kLayerSlots / kPerInstr; ++j) {
+    const int ab = j * kPerInstr + lane / C;  // lateral cell: a = ab >> 3, b = ab & 7 (b is the z-run)
+    const int ch = lane % C;
+    const int idx = ch * kWinSlots + lbase + chan_pos(w.layer_pos(key, ab), ch);
+    const double val = win[idx];
+    if (val != 0.0) {
+      win[idx] = 0.0;
+      const int iu = (ab >> 3) + offu, iv = (ab & 7) + offv;
+      const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+      atomicAdd(gpacked + vox * C + ch, (float)val);
+    }
+  }
+}
+
+template <int COUT, bool WANT_D, bool WANT_F>
+__global__ __launch_bounds__(64) void render_bwd_tile_kernel(
+    DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ jitter,
+    const float* __restrict__ colour, const float* __restrict__ depth,
+    const float* __restrict__ acc, const float* __restrict__ d_colour,
+    const float* __restrict__ d_depth, const float* __restrict__ d_acc,
+    float* __restrict__ gpacked) {
+  constexpr int C = COUT + 1;
+  __shared__ double win[C * kWinSlots];
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < C * kWinSlots / 64; ++i) win[i * 64 + lane] = 0.0;
+
+  // ---- tile -> ray (XCD-banded like map_ray) ----------------------------------------------------
+  const int per = gridDim.x >> 3;
+  const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  const int W = c.image_width, H = (int)(c.R / W);
+  const int ntx = (W + 7) >> 3;
+  const int ty = logical / ntx, tx = logical - ty * ntx;
+  const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
+  const bool alive = (px < W) && (py < H);
+  const long long r = alive ? (long long)py * W + px : 0;
+
+  RayCtx<COUT, 1, 1> rc;
+  rc.init(g, c, r, rays_o, rays_d, jitter);
+  const int k_lo = rc.k_lo;
+  int k_hi = alive ? rc.k_hi : k_lo - 1;
+  const bool has = k_lo <= k_hi;
+  const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
+  const int kmax = wave_max_i32(has ? k_hi : -1);
+  if (kmin > kmax) return;  // wave-uniform: no ray of the tile meets the volume
+
+  // ---- window geometry from a reference ray (the lane next to the tile centre, if it has samples) ----
+  Window w;
+  {
+    const unsigned long long hm = __ballot(has);
+    const int ref = ((hm >> 27) & 1ull) ? 27 : (__ffsll((long long)hm) - 1);
+    const int N[3] = {g.X, g.Y, g.Z};
+    float U0[3], DU[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
+      const float half = 0.5f * (float)N[a];
+      U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
+      DU[a] = rd * g.scale[a] * half;
+    }
+    const float ax = fabsf(DU[0]), ay = fabsf(DU[1]), az = fabsf(DU[2]);
+    w.m = (ax >= ay && ax >= az) ? 0 : ((ay >= az) ? 1 : 2);
+    w.u = (w.m == 0) ? 1 : 0;
+    w.v = (w.m == 2) ? 1 : 2;
+    const float DUm = (w.m == 0) ? DU[0] : ((w.m == 1) ? DU[1] : DU[2]);
+    const float U0m = (w.m == 0) ? U0[0] : ((w.m == 1) ? U0[1] : U0[2]);
+    const float DUu = (w.u == 0) ? DU[0] : DU[1], U0u = (w.u == 0) ? U0[0] : U0[1];
+    const float DUv = (w.v == 1) ? DU[1] : DU[2], U0v = (w.v == 1) ? U0[1] : U0[2];
+    w.sgn = (DUm < 0.0f) ? -1 : 1;
+    const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
+    w.Bu = DUu * inv; w.Au = U0u - w.Bu * U0m;
+    w.Bv = DUv * inv; w.Av = U0v - w.Bv * U0m;
+    const int stride[3] = {g.Y * g.Z, g.Z, 1};
+    w.stride_m = stride[w.m]; w.stride_u = stride[w.u]; w.stride_v = stride[w.v];
+  }
+  // lowest layer key a sample with low-corner index pm can write (layers pm and pm + 1)
+  auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
+  auto pick = [&](const int (&t)[3], int axis) { return axis == 0 ? t[0] : (axis == 1 ? t[1] : t[2]); };
+
+  // ---- per-ray constants of the backward (see render_bwd_kernel) -------------------------------
+  float gc[COUT], gsum = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
+  const float gdep = d_depth ? d_depth[r] : 0.0f;
+  const float gacc = d_acc ? d_acc[r] : 0.0f;
+  const bool white = c.white && !c.attn;
+  const float asum = acc[r];
+  float total = gdep * depth[r] + gacc * asum;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) {
+    const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
+    total += gc[ch] * csum;
+  }
+  if (white) total -= gsum * asum;
+
+  // first sample of every ray (rolling: z_cur / fp_cur always describe sample max(k, k_lo))
+  float z_cur = 0.0f;
+  Footprint fp_cur;
+  fp_cur.inside = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
+  int first_key = INT_MAX;
+  if (has) {
+    z_cur = rc.dg.z(k_lo);
+    float p[3];
+    rc.point(z_cur, p);
+    footprint(g, p, fp_cur);
+    first_key = minkey(pick(fp_cur.i0, w.m));
+  }
+  w.base = wave_min_i32(first_key);
+  __syncthreads();  // window zeroed
+
+  const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // corner rotation: neighbours in the tile differ
+  float prefix = 0.0f, T = 1.0f;
+
+  for (int k = kmin; k <= kmax; ++k) {
+    const bool on = has && (k >= k_lo) && (k <= k_hi);
+    if (on) {
+      const float z = z_cur;
+      const Footprint fp = fp_cur;
+      const bool last = (k == c.S - 1);
+      float z_next = z;
+      if (!last) {
+        z_next = rc.dg.z(k + 1);
+        float pn[3];
+        rc.point(z_next, pn);
+        footprint(g, pn, fp_cur);
+        z_cur = z_next;
+      }
+      if (fp.inside) {
+        Corners cr;
+        corners(g, fp, cr);
+        float v, rad[COUT];
+        gather<COUT, 1, 1>(packed, cr, rc.basis, v, rad);
+        const float sigma = post_activate(g.post_act, v);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = expf(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float wk = alpha * T;
+        float col[COUT], dldw = gdep * z + gacc;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw += gc[ch] * col[ch]; }
+        if (white) dldw -= gsum;
+        prefix += dldw * wk;
+        const float suffix = last ? 0.0f : (total - prefix);
+        const float tail = (om > 0.0f) ? suffix / om : 0.0f;
+        const float dsig = (delta * e) * (T * dldw - tail);
+        // per-channel gradient of the packed texel: (d rad_c * C0 ..., d v)
+        float gch[C];
+        bool any = false;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) {
+          gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
+          any = any || (gch[ch] != 0.0f);
+        }
+        gch[COUT] = WANT_D ? dsig * post_activate_grad(g.post_act, v) : 0.0f;
+        any = any || (gch[COUT] != 0.0f);
+        T = T * om;
+
+        if (any) {
+          // permute the footprint into (march, lateral u, lateral v) order; zero the weights of
+          // out-of-range corners (ATen skips them)
+          const int N[3] = {g.X, g.Y, g.Z};
+          const int pm = pick(fp.i0, w.m), pu = pick(fp.i0, w.u), pv = pick(fp.i0, w.v);
+          const int Nm = pick(N, w.m), Nu = pick(N, w.u), Nv = pick(N, w.v);
+          float wm[2], wu[2], wv[2];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const float am = (w.m == 0) ? fp.w[0][s] : ((w.m == 1) ? fp.w[1][s] : fp.w[2][s]);
+            const float au = (w.u == 0) ? fp.w[0][s] : fp.w[1][s];
+            const float av = (w.v == 1) ? fp.w[1][s] : fp.w[2][s];
+            wm[s] = (pm + s >= 0 && pm + s < Nm) ? am : 0.0f;
+            wu[s] = (pu + s >= 0 && pu + s < Nu) ? au : 0.0f;
+            wv[s] = (pv + s >= 0 && pv + s < Nv) ? av : 0.0f;
+          }
+          int offu[2], offv[2];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) { offu[s] = w.off_u(pm + s); offv[s] = w.off_v(pm + s); }
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) {
+            const int cidx = (cc + rot) & 7;
+            const int cm = cidx & 1, cu = (cidx >> 1) & 1, cv = cidx >> 2;
+            const float wgt = ((cm ? wm[1] : wm[0]) * (cu ? wu[1] : wu[0])) * (cv ? wv[1] : wv[0]);
+            if (wgt != 0.0f) {
+              const int im = pm + cm, iu = pu + cu, iv = pv + cv;
+              const int key = w.sgn * im;
+              const int a = iu - (cm ? offu[1] : offu[0]), b = iv - (cm ? offv[1] : offv[0]);
+              const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
+                                 ((unsigned)b < (unsigned)kLat);
+              if (inwin) {
+                const int lbase = (key & 7) * kLayerSlots, pos = w.layer_pos(key, a * kLat + b);
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                  if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                    __hip_atomic_fetch_add(&win[ch * kWinSlots + lbase + chan_pos(pos, ch)], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              } else {  // outside the LDS window: plain global scatter (rare)
+                const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+#pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                  if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)) atomicAdd(gpacked + vox * C + ch, gch[ch] * wgt);
+                }
+              }
+            }
+          }
+        }
+        if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k;
+      }
+    }
+    // ---- slide the window: flush every layer no lane can reach any more ---------------------------
+    int lb = INT_MAX;
+    if (has) {
+      if (k + 1 < k_lo) lb = first_key;
+      else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
+    }
+    const int newbase = wave_min_i32(lb);
+    if (newbase > w.base) {  // wave-uniform
+      __syncthreads();
+      const long long adv = (long long)newbase - (long long)w.base;
+      const int nflush = adv < kRing ? (int)adv : kRing;
+      for (int i = 0; i < nflush; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
+      w.base = newbase;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (w.base != INT_MAX) {
+    for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
+  }
+}
+
+bool tile_bwd_supported(const DevCfg& c, int deg) { return c.image_width > 0 && deg == 0; }
+
+void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
+  const long long W = c.image_width, H = c.R / W;
+  long long nb = ((W + 7) / 8) * ((H + 7) / 8);
+  nb = (nb + 7) / 8 * 8;
+#define VOXE_TBWD(COUT, WD, WF)                                                                   \
+  render_bwd_tile_kernel<COUT, WD, WF><<<(int)nb, 64, 0, st>>>(                                   \
+      g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
+      a.d_depth, a.d_acc, a.gpacked)
+  if (c.attn) {
+    if (a.want_d && a.want_f) VOXE_TBWD(1, true, true);
+    else if (a.want_d) VOXE_TBWD(1, true, false);
+    else VOXE_TBWD(1, false, true);
+  } else {
+    if (a.want_d && a.want_f) VOXE_TBWD(3, true, true);
+    else if (a.want_d) VOXE_TBWD(3, true, false);
+    else VOXE_TBWD(3, false, true);
+  }
+#undef VOXE_TBWD
+}
+
+}  // namespace voxe
