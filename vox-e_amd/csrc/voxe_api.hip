@@ -6,10 +6,31 @@
 
 #include "../../include/voxe.h"
 #include "voxe_launch.hpp"
+#include "voxe_render_common.hpp"
 
 using namespace voxe;
 
 namespace {
+
+// VOXE_BWD_MODE=scatter forces the plain global-atomic backward (A/B measurements, debugging)
+bool force_scatter_bwd() {
+  static const int mode = [] {
+    const char* e = getenv("VOXE_BWD_MODE");
+    return (e && strcmp(e, "scatter") == 0) ? 1 : 0;
+  }();
+  return mode == 1;
+}
+
+// VOXE_TILE_MAP = band (default) | linear | rows : block -> tile mapping (see logical_tile())
+int tile_map_mode() {
+  static const int mode = [] {
+    const char* e = getenv("VOXE_TILE_MAP");
+    if (e && strcmp(e, "linear") == 0) return 1;
+    if (e && strcmp(e, "rows") == 0) return 2;
+    return 0;
+  }();
+  return mode;
+}
 
 struct Variant {
   int cout, ncoef_mem, C;
@@ -62,32 +83,29 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32);
   dc->ctr3 = (uint32_t)c->rng_offset;
   dc->image_width = c->image_width;
+  dc->map_mode = tile_map_mode();
   dc->R = R;
 }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// workspace = [ packed grid | packed gradient ]
+// workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, total;
+  size_t packed_off, grad_off, state_off, fwd_total, total;
 };
-WsLayout ws_layout(const VoxeGridDesc* g) {
+WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t nvox = (size_t)g->X * g->Y * g->Z;
   const size_t bytes = align_up(nvox * (size_t)(g->F + 1) * sizeof(float), 256);
+  const int cout = g->feature_kind == VOXE_FEAT_ATTN ? 1 : 3;
+  const int nseg = c ? num_segments(c->num_samples) : 1;
+  const size_t state = align_up((size_t)(nseg - 1) * (size_t)(cout + 3) * (size_t)(R > 0 ? R : 0) * sizeof(float), 256);
   WsLayout l;
   l.packed_off = 0;
   l.grad_off = bytes;
-  l.total = 2 * bytes;
+  l.state_off = 2 * bytes;
+  l.fwd_total = bytes;  // the forward alone needs only the packed grid (states are written when they fit)
+  l.total = 2 * bytes + state;
   return l;
-}
-
-// VOXE_BWD_MODE=scatter forces the plain global-atomic backward (A/B measurements, debugging)
-bool force_scatter_bwd() {
-  static const int mode = [] {
-    const char* e = getenv("VOXE_BWD_MODE");
-    return (e && strcmp(e, "scatter") == 0) ? 1 : 0;
-  }();
-  return mode == 1;
 }
 
 int finish() { return hipGetLastError() == hipSuccess ? VOXE_OK : VOXE_ERR_LAUNCH; }
@@ -188,9 +206,8 @@ int voxe_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const fl
 }
 
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
-  (void)cfg; (void)R;
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
-  return ws_layout(grid).total;
+  return ws_layout(grid, cfg, R).total;
 }
 
 int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
@@ -201,15 +218,19 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   const int st = validate(grid, cfg, R, &v);
   if (st) return st;
   if (R > 0 && (!rays_o || !rays_d || !colour)) return VOXE_ERR_NULL_POINTER;
-  const WsLayout l = ws_layout(grid);
-  if (!workspace || workspace_bytes < l.grad_off) return VOXE_ERR_WORKSPACE;
+  const WsLayout l = ws_layout(grid, cfg, R);
+  if (!workspace || workspace_bytes < l.fwd_total) return VOXE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* packed = (float*)((char*)workspace + l.packed_off);
   if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
   if (R == 0) return finish();
   DevGrid dg; DevCfg dc;
   make_dev(grid, cfg, R, v, &dg, &dc);
-  FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity};
+  // depth-segment states for the segmented backward, when that backward applies and the workspace holds them
+  float* state = nullptr;
+  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd() && workspace_bytes >= l.total)
+    state = (float*)((char*)workspace + l.state_off);
+  FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state};
   { PhaseTimer t(PH_FWD, s); launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s); }
   return finish();
 }
@@ -225,23 +246,31 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   if (R > 0 && (!rays_o || !rays_d || !colour || !depth || !acc || !d_colour))
     return VOXE_ERR_NULL_POINTER;
   if (!d_densities && !d_features) return VOXE_OK;
-  const WsLayout l = ws_layout(grid);
+  const WsLayout l = ws_layout(grid, cfg, R);
   if (!workspace || workspace_bytes < l.total) return VOXE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* packed = (float*)((char*)workspace + l.packed_off);
   float* gpacked = (float*)((char*)workspace + l.grad_off);
+  float* state = (float*)((char*)workspace + l.state_off);
   if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
   {
     PhaseTimer t(PH_MEMSET, s);
-    if (hipMemsetAsync(gpacked, 0, l.total - l.grad_off, s) != hipSuccess) return VOXE_ERR_LAUNCH;
+    if (hipMemsetAsync(gpacked, 0, l.state_off - l.grad_off, s) != hipSuccess) return VOXE_ERR_LAUNCH;
   }
   if (R > 0) {
     DevGrid dg; DevCfg dc;
     make_dev(grid, cfg, R, v, &dg, &dc);
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
-              d_densities != nullptr, d_features != nullptr};
+              d_densities != nullptr, d_features != nullptr, state};
+    const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd();
+    if (tiled && !cfg->ray_state_valid) {
+      // the caller's workspace does not hold this call's forward states: re-march to rebuild them
+      PhaseTimer t(PH_FWD, s);
+      FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state};
+      launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, s);
+    }
     PhaseTimer t(PH_BWD, s);
-    if (tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd())
+    if (tiled)
       launch_bwd_tile(dg, dc, a, s);
     else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
@@ -261,8 +290,8 @@ int voxe_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
   const int st = validate(grid, cfg, R, &v);
   if (st) return st;
   if (R > 0 && (!rays_o || !rays_d)) return VOXE_ERR_NULL_POINTER;
-  const WsLayout l = ws_layout(grid);
-  if (!workspace || workspace_bytes < l.grad_off) return VOXE_ERR_WORKSPACE;
+  const WsLayout l = ws_layout(grid, cfg, R);
+  if (!workspace || workspace_bytes < l.fwd_total) return VOXE_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   float* packed = (float*)((char*)workspace + l.packed_off);
   if (!cfg->reuse_packed_grid) launch_pack_any(grid, packed, s);

@@ -33,6 +33,7 @@ struct DevCfg {
   float term_eps;
   uint32_t key0, key1, ctr3;  // Philox key / 4th counter word
   int image_width;            // 0 = linear ray order
+  int map_mode;               // block -> tile mapping: 0 XCD bands, 1 linear, 2 tile rows interleaved over XCDs
   long long R;
 };
 

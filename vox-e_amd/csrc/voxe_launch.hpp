@@ -10,11 +10,13 @@ namespace voxe {
 struct FwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter;
   float *colour, *depth, *acc, *disparity;
+  float* ray_state;  // per-ray depth-segment states (nullable): see ray_state_index()
 };
 struct BwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc;
   float* gpacked;
   bool want_d, want_f;
+  const float* ray_state;  // states written by the forward for the same rays (tile backward only)
 };
 struct ProbeArgs {
   const float *packed, *rays_o, *rays_d, *jitter;

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
                                                          float* __restrict__ colour,
                                                          float* __restrict__ depth,
                                                          float* __restrict__ acc,
-                                                         float* __restrict__ disparity) {
+                                                         float* __restrict__ disparity,
+                                                         float* __restrict__ ray_state) {
   long long r;
   if (!map_ray(c, r)) return;
   RayCtx<COUT, NCM, NCU> rc;
@@ -100,9 +101,22 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
   for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
 
+  // depth-segment states for the segmented backward: state BEFORE sample b * kSegLen
+  const int nbound = ray_state ? num_segments(c.S) - 1 : 0;
+  int nextb = 1;
+  auto save_state = [&](int b) {
+    constexpr int NC = COUT + 3;
+    ray_state[ray_state_index(b, 0, NC, c.R, r)] = T;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) ray_state[ray_state_index(b, 1 + ch, NC, c.R, r)] = csum[ch];
+    ray_state[ray_state_index(b, 1 + COUT, NC, c.R, r)] = asum;
+    ray_state[ray_state_index(b, 2 + COUT, NC, c.R, r)] = dsum;
+  };
+
   if (rc.k_lo <= rc.k_hi) {
     float z_next = rc.dg.z(rc.k_lo);
     for (int k = rc.k_lo; k <= rc.k_hi; ++k) {
+      while (nextb <= nbound && nextb * kSegLen <= k) { save_state(nextb); ++nextb; }
       const float z = z_next;
       const bool last = (k == c.S - 1);
       if (!last) z_next = rc.dg.z(k + 1);
@@ -131,6 +145,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
       if (c.term_eps > 0.0f && T < c.term_eps) break;
     }
   }
+  while (nextb <= nbound) { save_state(nextb); ++nextb; }  // boundaries behind the last sample: final state
   // accumulate.py:77-88
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) {
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
       if (c.attn) bk = bk * 0.0f;
       col = col + bk;
     }
-    colour[r * COUT + ch] = col;
+    if (colour) colour[r * COUT + ch] = col;
   }
   if (depth) depth[r] = dsum;
   if (acc) acc[r] = asum;
@@ -297,15 +312,11 @@ __global__ __launch_bounds__(256) void sample_probe_kernel(
 // Host-side launchers (called from voxe_api.hip)
 // ------------------------------------------------------------------------------------------------
 static inline int blocks_for(const DevCfg& c) {
-  long long nb;
   if (c.image_width > 0) {
     const long long W = c.image_width, H = c.R / W;
-    nb = ((W + 15) / 16) * ((H + 15) / 16);
-  } else {
-    nb = (c.R + 255) / 256;
+    return blocks_for_tiles(c.map_mode, (W + 15) / 16, (H + 15) / 16);
   }
-  nb = (nb + 7) / 8 * 8;  // map_ray(): 8 XCD bands
-  return (int)nb;
+  return blocks_for_tiles(c.map_mode, 1, (c.R + 255) / 256);
 }
 
 template <int C>
@@ -328,7 +339,7 @@ static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d
 template <int COUT, int NCM, int NCU>
 static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
   render_fwd_kernel<COUT, NCM, NCU><<<blocks_for(c), 256, 0, st>>>(
-      g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.disparity);
+      g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
 }
 
 template <int COUT, int NCM, int NCU>

@@ -14,15 +14,50 @@ namespace voxe {
 //   * image_width > 0: a 256-thread block is a 16x16 pixel tile, each wave an 8x8 sub-tile, so the
 //     64 lanes of a wave touch a ~4x4x2 voxel neighbourhood per step (coalesced 16 B texel reads).
 // ------------------------------------------------------------------------------------------------
+// Per-ray depth-segment states.  The image-ordered backward splits every ray's march into segments of
+// kSegLen samples that are processed by different waves; the forward saves, at every segment boundary
+// k = b * kSegLen (b = 1 .. nseg-1), the state BEFORE sample k: transmittance T and the partial sums
+// (csum[COUT], asum, dsum).  Layout [boundary-1][component][ray] (component-major: coalesced per ray run).
+constexpr int kSegLen = VOXE_SEGMENT_SAMPLES;
+__host__ __device__ inline int num_segments(int S) { return (S + kSegLen - 1) / kSegLen; }
+__device__ __forceinline__ long long ray_state_index(int boundary, int comp, int ncomp, long long R, long long r) {
+  return ((long long)(boundary - 1) * ncomp + comp) * R + r;
+}
+
+// logical tile index of this block.  nt = number of tiles, ntx = tiles per image row (1 for linear ray order).
+//   mode 0: XCD bands  -- XCD x (blocks b % 8 == x) walks tiles [x*nt/8, (x+1)*nt/8): compulsory L2 traffic only
+//   mode 1: linear     -- tile = block index (neighbouring tiles on different XCDs)
+//   mode 2: row interleave -- XCD x walks tile rows x, x+8, x+16, ...: balances the XCDs when the work per
+//           row varies (image centre vs borders) at the price of every XCD touching the whole frustum
+// Tiles >= nt (padding of the launch) are reported as -1.
+__device__ __forceinline__ int logical_tile(const DevCfg& c, int ntx, int nty) {
+  const int b = blockIdx.x;
+  if (c.map_mode == 1) return b < ntx * nty ? b : -1;
+  const int x = b & 7, slot = b >> 3;
+  if (c.map_mode == 2) {
+    const int row = x + 8 * (slot / ntx), col = slot % ntx;
+    return row < nty ? row * ntx + col : -1;
+  }
+  const int per = gridDim.x >> 3;  // host launches a multiple of 8 blocks
+  const int t = x * per + slot;
+  return t < ntx * nty ? t : -1;
+}
+
+// number of blocks to launch for nt = ntx * nty tiles under the mapping mode
+static inline int blocks_for_tiles(int map_mode, long long ntx, long long nty) {
+  if (map_mode == 1) return (int)(ntx * nty);
+  if (map_mode == 2) return (int)(8 * ((nty + 7) / 8) * ntx);
+  return (int)((ntx * nty + 7) / 8 * 8);
+}
+
 __device__ __forceinline__ bool map_ray(const DevCfg& c, long long& r) {
-  const int nb = gridDim.x;
-  const int per = nb >> 3;  // host launches a multiple of 8 blocks
-  const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   const int tid = threadIdx.x;
   if (c.image_width > 0) {
     const int W = c.image_width;
     const int H = (int)(c.R / W);
-    const int ntx = (W + 15) >> 4;
+    const int ntx = (W + 15) >> 4, nty = (H + 15) >> 4;
+    const int logical = logical_tile(c, ntx, nty);
+    if (logical < 0) return false;
     const int ty = logical / ntx, tx = logical - ty * ntx;
     const int wave = tid >> 6, lane = tid & 63;
     const int px = (tx << 4) + ((wave & 1) << 3) + (lane & 7);
@@ -31,6 +66,9 @@ __device__ __forceinline__ bool map_ray(const DevCfg& c, long long& r) {
     r = (long long)py * W + px;
     return true;
   }
+  const int nt = (int)((c.R + 255) / 256);
+  const int logical = logical_tile(c, 1, nt);
+  if (logical < 0) return false;
   r = (long long)logical * 256 + tid;
   return r < c.R;
 }

@@ -92,13 +92,13 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
 }
 
 template <int COUT, bool WANT_D, bool WANT_F>
-__global__ __launch_bounds__(64) void render_bwd_tile_kernel(
+__global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
-    float* __restrict__ gpacked) {
+    const float* __restrict__ ray_state, float* __restrict__ gpacked) {
   constexpr int C = COUT + 1;
   __shared__ double win[C * kWinSlots];
   const int lane = threadIdx.x;
@@ -106,20 +106,37 @@ __global__ __launch_bounds__(64) void render_bwd_tile_kernel(
   for (int i = 0; i < C * kWinSlots / 64; ++i) win[i * 64 + lane] = 0.0;
 
   // ---- tile -> ray (XCD-banded like map_ray) ----------------------------------------------------
-  const int per = gridDim.x >> 3;
-  const int logical = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
   const int W = c.image_width, H = (int)(c.R / W);
-  const int ntx = (W + 7) >> 3;
-  const int ty = logical / ntx, tx = logical - ty * ntx;
+  const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
+  // a block = (pixel tile, depth segment): the segments of one tile are consecutive logical indices
+  const int nseg = num_segments(c.S);
+  const int logical = logical_tile(c, ntx * nseg, nty);
+  if (logical < 0) return;  // launch padding (wave-uniform)
+  const int seg = logical % nseg, tile = logical / nseg;
+  const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
+  const int ty = tile / ntx, tx = tile - ty * ntx;
   const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
   const bool alive = (px < W) && (py < H);
   const long long r = alive ? (long long)py * W + px : 0;
 
   RayCtx<COUT, 1, 1> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
-  const int k_lo = rc.k_lo;
-  int k_hi = alive ? rc.k_hi : k_lo - 1;
-  const bool has = k_lo <= k_hi;
+  const int k_lo = max(rc.k_lo, ks);          // this lane's samples inside the segment
+  int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
+  bool has = k_lo <= k_hi;
+  // state at the segment start (transmittance + partial sums of the forward), see save_state()
+  float T = 1.0f, pre_c[COUT], pre_a = 0.0f, pre_d = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = 0.0f;
+  if (has && seg > 0) {
+    constexpr int NC = COUT + 3;
+    T = ray_state[ray_state_index(seg, 0, NC, c.R, r)];
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
+    pre_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
+    pre_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
+    if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
+  }
   const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
   const int kmax = wave_max_i32(has ? k_hi : -1);
   if (kmin > kmax) return;  // wave-uniform: no ray of the tile meets the volume
@@ -172,6 +189,11 @@ __global__ __launch_bounds__(64) void render_bwd_tile_kernel(
     total += gc[ch] * csum;
   }
   if (white) total -= gsum * asum;
+  // prefix = sum_{j < segment start} dL/dw_j w_j from the saved partial sums
+  float prefix = gdep * pre_d + gacc * pre_a;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
+  if (white) prefix -= gsum * pre_a;
 
   // first sample of every ray (rolling: z_cur / fp_cur always describe sample max(k, k_lo))
   float z_cur = 0.0f;
@@ -191,8 +213,6 @@ __global__ __launch_bounds__(64) void render_bwd_tile_kernel(
   __syncthreads();  // window zeroed
 
   const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // corner rotation: neighbours in the tile differ
-  float prefix = 0.0f, T = 1.0f;
-
   for (int k = kmin; k <= kmax; ++k) {
     const bool on = has && (k >= k_lo) && (k <= k_hi);
     if (on) {
@@ -316,12 +336,11 @@ bool tile_bwd_supported(const DevCfg& c, int deg) { return c.image_width > 0 && 
 
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
   const long long W = c.image_width, H = c.R / W;
-  long long nb = ((W + 7) / 8) * ((H + 7) / 8);
-  nb = (nb + 7) / 8 * 8;
+  const int nb = blocks_for_tiles(c.map_mode, ((W + 7) / 8) * num_segments(c.S), (H + 7) / 8);
 #define VOXE_TBWD(COUT, WD, WF)                                                                   \
-  render_bwd_tile_kernel<COUT, WD, WF><<<(int)nb, 64, 0, st>>>(                                   \
+  render_bwd_tile_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                   \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.gpacked)
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked)
   if (c.attn) {
     if (a.want_d && a.want_f) VOXE_TBWD(1, true, true);
     else if (a.want_d) VOXE_TBWD(1, true, false);

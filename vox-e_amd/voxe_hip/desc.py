@@ -67,6 +67,7 @@ def make_render_cfg(
     rng_offset: int = 0,
     reuse_packed_grid: bool = False,
     image_width: Optional[int] = None,
+    ray_state_valid: bool = False,
 ) -> abi.VoxeRenderCfg:
     c = abi.VoxeRenderCfg()
     c.num_samples = int(num_samples)
@@ -83,4 +84,5 @@ def make_render_cfg(
     c.rng_offset = int(rng_offset) & 0xFFFFFFFFFFFFFFFF
     c.reuse_packed_grid = int(bool(reuse_packed_grid))
     c.image_width = int(image_width or 0)
+    c.ray_state_valid = int(bool(ray_state_valid))
     return c

@@ -44,21 +44,30 @@ class Workspace:
 
     def __init__(self):
         self.buf: Optional[torch.Tensor] = None
-        self.key = None
+        self.key = None        # which grid values are packed in the buffer
+        self.state_key = None  # which forward call's per-ray depth-segment states it holds
 
     def ensure(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self.key = None
+            self.state_key = None
         return self.buf
 
     def invalidate(self):
         self.key = None
+        self.state_key = None
 
 
 def _pack_key(spec: GridSpec, densities: torch.Tensor, features: torch.Tensor):
     return (densities.data_ptr(), densities._version, features.data_ptr(), features._version,
             tuple(features.shape), spec.density_scale, spec.density_pre_act, spec.feature_kind)
+
+
+def _state_key(pack_key, params: RenderParams, rays_o, rays_d, jitter, rng):
+    """identity of a forward call: the backward may consume the ray states only of exactly this call"""
+    return (pack_key, tuple(vars(params).items()), rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0],
+            None if jitter is None else jitter.data_ptr(), tuple(rng))
 
 
 def _descs(spec: GridSpec, params: RenderParams, densities, features, seed, rng_offset, reuse):
@@ -106,6 +115,7 @@ def render_fwd_into(spec: GridSpec, params: RenderParams, densities, features, r
                                 ptr(depth), ptr(acc), ptr(disparity), ptr(ws), ws.numel(),
                                 stream_ptr(device)), "voxe_render_fwd")
     workspace.key = key
+    workspace.state_key = _state_key(key, params, rays_o, rays_d, jitter, rng)
 
 
 def render_bwd_into(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
@@ -120,6 +130,7 @@ def render_bwd_into(spec: GridSpec, params: RenderParams, densities, features, r
     with torch.cuda.device(device):
         ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
         c.reuse_packed_grid = int(workspace.key == key)
+        c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng))
         check(L.voxe_render_bwd(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
                                 ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
                                 ptr(d_densities), ptr(d_features), int(accumulate), ptr(ws), ws.numel(),
