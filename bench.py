@@ -3,7 +3,7 @@
 
 Workload (BASELINE.json configs[1] / SURVEY.md 8d): 160^3 SH-0 softplus grid (U(-1,1) init, seed 42,
 expected_density_scale 100/3), one 400x400 synthetic camera per GPU, S = 256 samples per ray with the
-reference's always-on stratified jitter (in-kernel Philox), white background, upstream gradient
+reference's always-on stratified jitter (in-kernel counter hash), white background, upstream gradient
 d_colour ~ N(0,1) (seed 43).  One STEP = render forward + render backward through the C ABI
 (pack + forward kernel + gradient memset + backward kernel + unpack), the RCCL all-reduce of the
 voxel-grid gradient when N > 1, and the fused Adam update of both grid tensors (so the grid really

@@ -76,7 +76,7 @@ typedef struct VoxeRenderCfg {
   int32_t num_samples;        /* S   SHVoxGridRenderConfig.num_samples_per_ray (renderers.py:32)  */
   float near, far;            /* CameraBounds (sample.py:38-41)                                   */
   int32_t perturb;            /* stratified jitter (sample.py:55-64). jitter==NULL -> in-kernel
-                                 Philox4x32-10 keyed by (seed, rng_offset, ray, sample)            */
+                                 counter hash keyed by (seed, rng_offset, ray, sample)             */
   int32_t linear_disparity;   /* sample.py:48-51                                                  */
   int32_t aabb_clip;          /* optimized_sampling: per-ray bounds from the ray/AABB slab test
                                  (sample.py:71-202)                                               */
@@ -238,8 +238,8 @@ int voxe_cpu_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t 
                                 float* dst, int32_t X2, int32_t Y2, int32_t Z2);
 /* number of OpenMP threads the oracle will use (1 when built without OpenMP) */
 int voxe_cpu_num_threads(void);
-/* Philox jitter value the HIP kernels draw for (seed, offset, ray, sample): lets tests replay it */
-float voxe_cpu_philox_uniform(uint64_t seed, uint64_t rng_offset, int64_t ray, int32_t sample);
+/* jitter value the HIP kernels draw for (seed, offset, ray, sample): lets tests replay the stream */
+float voxe_cpu_jitter_uniform(uint64_t seed, uint64_t rng_offset, int64_t ray, int32_t sample);
 
 #ifdef __cplusplus
 }

@@ -102,13 +102,13 @@ def num_threads() -> int:
     return int(lib().voxe_cpu_num_threads())
 
 
-def philox_uniform(seed: int, rng_offset: int, ray: int, sample: int) -> float:
-    return float(lib().voxe_cpu_philox_uniform(seed, rng_offset, ray, sample))
+def jitter_uniform(seed: int, rng_offset: int, ray: int, sample: int) -> float:
+    return float(lib().voxe_cpu_jitter_uniform(seed, rng_offset, ray, sample))
 
 
-def philox_jitter(seed: int, rng_offset: int, R: int, S: int) -> np.ndarray:
+def jitter_stream(seed: int, rng_offset: int, R: int, S: int) -> np.ndarray:
     out = np.empty((R, S), np.float32)
-    f = lib().voxe_cpu_philox_uniform
+    f = lib().voxe_cpu_jitter_uniform
     for r in range(R):
         for k in range(S):
             out[r, k] = f(seed, rng_offset, r, k)

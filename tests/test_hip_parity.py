@@ -119,8 +119,8 @@ def test_sh_degrees(deg, mode):
     assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
 
 
-def test_philox_jitter_matches_oracle_stream():
-    """perturb with no jitter tensor: the in-kernel Philox stream equals the oracle's, depths bit-exact."""
+def test_jitter_stream_matches_oracle_stream():
+    """perturb with no jitter tensor: the in-kernel counter-hash stream equals the oracle's, depths bit-exact."""
     g = load_golden("render_sh0.npz")
     grid = grid_from_golden(g, "softplus_soft_", "softplus_soft")
     o, d = g["rays_o"], g["rays_d"]

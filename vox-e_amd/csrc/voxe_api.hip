@@ -79,9 +79,8 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->perturb = c->perturb; dc->lindisp = c->linear_disparity; dc->aabb_clip = c->aabb_clip;
   dc->white = c->white_bkgd; dc->attn = v.attn ? 1 : 0;
   dc->term_eps = c->term_eps;
-  dc->key0 = (uint32_t)c->seed;
-  dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32);
-  dc->ctr3 = (uint32_t)c->rng_offset;
+  dc->key0 = (uint32_t)c->seed ^ ((uint32_t)c->rng_offset * 0x9E3779B1u);
+  dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32) ^ 0x7F4A7C15u;
   dc->image_width = c->image_width;
   dc->map_mode = tile_map_mode();
   dc->R = R;

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
 #include "../../include/voxe.h"
@@ -31,28 +32,51 @@ struct DevCfg {
   float near, far;
   int perturb, lindisp, aabb_clip, white, attn;
   float term_eps;
-  uint32_t key0, key1, ctr3;  // Philox key / 4th counter word
+  uint32_t key0, key1;        // jitter stream keys (see jitter_base())
   int image_width;            // 0 = linear ray order
   int map_mode;               // block -> tile mapping: 0 XCD bands, 1 linear, 2 tile rows interleaved over XCDs
   long long R;
 };
 
 // ------------------------------------------------------------------------------------------------
-// Philox4x32-10: in-kernel jitter stream (same definition as oracle/voxe_cpu.c)
+// In-kernel jitter stream: a counter-based 32-bit hash (same definition as oracle/voxe_cpu.c).
+//   key0 = seed_lo ^ (offset_lo * 0x9E3779B1), key1 = seed_hi ^ offset_hi ^ 0x7F4A7C15
+//   base(ray)  = mix32(mix32(ray_lo ^ key0) + (ray_hi ^ key1))
+//   u(ray, k)  = (mix32(base + k * 0x9E3779B9) >> 8) * 2^-24          in [0, 1)
+// mix32 is the "lowbias32" integer finaliser (2 multiplies, 3 xor-shifts): ~10 VALU per sample instead of
+// ~25 for Philox4x32-10, which matters because the render kernels are instruction-issue bound.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-  for (int round = 0; round < 10; ++round) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]);
-    const uint32_t lo0 = 0xD2511F53u * c[0];
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]);
-    const uint32_t lo1 = 0xCD9E8D57u * c[2];
-    const uint32_t n0 = hi1 ^ c[1] ^ k0;
-    const uint32_t n2 = hi0 ^ c[3] ^ k1;
-    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-    k0 += 0x9E3779B9u;
-    k1 += 0xBB67AE85u;
-  }
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t jitter_base(uint32_t key0, uint32_t key1, long long ray) {
+  const uint32_t lo = (uint32_t)ray, hi = (uint32_t)((unsigned long long)ray >> 32);
+  return mix32(mix32(lo ^ key0) + (hi ^ key1));
+}
+__host__ __device__ inline float jitter_uniform(uint32_t base, int k) {
+  return (float)(mix32(base + (uint32_t)k * 0x9E3779B9u) >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast transcendental helpers (v_exp_f32 / v_log_f32 / v_rcp_f32 are 1-ulp hardware ops).  Only used
+// for VALUES (alpha, softplus, sigmoid); the voxel-index arithmetic never goes through them.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// exp(x) = 2^(x log2 e) with the product carried in two floats (keeps ~1-2 ulp for |x| up to ~100)
+__device__ __forceinline__ float fast_exp(float x) {
+  constexpr float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
+  const float t = x * kL2eHi;
+  const float r = fmaf(x, kL2eLo, fmaf(x, kL2eHi, -t));
+  const float e0 = __builtin_amdgcn_exp2f(t);
+  return fmaf(e0, r * kLn2, e0);
+}
+// log1p(t) for t in [0, 1]
+__device__ __forceinline__ float fast_log1p01(float t) {
+  constexpr float kLn2 = 0.693147182464599609375f;
+  const float big = __builtin_amdgcn_logf(1.0f + t) * kLn2;
+  const float small = fmaf(t, -0.5f * t, t);  // t - t^2/2, exact to float for t < 2^-12
+  return t < 0.000244140625f ? small : big;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -68,22 +92,33 @@ __device__ __forceinline__ float pre_activate_grad(int act, float raw, float sca
   if (act == VOXE_ACT_ABS) s = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
   return s * scale;
 }
-// torch.nn.Softplus(beta=1, threshold=20) | ReLU | Identity
-__device__ __forceinline__ float post_activate(int act, float v) {
-  if (act == VOXE_ACT_SOFTPLUS) return v > 20.0f ? v : log1pf(expf(v));
-  if (act == VOXE_ACT_RELU) return v > 0.f ? v : 0.f;
-  return v;
-}
-__device__ __forceinline__ float post_activate_grad(int act, float v) {
+// torch.nn.Softplus(beta=1, threshold=20) | ReLU | Identity, value and derivative in one go.
+// softplus(v) = max(v, 0) + log1p(exp(-|v|)) (== v above the threshold 20 in float32, like torch);
+// softplus'(v) = sigmoid(v) (torch: z / (z + 1), z = exp(v)).
+__device__ __forceinline__ void post_activate_vg(int act, float v, float& value, float& grad) {
   if (act == VOXE_ACT_SOFTPLUS) {
-    if (v > 20.0f) return 1.0f;
-    const float z = expf(v);
-    return z / (z + 1.0f);
+    const float t = fast_exp(-fabsf(v));
+    const float rc = fast_rcp(1.0f + t);
+    value = fmaxf(v, 0.0f) + fast_log1p01(t);
+    grad = v >= 0.0f ? rc : t * rc;
+  } else if (act == VOXE_ACT_RELU) {
+    value = v > 0.f ? v : 0.f;
+    grad = v > 0.f ? 1.f : 0.f;
+  } else {
+    value = v;
+    grad = 1.0f;
   }
-  if (act == VOXE_ACT_RELU) return v > 0.f ? 1.f : 0.f;
-  return 1.0f;
 }
-__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float post_activate(int act, float v) {
+  float value, grad;
+  post_activate_vg(act, v, value, grad);
+  return value;
+}
+__device__ __forceinline__ float sigmoidf(float x) {
+  const float t = fast_exp(-fabsf(x));
+  const float rc = fast_rcp(1.0f + t);
+  return x >= 0.0f ? rc : t * rc;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Sample depths: sample_uniform_points_on_rays (sample.py:15-68) as a rolling generator.
@@ -94,10 +129,10 @@ struct DepthGen {
   float near, far, step;
   int S, half;
   bool lindisp, perturb;
-  const float* jit;  // this ray's row of the jitter tensor or nullptr
-  uint32_t k0, k1, c0, c1, c3;
-  uint32_t r0, r1, r2, r3;  // cached Philox block (scalars: a register array indexed by k&3 would spill)
-  int rnd_block;
+  const float* jit;   // this ray's row of the jitter tensor or nullptr
+  uint32_t base;      // jitter_base() of this ray
+  int kc;             // centre of the cached window (zm, z0, zp) = zlin(kc-1 .. kc+1); INT_MIN = empty
+  float zm, z0, zp;
 
   // torch.linspace(0,1,S)[k]  (sample.py:44)
   __device__ __forceinline__ float tval(int k) const {
@@ -117,28 +152,18 @@ struct DepthGen {
     const float b = far * t;
     return a + b;
   }
-  __device__ __forceinline__ float uniform(int k) {
-    if (jit) return jit[k];
-    const int blk = k >> 2;
-    if (blk != rnd_block) {
-      uint32_t c[4] = {c0, c1, (uint32_t)blk, c3};
-      philox4x32_10(c, k0, k1);
-      r0 = c[0]; r1 = c[1]; r2 = c[2]; r3 = c[3];
-      rnd_block = blk;
-    }
-    const uint32_t lo = (k & 1) ? r1 : r0, hi = (k & 1) ? r3 : r2;
-    const uint32_t x = (k & 2) ? hi : lo;
-    return (float)(x >> 8) * (1.0f / 16777216.0f);
-  }
-  // final depth of sample k (sample.py:57-64)
+  __device__ __forceinline__ float uniform(int k) const { return jit ? jit[k] : jitter_uniform(base, k); }
+  // final depth of sample k (sample.py:57-64).  Sequential calls (k, k+1, ...) cost one zlin() each.
   __device__ __forceinline__ float z(int k) {
-    const float zk = zlin(k);
-    if (!perturb) return zk;
-    const float lower = (k == 0) ? zk : 0.5f * (zk + zlin(k - 1));
-    const float upper = (k == S - 1) ? zk : 0.5f * (zlin(k + 1) + zk);
-    const float u = uniform(k);
+    if (!perturb) return zlin(k);
+    if (k == kc + 1) { zm = z0; z0 = zp; }
+    else { zm = (k > 0) ? zlin(k - 1) : 0.0f; z0 = zlin(k); }
+    zp = (k < S - 1) ? zlin(k + 1) : 0.0f;
+    kc = k;
+    const float lower = (k == 0) ? z0 : 0.5f * (z0 + zm);
+    const float upper = (k == S - 1) ? z0 : 0.5f * (zp + z0);
     const float span = upper - lower;
-    return lower + span * u;
+    return lower + span * uniform(k);
   }
 };
 
@@ -246,33 +271,43 @@ __device__ __forceinline__ void footprint(const DevGrid& g, const float (&p)[3],
   }
 }
 
-// Clamped corner addressing: corner (cx,cy,cz) -> voxel index + weight (0 for out-of-range corners,
-// which ATen skips).  Order of the 8 corners = ATen's tnw,tne,tsw,tse,bnw,bne,bsw,bse.
-struct Corners {
-  int vox[8];
-  float wgt[8];
+// Cell: the footprint with ATen's zero-padding rule folded into the weights.  Corners that fall outside
+// the grid (index -1 or N at the faces) contribute nothing in grid_sampler_3d; instead of testing each of
+// the 8 corners, the low corner is shifted into [0, N-2] per axis and the weight of the out-of-range side
+// is set to 0 (and moved to the other side), so all 8 corners i + {0,1} are always addressable:
+//   i0 == -1  : corners (-1, 0), weights (w0, w1)  ->  corners (0, 1),     weights (w1, 0)
+//   i0 == N-1 : corners (N-1, N), weights (w0, w1) ->  corners (N-2, N-1), weights (0, w0)
+// (axes of size 1 use stride 0 for the "+1" corner, whose weight is always 0.)
+struct Cell {
+  int i[3];
+  float w[3][2];
 };
 
-__device__ __forceinline__ void corners(const DevGrid& g, const Footprint& f, Corners& c) {
-  int ix[2], iy[2], iz[2];
-  float wx[2], wy[2], wz[2];
+__device__ __forceinline__ void make_cell(const DevGrid& g, const Footprint& f, Cell& c) {
+  const int N[3] = {g.X, g.Y, g.Z};
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    const int x = f.i0[0] + s, y = f.i0[1] + s, z = f.i0[2] + s;
-    const bool vx = (x >= 0) && (x < g.X), vy = (y >= 0) && (y < g.Y), vz = (z >= 0) && (z < g.Z);
-    ix[s] = min(max(x, 0), g.X - 1);
-    iy[s] = min(max(y, 0), g.Y - 1);
-    iz[s] = min(max(z, 0), g.Z - 1);
-    wx[s] = vx ? f.w[0][s] : 0.0f;
-    wy[s] = vy ? f.w[1][s] : 0.0f;
-    wz[s] = vz ? f.w[2][s] : 0.0f;
+  for (int a = 0; a < 3; ++a) {
+    const int i0 = f.i0[a];
+    const float w0 = f.w[a][0], w1 = f.w[a][1];
+    const bool lo = i0 < 0, hi = i0 >= N[a] - 1, wide = N[a] > 1;
+    const float w0_at_top = (i0 == N[a] - 1) ? w0 : 0.0f;
+    c.i[a] = lo ? 0 : (hi ? max(N[a] - 2, 0) : i0);
+    c.w[a][0] = lo ? ((i0 == -1) ? w1 : 0.0f) : (hi ? (wide ? 0.0f : w0_at_top) : w0);
+    c.w[a][1] = lo ? 0.0f : (hi ? (wide ? w0_at_top : 0.0f) : w1);
   }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int cx = k & 1, cy = (k >> 1) & 1, cz = k >> 2;
-    c.vox[k] = (ix[cx] * g.Y + iy[cy]) * g.Z + iz[cz];
-    c.wgt[k] = (wx[cx] * wy[cy]) * wz[cz];
-  }
+}
+
+// linear voxel index of the cell's low corner and the strides of the +1 corners
+struct CellAddr {
+  int base, sx, sy, sz;
+};
+__device__ __forceinline__ CellAddr cell_addr(const DevGrid& g, const Cell& c) {
+  CellAddr a;
+  a.base = (c.i[0] * g.Y + c.i[1]) * g.Z + c.i[2];
+  a.sx = g.X > 1 ? g.Y * g.Z : 0;
+  a.sy = g.Y > 1 ? g.Z : 0;
+  a.sz = g.Z > 1 ? 1 : 0;
+  return a;
 }
 
 // SH basis for a unit view direction (spherical_harmonics.py:86-116). NC = (deg+1)^2 used.

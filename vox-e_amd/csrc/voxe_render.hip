@@ -125,15 +125,15 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
       Footprint fp;
       footprint(g, p, fp);
       if (!fp.inside) continue;  // sigma = 0 -> alpha = 0 -> w = 0, T unchanged (process.py:83)
-      Corners cr;
-      corners(g, fp, cr);
+      Cell cell;
+      make_cell(g, fp, cell);
       float v, rad[COUT];
-      gather<COUT, NCM, NCU>(packed, cr, rc.basis, v, rad);
+      gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
       const float sigma = post_activate(g.post_act, v);
       // accumulate.py:49-55,63-67
       const float dl = last ? kInfinity : (z_next - z);
       const float delta = dl * rc.dnorm;
-      const float e = expf(-(sigma * delta));
+      const float e = fast_exp(-(sigma * delta));
       const float alpha = 1.0f - e;
       const float om = 1.0f - alpha;
       const float w = alpha * T;
@@ -215,14 +215,15 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     Footprint fp;
     footprint(g, p, fp);
     if (!fp.inside) continue;
-    Corners cr;
-    corners(g, fp, cr);
+    Cell cell;
+    make_cell(g, fp, cell);
     float v, rad[COUT];
-    gather<COUT, NCM, NCU>(packed, cr, rc.basis, v, rad);
-    const float sigma = post_activate(g.post_act, v);
+    gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
+    float sigma, dpost;
+    post_activate_vg(g.post_act, v, sigma, dpost);
     const float dl = last ? kInfinity : (z_next - z);
     const float delta = dl * rc.dnorm;
-    const float e = expf(-(sigma * delta));
+    const float e = fast_exp(-(sigma * delta));
     const float alpha = 1.0f - e;
     const float om = 1.0f - alpha;
     const float w = alpha * T;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     const float suffix = last ? 0.0f : (total - prefix);
     const float tail = (om > 0.0f) ? suffix / om : 0.0f;
     const float dsig = (delta * e) * (T * dldw - tail);
-    const float dv = dsig * post_activate_grad(g.post_act, v);
+    const float dv = dsig * dpost;
     float drad[COUT];
     bool any = (dv != 0.0f);
 #pragma unroll
@@ -246,11 +247,13 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     T = T * om;
 
     if (any) {  // adding exact zeros is skipped
+      const CellAddr ad = cell_addr(g, cell);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const float wg = cr.wgt[kk];
+        const float wg = (cell.w[0][kk & 1] * cell.w[1][(kk >> 1) & 1]) * cell.w[2][kk >> 2];
         if (wg != 0.0f) {
-          float* __restrict__ dst = gpacked + (long long)cr.vox[kk] * C;
+          float* __restrict__ dst =
+              gpacked + (long long)(ad.base + (kk & 1) * ad.sx + ((kk >> 1) & 1) * ad.sy + (kk >> 2) * ad.sz) * C;
           if constexpr (WANT_F) {
 #pragma unroll
             for (int ch = 0; ch < COUT; ++ch)
@@ -295,9 +298,9 @@ __global__ __launch_bounds__(256) void sample_probe_kernel(
     float sg = 0.0f;
     // the renderer only evaluates samples of [k_lo, k_hi]; the probe reports the same decision
     if (fp.inside && k >= rc.k_lo && k <= rc.k_hi) {
-      Corners cr;
-      corners(g, fp, cr);
-      gather<COUT, NCM, NCU>(packed, cr, rc.basis, v, rad);
+      Cell cell;
+      make_cell(g, fp, cell);
+      gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
       sg = post_activate(g.post_act, v);
     }
     if (sigma) sigma[i] = sg;

@@ -108,9 +108,8 @@ struct RayCtx {
     dg.step = 1.0f / (float)(c.S - 1);
     dg.perturb = c.perturb != 0;
     dg.jit = jitter ? jitter + r * c.S : nullptr;
-    dg.k0 = c.key0; dg.k1 = c.key1; dg.c3 = c.ctr3;
-    dg.c0 = (uint32_t)r; dg.c1 = (uint32_t)((unsigned long long)r >> 32);
-    dg.rnd_block = -1;
+    dg.base = jitter_base(c.key0, c.key1, r);
+    dg.kc = INT_MIN;
     inside_range(g, c, dg, o, d, k_lo, k_hi);
   }
 
@@ -123,12 +122,17 @@ struct RayCtx {
   }
 };
 
-// Interpolate density + features at the 8 corners (ATen order, zero padding) and evaluate
-// sigma = post(v), rad_c = sum_j basis_j * coef_cj   (process.py:45-78, voxels.py:307-332)
+// Interpolate density + features at the 8 corners of a Cell and evaluate
+// v = interp(pre-activated density), rad_c = sum_j basis_j * interp(coef_cj)   (process.py:45-78, voxels.py:307-332).
+// Values are interpolated with FMAs (only the index math has to round like the reference).
 template <int COUT, int NCM, int NCU>
-__device__ __forceinline__ void gather(const float* __restrict__ packed, const Corners& cr,
+__device__ __forceinline__ void gather(const DevGrid& g, const float* __restrict__ packed, const Cell& cell,
                                        const float (&basis)[NCU], float& v, float (&rad)[COUT]) {
   constexpr int C = COUT * NCM + 1;
+  const CellAddr ad = cell_addr(g, cell);
+  float wxy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wxy[k] = cell.w[0][k & 1] * cell.w[1][k >> 1];
   float f[COUT * NCU];
 #pragma unroll
   for (int i = 0; i < COUT * NCU; ++i) f[i] = 0.0f;
@@ -136,45 +140,47 @@ __device__ __forceinline__ void gather(const float* __restrict__ packed, const C
   if constexpr (C == 4) {
     float4 t[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = reinterpret_cast<const float4*>(packed)[cr.vox[k]];
+    for (int k = 0; k < 8; ++k)
+      t[k] = reinterpret_cast<const float4*>(packed)[ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float w = cr.wgt[k];
-      f[0] = f[0] + t[k].x * w;
-      f[1] = f[1] + t[k].y * w;
-      f[2] = f[2] + t[k].z * w;
-      v = v + t[k].w * w;
+      const float w = wxy[k & 3] * cell.w[2][k >> 2];
+      f[0] = fmaf(t[k].x, w, f[0]);
+      f[1] = fmaf(t[k].y, w, f[1]);
+      f[2] = fmaf(t[k].z, w, f[2]);
+      v = fmaf(t[k].w, w, v);
     }
   } else if constexpr (C == 2) {
     float2 t[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = reinterpret_cast<const float2*>(packed)[cr.vox[k]];
+    for (int k = 0; k < 8; ++k)
+      t[k] = reinterpret_cast<const float2*>(packed)[ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float w = cr.wgt[k];
-      f[0] = f[0] + t[k].x * w;
-      v = v + t[k].y * w;
+      const float w = wxy[k & 3] * cell.w[2][k >> 2];
+      f[0] = fmaf(t[k].x, w, f[0]);
+      v = fmaf(t[k].y, w, v);
     }
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float w = cr.wgt[k];
-      const float* __restrict__ src = packed + (long long)cr.vox[k] * C;
+      const float w = wxy[k & 3] * cell.w[2][k >> 2];
+      const float* __restrict__ src =
+          packed + (long long)(ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz) * C;
 #pragma unroll
       for (int ch = 0; ch < COUT; ++ch)
 #pragma unroll
-        for (int j = 0; j < NCU; ++j) f[ch * NCU + j] = f[ch * NCU + j] + src[ch * NCM + j] * w;
-      v = v + src[C - 1] * w;
+        for (int j = 0; j < NCU; ++j) f[ch * NCU + j] = fmaf(src[ch * NCM + j], w, f[ch * NCU + j]);
+      v = fmaf(src[C - 1], w, v);
     }
   }
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) {
     float r = basis[0] * f[ch * NCU];
 #pragma unroll
-    for (int j = 1; j < NCU; ++j) r = r + basis[j] * f[ch * NCU + j];
+    for (int j = 1; j < NCU; ++j) r = fmaf(basis[j], f[ch * NCU + j], r);
     rad[ch] = r;
   }
 }
-
 
 }  // namespace voxe

@@ -33,6 +33,9 @@ constexpr int kRing = 8;                 // live layers along the march axis
 constexpr int kLat = 8;                  // lateral window edge (voxels)
 constexpr int kLayerSlots = kLat * kLat; // 64
 constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
+// channel planes are padded by 8 doubles (16 banks) so the C channels of one voxel, read together by the
+// flush, sit in different bank groups; the plane offset folds into the ds instruction's immediate
+constexpr int kPlane = kWinSlots + 8;
 
 // wave-wide integer min / max, result wave-uniform (DPP inside rows of 16, readlane across rows).
 // Must be called with all 64 lanes active.
@@ -65,10 +68,6 @@ struct Window {
   // of neighbouring layers lands in different LDS banks
   __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + 21 * (key & 7)) & 63; }
 };
-// the channel planes are 512 doubles (a multiple of all 64 banks) apart: rotate the in-layer position
-// by 8 slots per channel so the 4 channels of one voxel (read together by the flush) use 4 bank groups
-__device__ __forceinline__ int chan_pos(int pos, int ch) { return (pos + 8 * ch) & 63; }
-
 template <int C>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
                                             const Window& w, int key, int lane) {
@@ -80,7 +79,7 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
   for (int j = 0; j < kLayerSlots / kPerInstr; ++j) {
     const int ab = j * kPerInstr + lane / C;  // lateral cell: a = ab >> 3, b = ab & 7 (b is the z-run)
     const int ch = lane % C;
-    const int idx = ch * kWinSlots + lbase + chan_pos(w.layer_pos(key, ab), ch);
+    const int idx = ch * kPlane + lbase + w.layer_pos(key, ab);
     const double val = win[idx];
     if (val != 0.0) {
       win[idx] = 0.0;
@@ -100,10 +99,9 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
     const float* __restrict__ ray_state, float* __restrict__ gpacked) {
   constexpr int C = COUT + 1;
-  __shared__ double win[C * kWinSlots];
+  __shared__ double win[C * kPlane];
   const int lane = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < C * kWinSlots / 64; ++i) win[i * 64 + lane] = 0.0;
+  for (int i = lane; i < C * kPlane; i += 64) win[i] = 0.0;
 
   // ---- tile -> ray (XCD-banded like map_ray) ----------------------------------------------------
   const int W = c.image_width, H = (int)(c.R / W);
@@ -167,8 +165,10 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
     w.Bu = DUu * inv; w.Au = U0u - w.Bu * U0m;
     w.Bv = DUv * inv; w.Av = U0v - w.Bv * U0m;
-    const int stride[3] = {g.Y * g.Z, g.Z, 1};
-    w.stride_m = stride[w.m]; w.stride_u = stride[w.u]; w.stride_v = stride[w.v];
+    const int sx = g.Y * g.Z, sy = g.Z;
+    w.stride_m = (w.m == 0) ? sx : ((w.m == 1) ? sy : 1);
+    w.stride_u = (w.u == 0) ? sx : sy;
+    w.stride_v = (w.v == 1) ? sy : 1;
   }
   // lowest layer key a sample with low-corner index pm can write (layers pm and pm + 1)
   auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
@@ -228,25 +228,26 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
         z_cur = z_next;
       }
       if (fp.inside) {
-        Corners cr;
-        corners(g, fp, cr);
+        Cell cell;
+        make_cell(g, fp, cell);
         float v, rad[COUT];
-        gather<COUT, 1, 1>(packed, cr, rc.basis, v, rad);
-        const float sigma = post_activate(g.post_act, v);
+        gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
+        float sigma, dpost;
+        post_activate_vg(g.post_act, v, sigma, dpost);
         const float dl = last ? kInfinity : (z_next - z);
         const float delta = dl * rc.dnorm;
-        const float e = expf(-(sigma * delta));
+        const float e = fast_exp(-(sigma * delta));
         const float alpha = 1.0f - e;
         const float om = 1.0f - alpha;
         const float wk = alpha * T;
-        float col[COUT], dldw = gdep * z + gacc;
+        float col[COUT], dldw = fmaf(gdep, z, gacc);
 #pragma unroll
-        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw += gc[ch] * col[ch]; }
+        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
         if (white) dldw -= gsum;
-        prefix += dldw * wk;
+        prefix = fmaf(dldw, wk, prefix);
         const float suffix = last ? 0.0f : (total - prefix);
-        const float tail = (om > 0.0f) ? suffix / om : 0.0f;
-        const float dsig = (delta * e) * (T * dldw - tail);
+        const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+        const float dsig = (delta * e) * fmaf(T, dldw, -tail);
         // per-channel gradient of the packed texel: (d rad_c * C0 ..., d v)
         float gch[C];
         bool any = false;
@@ -255,53 +256,71 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
           gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
           any = any || (gch[ch] != 0.0f);
         }
-        gch[COUT] = WANT_D ? dsig * post_activate_grad(g.post_act, v) : 0.0f;
+        gch[COUT] = WANT_D ? dsig * dpost : 0.0f;
         any = any || (gch[COUT] != 0.0f);
         T = T * om;
 
         if (any) {
-          // permute the footprint into (march, lateral u, lateral v) order; zero the weights of
-          // out-of-range corners (ATen skips them)
-          const int N[3] = {g.X, g.Y, g.Z};
-          const int pm = pick(fp.i0, w.m), pu = pick(fp.i0, w.u), pv = pick(fp.i0, w.v);
-          const int Nm = pick(N, w.m), Nu = pick(N, w.u), Nv = pick(N, w.v);
+          // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
+          const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
           float wm[2], wu[2], wv[2];
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
-            const float am = (w.m == 0) ? fp.w[0][s] : ((w.m == 1) ? fp.w[1][s] : fp.w[2][s]);
-            const float au = (w.u == 0) ? fp.w[0][s] : fp.w[1][s];
-            const float av = (w.v == 1) ? fp.w[1][s] : fp.w[2][s];
-            wm[s] = (pm + s >= 0 && pm + s < Nm) ? am : 0.0f;
-            wu[s] = (pu + s >= 0 && pu + s < Nu) ? au : 0.0f;
-            wv[s] = (pv + s >= 0 && pv + s < Nv) ? av : 0.0f;
+            wm[s] = (w.m == 0) ? cell.w[0][s] : ((w.m == 1) ? cell.w[1][s] : cell.w[2][s]);
+            wu[s] = (w.u == 0) ? cell.w[0][s] : cell.w[1][s];
+            wv[s] = (w.v == 1) ? cell.w[1][s] : cell.w[2][s];
           }
-          int offu[2], offv[2];
+          // per layer (cm = 0, 1): ring slot, lateral position of corner (cu, cv) = (0, 0), window test
+          int lofs[2], ab0[2];
+          bool fits = true;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) { offu[s] = w.off_u(pm + s); offv[s] = w.off_v(pm + s); }
+          for (int s = 0; s < 2; ++s) {
+            const int im = pm + s, key = w.sgn * im;
+            const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
+            fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
+                   ((unsigned)b0 < (unsigned)(kLat - 1));
+            lofs[s] = (key & 7) * kLayerSlots;
+            ab0[s] = a0 * kLat + b0 + 21 * (key & 7);  // + the per-layer rotation of layer_pos()
+          }
+          if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
 #pragma unroll
-          for (int cc = 0; cc < 8; ++cc) {
-            const int cidx = (cc + rot) & 7;
-            const int cm = cidx & 1, cu = (cidx >> 1) & 1, cv = cidx >> 2;
-            const float wgt = ((cm ? wm[1] : wm[0]) * (cu ? wu[1] : wu[0])) * (cv ? wv[1] : wv[0]);
-            if (wgt != 0.0f) {
-              const int im = pm + cm, iu = pu + cu, iv = pv + cv;
-              const int key = w.sgn * im;
-              const int a = iu - (cm ? offu[1] : offu[0]), b = iv - (cm ? offv[1] : offv[0]);
-              const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
-                                 ((unsigned)b < (unsigned)kLat);
-              if (inwin) {
-                const int lbase = (key & 7) * kLayerSlots, pos = w.layer_pos(key, a * kLat + b);
+            for (int cc = 0; cc < 8; ++cc) {
+              const int cidx = (cc + rot) & 7;
+              const bool cm = cidx & 1, cu = cidx & 2, cv = cidx & 4;
+              const float wgt = ((cm ? wm[1] : wm[0]) * (cu ? wu[1] : wu[0])) * (cv ? wv[1] : wv[0]);
+              const int idx = (cm ? lofs[1] : lofs[0]) + (((cm ? ab0[1] : ab0[0]) + (cu ? kLat : 0) + (cv ? 1 : 0)) & 63);
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) {
-                  if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
-                    __hip_atomic_fetch_add(&win[ch * kWinSlots + lbase + chan_pos(pos, ch)], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-              } else {  // outside the LDS window: plain global scatter (rare)
-                const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+              for (int ch = 0; ch < C; ++ch) {
+                if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                  __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          } else {  // some corner outside the window: per-corner test, global scatter for the outsiders (rare)
 #pragma unroll
-                for (int ch = 0; ch < C; ++ch) {
-                  if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)) atomicAdd(gpacked + vox * C + ch, gch[ch] * wgt);
+            for (int cc = 0; cc < 8; ++cc) {
+              const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
+              const float wgt = (wm[cm] * wu[cu]) * wv[cv];
+              if (wgt != 0.0f) {
+                const int im = pm + cm, iu = pu + cu, iv = pv + cv;
+                const int key = w.sgn * im;
+                const int a = iu - w.off_u(im), b = iv - w.off_v(im);
+                const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
+                                   ((unsigned)b < (unsigned)kLat);
+                if (inwin) {
+                  const int idx = (key & 7) * kLayerSlots + w.layer_pos(key, a * kLat + b);
+#pragma unroll
+                  for (int ch = 0; ch < C; ++ch) {
+                    if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                      __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                  }
+                } else {
+                  const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+#pragma unroll
+                  for (int ch = 0; ch < C; ++ch) {
+                    if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)) atomicAdd(gpacked + vox * C + ch, gch[ch] * wgt);
+                  }
                 }
               }
             }

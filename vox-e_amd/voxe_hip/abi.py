@@ -111,7 +111,7 @@ HIP_ONLY = {
 
 CPU_ONLY = {
     "num_threads": (C.c_int, []),
-    "philox_uniform": (C.c_float, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32]),
+    "jitter_uniform": (C.c_float, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32]),
 }
 
 

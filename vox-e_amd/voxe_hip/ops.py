@@ -92,7 +92,7 @@ def _validate_inputs(densities, features, rays_o, rays_d, jitter, params: Render
 
 
 def _next_rng():
-    """(seed, offset) of the in-kernel Philox jitter stream, tied to torch's CPU generator so that
+    """(seed, offset) of the in-kernel counter-hash jitter stream, tied to torch's CPU generator so that
     torch.manual_seed() makes renders reproducible (no device sync involved)."""
     seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
     offset = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
