@@ -64,10 +64,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("VOXE_BENCH_FORCE_DIST") == "1":  # FORCE: exercise the RCCL path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     G, HW, S = args.grid, args.image, args.samples
@@ -211,9 +212,15 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so the JSON is the LAST line
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
