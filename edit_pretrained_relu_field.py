@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Text-guided edit of a pre-trained ReLU/softplus field with score distillation (entry point kept from the
+reference's edit_pretrained_relu_field.py:234-319; option names of the global-edit stage).  The render
+forward/backward, the density-correlation regulariser and Adam run in the HIP library; Stable Diffusion
+(diffusers) runs under PyTorch-ROCm.  The local-edit refinement stage (cross-attention grids + graph cut,
+:321-427) is outside this build's scope."""
+import copy
+import os
+import sys
+from pathlib import Path
+
+import click
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "vox-e_amd"))
+
+from thre3d_atom.modules.sds_trainer import train_sh_vox_grid_vol_mod_with_posed_images_and_sds  # noqa: E402
+from thre3d_atom.modules.volumetric_model import create_volumetric_model_from_saved_model  # noqa: E402
+from thre3d_atom.thre3d_reprs.voxels import create_voxel_grid_from_saved_info_dict  # noqa: E402
+from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS  # noqa: E402
+from thre3d_atom.utils.imaging_utils import scale_camera_intrinsics  # noqa: E402
+from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
+
+
+@click.command()
+@click.option("-i", "--ref_model_path", type=click.Path(file_okay=True, dir_okay=False), required=True, help="path to the pre-trained relu field model")
+@click.option("-o", "--output_path", type=click.Path(file_okay=False, dir_okay=True), required=True, help="path for training output")
+@click.option("-p", "--prompt", type=click.STRING, required=True, help="prompt used for the SDS based loss")
+@click.option("-d", "--data_path", type=click.Path(file_okay=False, dir_okay=True), required=False, default=None,
+              help="input dataset (only needed for --data_pose_mode / --uncoupled_mode; cameras otherwise come from the checkpoint)")
+@click.option("--data_downsample_factor", type=click.FloatRange(min=1.0), default=3.0, show_default=True)
+@click.option("--white_bkgd", type=click.BOOL, default=True, show_default=True)
+@click.option("--train_num_samples_per_ray", type=click.INT, default=256, show_default=True)
+@click.option("--render_num_samples_per_ray", type=click.INT, default=512, show_default=True)
+@click.option("--num_iterations_edit", type=click.INT, default=8000, show_default=True)
+@click.option("--learning_rate", type=click.FLOAT, default=0.03, show_default=True)
+@click.option("--lr_freq", type=click.INT, default=400, show_default=True)
+@click.option("--lr_decay_start", type=click.INT, default=5000, show_default=True)
+@click.option("--lr_gamma", type=click.FLOAT, default=0.96, show_default=True)
+@click.option("--save_frequency", type=click.INT, default=500, show_default=True)
+@click.option("--feedback_frequency", type=click.INT, default=200, show_default=True)
+@click.option("--summary_frequency", type=click.INT, default=50, show_default=True)
+@click.option("--do_sds", type=click.BOOL, default=True, show_default=True)
+@click.option("--new_frame_frequency", type=click.INT, default=1, show_default=True)
+@click.option("--density_correlation_weight", type=click.FLOAT, default=200.0, show_default=True)
+@click.option("--feature_correlation_weight", type=click.FLOAT, default=0.0, show_default=True)
+@click.option("--tv_density_weight", type=click.FLOAT, default=0.0, show_default=True)
+@click.option("--tv_features_weight", type=click.FLOAT, default=0.0, show_default=True)
+@click.option("--sds_t_freq", type=click.INT, default=600, show_default=True)
+@click.option("--sds_t_start", type=click.INT, default=4000, show_default=True)
+@click.option("--sds_t_gamma", type=click.FLOAT, default=0.75, show_default=True)
+@click.option("--uncoupled_mode", type=click.BOOL, default=False, show_default=True)
+@click.option("--data_pose_mode", type=click.BOOL, default=False, show_default=True)
+@click.option("--do_refinement", type=click.BOOL, default=False, show_default=True)
+def main(**kwargs) -> None:
+    cfg = type("Config", (), kwargs)
+    if cfg.do_refinement:
+        raise click.UsageError("the local-edit refinement stage is not part of this build (see module docstring)")
+    device = torch.device("cuda")
+    output_path = Path(cfg.output_path)
+    log_config_to_disk(kwargs, output_path)
+    ref_vol_mod, extra = create_volumetric_model_from_saved_model(Path(cfg.ref_model_path), create_voxel_grid_from_saved_info_dict, device=device)
+    ref_vol_mod.render_config.num_samples_per_ray = cfg.train_num_samples_per_ray
+    ref_vol_mod.render_config.render_num_samples_per_ray = cfg.render_num_samples_per_ray
+    ref_vol_mod.render_config.white_bkgd = cfg.white_bkgd
+    sds_vol_mod = copy.deepcopy(ref_vol_mod)
+    dataset = None
+    if cfg.data_path is not None and (cfg.uncoupled_mode or cfg.data_pose_mode):
+        from thre3d_atom.data.datasets import PosedImagesDataset
+
+        dataset = PosedImagesDataset(Path(cfg.data_path) / "train", Path(cfg.data_path) / "train_camera_params.json",
+                                     downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
+    # the reference trains at the dataset's (down-sampled) resolution; the checkpoint stores those intrinsics
+    intrinsics = scale_camera_intrinsics(extra[CAMERA_INTRINSICS], 1.0)
+    train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
+        sds_vol_mod=sds_vol_mod, pretrained_vol_mod=ref_vol_mod, train_dataset=dataset, image_dims=None,
+        output_dir=output_path, num_iterations=cfg.num_iterations_edit, learning_rate=cfg.learning_rate,
+        lr_decay_start=cfg.lr_decay_start, lr_freq=cfg.lr_freq, lr_gamma=cfg.lr_gamma, save_freq=cfg.save_frequency,
+        feedback_freq=cfg.feedback_frequency, summary_freq=cfg.summary_frequency, sds_prompt=cfg.prompt,
+        new_frame_frequency=cfg.new_frame_frequency, density_correlation_weight=cfg.density_correlation_weight,
+        feature_correlation_weight=cfg.feature_correlation_weight, tv_density_weight=cfg.tv_density_weight,
+        tv_features_weight=cfg.tv_features_weight, do_sds=cfg.do_sds, sds_t_freq=cfg.sds_t_freq,
+        sds_t_start=cfg.sds_t_start, sds_t_gamma=cfg.sds_t_gamma, uncoupled_mode=cfg.uncoupled_mode,
+        data_pose_mode=cfg.data_pose_mode, camera_intrinsics=intrinsics, camera_bounds=extra[CAMERA_BOUNDS],
+        hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
+    )
+
+
+if __name__ == "__main__":
+    main()

@@ -170,3 +170,38 @@ def test_reference_checkpoint_loads_and_product_refuses_cpu():
         rays = Rays(torch.zeros(4, 3), torch.ones(4, 3))
         with pytest.raises(VoxeError):
             vm.render_rays(rays)
+
+
+def test_datasets_on_disk_format_and_downsampling(tmp_path):
+    """`*_camera_params.json` + image folder (reference data/datasets.py, data/constants.py) round trip."""
+    import json
+
+    from PIL import Image
+
+    from thre3d_atom.data.datasets import InMemoryPosedImages, PosedImagesDataset
+    from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics, pose_spherical
+
+    img_dir = tmp_path / "train"
+    img_dir.mkdir()
+    params = {}
+    rng = np.random.default_rng(0)
+    for i in range(3):
+        pose = pose_spherical(40.0 * i, 30.0, 4.0311)
+        rgba = (rng.random((12, 16, 4)) * 255).astype(np.uint8)
+        Image.fromarray(rgba, "RGBA").save(img_dir / f"r_{i}.png")
+        params[f"r_{i}.png"] = {
+            "extrinsic": {"rotation": pose.rotation.numpy().tolist(), "translation": pose.translation.numpy().tolist()},
+            "intrinsic": {"height": 12, "width": 16, "focal": 20.0, "bounds": [2.0, 6.0]},
+        }
+    (tmp_path / "train_camera_params.json").write_text(json.dumps(params))
+    ds = PosedImagesDataset(img_dir, tmp_path / "train_camera_params.json", rgba_white_bkgd=True)
+    assert len(ds) == 3 and ds.images.shape == (3, 3, 12, 16) and ds.poses.shape == (3, 3, 4)
+    assert ds.camera_intrinsics == CameraIntrinsics(12, 16, 20.0)
+    assert ds.camera_bounds == CameraBounds(2.0 * 0.9, 6.0 * 1.1)           # datasets.py:275-276
+    assert abs(ds.get_hemispherical_radius_estimate() - 4.0311) < 1e-3       # test_datasets.py:48-52
+    assert 0.0 <= float(ds.images.min()) and float(ds.images.max()) <= 1.0
+    img, pose, idx = ds[1]
+    assert img.shape == (3, 12, 16) and idx == 1 and abs(float(torch.det(pose[:, :3])) - 1.0) < 1e-4
+    half = ds.downsampled(2.0)
+    assert half.images.shape == (3, 3, 6, 8) and half.camera_intrinsics == CameraIntrinsics(6, 8, 10.0)
+    assert isinstance(half, InMemoryPosedImages)

@@ -1,0 +1,136 @@
+"""GPU tests of the callers either side of the hot path: fused Adam, the SDS editing loop (with a stand-in
+guidance object -- Stable Diffusion weights are not available offline), the coarse-to-fine reconstruction
+trainer and the render entry point."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from thre3d_atom.data.datasets import InMemoryPosedImages
+    from thre3d_atom.modules.optim import VoxeAdam
+    from thre3d_atom.modules.sds_trainer import train_sh_vox_grid_vol_mod_with_posed_images_and_sds
+    from thre3d_atom.modules.trainers import train_sh_vox_grid_vol_mod_with_posed_images
+    from thre3d_atom.modules.volumetric_model import VolumetricModel, create_volumetric_model_from_saved_model
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelSize, create_voxel_grid_from_saved_info_dict
+    from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics, pose_spherical
+
+    DEV = torch.device("cuda:0")
+
+
+def _sphere_model(side=24, samples=64):
+    ax = (torch.arange(side, dtype=torch.float32) + 0.5) / side * 3.0 - 1.5
+    x, y, z = torch.meshgrid(ax, ax, ax, indexing="ij")
+    r = torch.sqrt(x * x + y * y + z * z)
+    dens = torch.where(r < 0.9, torch.tensor(1.0), torch.tensor(-1.0))[..., None].contiguous()
+    feat = torch.stack([2.0 * torch.sin(2 * x), 2.0 * torch.cos(3 * y), 2.0 * torch.sin(2.5 * z + 1)], dim=-1).contiguous()
+    vg = VoxelGrid(dens, feat, VoxelSize(3.0 / side, 3.0 / side, 3.0 / side), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=100.0 / 3.0, tunable=True)
+    cfg = SHVoxGridRenderConfig(samples, CameraBounds(1.8, 6.6), white_bkgd=True, render_num_samples_per_ray=96)
+    return VolumetricModel(vg, render_sh_voxel_grid, cfg, device=DEV)
+
+
+def test_voxe_adam_matches_torch_adam():
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(5, 6, 7, 3, generator=g)
+    a = torch.nn.Parameter(p0.clone().to(DEV))
+    b = torch.nn.Parameter(p0.clone().to(DEV))
+    oa, ob = VoxeAdam([a], lr=0.03), torch.optim.Adam([b], lr=0.03)
+    sched = torch.optim.lr_scheduler.ExponentialLR(oa, gamma=0.5)
+    sched_b = torch.optim.lr_scheduler.ExponentialLR(ob, gamma=0.5)
+    for step in range(6):
+        grad = (torch.randn(p0.shape, generator=g) * 10.0 ** (step - 3)).to(DEV)
+        a.grad, b.grad = grad.clone(), grad.clone()
+        oa.step(), ob.step()
+        if step == 2:
+            sched.step(), sched_b.step()
+        torch.testing.assert_close(a.data, b.data, rtol=2e-6, atol=1e-7)
+    assert oa.state[a]["step"] == 6
+
+
+class _TintGuidance:
+    """stand-in for the SD guidance: pulls the rendered image towards a flat colour (differentiable)"""
+
+    def __init__(self, colour):
+        self.colour = torch.tensor(colour, device=DEV)
+        self.losses = []
+
+    def training_step(self, output, image_height, image_width, directions=None, global_step=-1, logvars=None):
+        assert output.shape == (image_height * image_width, 3) and directions[0] in ("front", "side", "back", "overhead")
+        loss = ((output - self.colour) ** 2).mean()
+        self.losses.append(float(loss.detach()))
+        return loss
+
+    def get_current_max_step_ratio(self):
+        return 0.98
+
+
+def test_sds_loop_with_stub_guidance(tmp_path):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ref = _sphere_model()
+    sds = copy.deepcopy(ref)
+    guidance = _TintGuidance([1.0, 0.1, 0.1])
+    dens_before = sds.thre3d_repr.densities.detach().clone()
+    out = train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
+        sds, ref, None, None, tmp_path, num_iterations=40, learning_rate=0.05, save_freq=20, feedback_freq=20,
+        summary_freq=20, density_correlation_weight=5.0, guidance=guidance,
+        camera_intrinsics=CameraIntrinsics(40, 40, 55.0), camera_bounds=CameraBounds(1.8, 6.6))
+    assert out is sds
+    # (most pixels are white background that no feature change can tint, so the drop is bounded)
+    assert np.mean(guidance.losses[-5:]) < 0.95 * np.mean(guidance.losses[:5])  # the edit moves the render
+    assert not torch.equal(sds.thre3d_repr.densities, dens_before)
+    assert torch.equal(ref.thre3d_repr.densities.detach(), dens_before)       # the reference model is untouched
+    for name in ("model_iter_1.pth", "model_iter_20.pth", "model_iter_40.pth", "model_final.pth"):
+        assert (tmp_path / "saved_models" / name).exists()
+    assert (tmp_path / "training_logs" / "rendered_output" / "sds_40.png").exists()
+    vm, extra = create_volumetric_model_from_saved_model(tmp_path / "saved_models" / "model_final.pth",
+                                                         create_voxel_grid_from_saved_info_dict, device=DEV)
+    assert torch.equal(vm.thre3d_repr.features, sds.thre3d_repr.features) and extra["hemispherical_radius"] == 4.0311
+
+
+def test_reconstruction_trainer_fits_synthetic_views(tmp_path):
+    torch.manual_seed(1)
+    truth = _sphere_model(side=24, samples=96)
+    intr = CameraIntrinsics(48, 48, 0.5 * 48 / np.tan(0.5 * 0.6911112))
+    poses, images = [], []
+    for i in range(16):
+        pose = pose_spherical(360.0 * i / 16, 20.0 + 50.0 * ((i * 0.618) % 1.0), 4.0311)
+        poses.append(torch.cat([pose.rotation, pose.translation], dim=1))
+        images.append(truth.render(pose, intr, perturb_sampled_points=False).colour.permute(2, 0, 1).cpu())
+    data = InMemoryPosedImages(torch.stack(images), torch.stack(poses), intr, CameraBounds(1.8, 6.6))
+    g = torch.Generator().manual_seed(3)
+    vg = VoxelGrid(torch.empty(24, 24, 24, 1).uniform_(-1, 1, generator=g), torch.empty(24, 24, 24, 3).uniform_(-1, 1, generator=g),
+                   VoxelSize(0.125, 0.125, 0.125), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=100.0 / 3.0, tunable=True)
+    vm = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(96, CameraBounds(1.8, 6.6), white_bkgd=True), device=DEV)
+    train_sh_vox_grid_vol_mod_with_posed_images(vm, data, tmp_path, ray_batch_size=4096, num_stages=2,
+                                                num_iterations_per_stage=150, summary_freq=150, save_freq=10 ** 6)
+    assert vm.thre3d_repr.grid_dims == (24, 24, 24) and (tmp_path / "saved_models" / "model_final.pth").exists()
+    psnrs = []
+    for i in (0, 5, 11):
+        pose = pose_spherical(360.0 * i / 16, 20.0 + 50.0 * ((i * 0.618) % 1.0), 4.0311)
+        img = vm.render(pose, intr, perturb_sampled_points=False).colour.permute(2, 0, 1).cpu()
+        psnrs.append(-10 * np.log10(float(((img - data.images[i]) ** 2).mean())))
+    assert min(psnrs) > 20.0, psnrs  # a random grid renders at ~8 dB
+
+
+def test_render_entry_point(tmp_path):
+    import importlib.util
+
+    from click.testing import CliRunner
+
+    spec = importlib.util.spec_from_file_location("render_cli", os.path.join(ROOT, "render_sh_based_voxel_grid.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = CliRunner().invoke(mod.main, ["-i", os.path.join(GOLDEN, "ref_checkpoint.pth"), "-o", str(tmp_path), "--num_frames", "4",
+                                        "--render_scale_factor", "1.0", "--overridden_num_samples_per_ray", "64"])
+    assert res.exit_code == 0, res.output
+    assert len(list(tmp_path.glob("frame_*.png"))) == 3  # num_frames - 1 poses, like the reference's thre360 path

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Reconstruct an SH voxel grid (ReLU / softplus field) from posed images (entry point kept from the
+reference's train_sh_based_voxel_grid_with_posed_images.py:142-267; same option names for the options kept)."""
+import os
+import sys
+from pathlib import Path
+
+import click
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "vox-e_amd"))
+
+from thre3d_atom.data.datasets import PosedImagesDataset  # noqa: E402
+from thre3d_atom.modules.trainers import train_sh_vox_grid_vol_mod_with_posed_images  # noqa: E402
+from thre3d_atom.modules.volumetric_model import VolumetricModel  # noqa: E402
+from thre3d_atom.rendering.volumetric.utils.misc import compute_expected_density_scale_for_relu_field_grid  # noqa: E402
+from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid  # noqa: E402
+from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelGridLocation, VoxelSize  # noqa: E402
+from thre3d_atom.utils.constants import NUM_COLOUR_CHANNELS  # noqa: E402
+from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
+
+
+def density_activations(use_relu_field: bool, use_softplus_field: bool, grid_world_size):
+    """Activation table of the reference CLI (:177-200).  NB: there the `else` of the softplus test also
+    overrides the ReLU branch, so (relu=True, softplus=False) yields the abs/Identity field; reproduced."""
+    scale = compute_expected_density_scale_for_relu_field_grid(grid_world_size)
+    if use_softplus_field:
+        return dict(density_preactivation=torch.nn.Identity(), density_postactivation=torch.nn.Softplus(), expected_density_scale=scale)
+    return dict(density_preactivation=torch.abs, density_postactivation=torch.nn.Identity(), expected_density_scale=1.0)
+
+
+@click.command()
+@click.option("-d", "--data_path", type=click.Path(file_okay=False, dir_okay=True), required=True)
+@click.option("-o", "--output_path", type=click.Path(file_okay=False, dir_okay=True), required=True)
+@click.option("--data_downsample_factor", type=click.FloatRange(min=1.0), default=2.0, show_default=True)
+@click.option("--grid_dims", type=click.INT, nargs=3, default=(160, 160, 160), show_default=True)
+@click.option("--grid_location", type=click.FLOAT, nargs=3, default=(0.0, 0.0, 0.0), show_default=True)
+@click.option("--grid_world_size", type=click.FLOAT, nargs=3, default=(3.0, 3.0, 3.0), show_default=True)
+@click.option("--sh_degree", type=click.INT, default=0, show_default=True)
+@click.option("--use_relu_field", type=click.BOOL, default=True, show_default=True)
+@click.option("--use_softplus_field", type=click.BOOL, default=True, show_default=True)
+@click.option("--white_bkgd", type=click.BOOL, default=True, show_default=True)
+@click.option("--ray_batch_size", type=click.INT, default=32768, show_default=True)
+@click.option("--train_num_samples_per_ray", type=click.INT, default=256, show_default=True)
+@click.option("--render_num_samples_per_ray", type=click.INT, default=1024, show_default=True)
+@click.option("--num_stages", type=click.INT, default=4, show_default=True)
+@click.option("--num_iterations_per_stage", type=click.INT, default=2000, show_default=True)
+@click.option("--scale_factor", type=click.FLOAT, default=2.0, show_default=True)
+@click.option("--learning_rate", type=click.FLOAT, default=0.03, show_default=True)
+@click.option("--lr_decay_steps_per_stage", type=click.INT, default=1000, show_default=True)
+@click.option("--lr_decay_gamma_per_stage", type=click.FLOAT, default=0.1, show_default=True)
+@click.option("--stagewise_lr_decay_gamma", type=click.FLOAT, default=0.9, show_default=True)
+@click.option("--apply_diffuse_render_regularization", type=click.BOOL, default=True)
+@click.option("--optimized_sampling", type=click.BOOL, default=False, show_default=True)
+@click.option("--linear_disparity_sampling", type=click.BOOL, default=False, show_default=True)
+@click.option("--fast_debug_mode", type=click.BOOL, default=False, show_default=True)
+def main(**kwargs) -> None:
+    cfg = type("Config", (), kwargs)
+    device = torch.device("cuda")
+    data_path, output_path = Path(cfg.data_path), Path(cfg.output_path)
+    log_config_to_disk(kwargs, output_path)
+    train_dir = data_path / "train" if (data_path / "train").is_dir() else data_path / "images"
+    params = data_path / ("train_camera_params.json" if (data_path / "train_camera_params.json").exists() else "camera_params.json")
+    dataset = PosedImagesDataset(train_dir, params, downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
+    densities = torch.empty((*cfg.grid_dims, 1), dtype=torch.float32, device=device).uniform_(-1.0, 1.0)
+    num_sh = NUM_COLOUR_CHANNELS * ((cfg.sh_degree + 1) ** 2)
+    features = torch.empty((*cfg.grid_dims, num_sh), dtype=torch.float32, device=device).uniform_(-1.0, 1.0)
+    voxel_size = VoxelSize(*[w / n for w, n in zip(cfg.grid_world_size, cfg.grid_dims)])
+    grid = VoxelGrid(densities, features, voxel_size, VoxelGridLocation(*cfg.grid_location), tunable=True,
+                     **density_activations(cfg.use_relu_field, cfg.use_softplus_field, cfg.grid_world_size))
+    vol_mod = VolumetricModel(grid, render_sh_voxel_grid, SHVoxGridRenderConfig(
+        num_samples_per_ray=cfg.train_num_samples_per_ray, camera_bounds=dataset.camera_bounds, white_bkgd=cfg.white_bkgd,
+        render_num_samples_per_ray=cfg.render_num_samples_per_ray, optimized_sampling=cfg.optimized_sampling,
+        linear_disparity_sampling=cfg.linear_disparity_sampling), device=device)
+    train_sh_vox_grid_vol_mod_with_posed_images(
+        vol_mod, dataset, output_path, ray_batch_size=cfg.ray_batch_size, num_stages=cfg.num_stages,
+        num_iterations_per_stage=cfg.num_iterations_per_stage, scale_factor=cfg.scale_factor,
+        learning_rate=cfg.learning_rate, lr_decay_gamma_per_stage=cfg.lr_decay_gamma_per_stage,
+        lr_decay_steps_per_stage=cfg.lr_decay_steps_per_stage, stagewise_lr_decay_gamma=cfg.stagewise_lr_decay_gamma,
+        apply_diffuse_render_regularization=cfg.apply_diffuse_render_regularization, fast_debug_mode=cfg.fast_debug_mode)
+
+
+if __name__ == "__main__":
+    main()

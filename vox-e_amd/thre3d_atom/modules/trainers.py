@@ -1,0 +1,121 @@
+"""Coarse-to-fine reconstruction of an SH voxel grid from posed images.
+
+Entry point of the reference's thre3d_atom/modules/trainers.py (`train_sh_vox_grid_vol_mod_with_posed_images`
+:55-506): `num_stages` stages, the grid doubling each stage (trilinear upsampling, HIP kernel), images
+down-sampled by the matching factor, per iteration a random batch of rays over `image_batch_cache_size`
+images, L1 loss on the specular render plus (optionally) on the diffuse render, Adam with a per-stage decay.
+Rendering and its backward are the fused HIP kernels; the optimiser is the fused HIP Adam.
+"""
+import time
+from functools import partial
+from pathlib import Path
+from typing import Any, Callable, Optional
+
+import torch
+from torch import Tensor
+
+from thre3d_atom.modules.optim import VoxeAdam
+from thre3d_atom.modules.volumetric_model import VolumetricModel
+from thre3d_atom.rendering.volumetric.utils.misc import (
+    cast_rays,
+    collate_rays,
+    flatten_rays,
+    sample_random_rays_and_pixels_synchronously,
+)
+from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid
+from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, scale_voxel_grid_with_required_output_size
+from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
+from thre3d_atom.utils.imaging_utils import CameraPose
+from thre3d_atom.utils.logging import log
+from thre3d_atom.utils.metric_utils import mse2psnr
+from thre3d_atom.utils.misc import compute_thre3d_grid_sizes
+
+
+def train_sh_vox_grid_vol_mod_with_posed_images(
+    vol_mod: VolumetricModel,
+    train_dataset: Any,
+    output_dir: Path,
+    random_initializer: Callable[[Tensor], Tensor] = partial(torch.nn.init.uniform_, a=-1.0, b=1.0),
+    test_dataset: Optional[Any] = None,
+    image_batch_cache_size: int = 8,
+    ray_batch_size: int = 32768,
+    num_stages: int = 4,
+    num_iterations_per_stage: int = 2000,
+    scale_factor: float = 2.0,
+    learning_rate: float = 0.03,
+    lr_decay_gamma_per_stage: float = 0.1,
+    lr_decay_steps_per_stage: int = 1000,
+    stagewise_lr_decay_gamma: float = 0.9,
+    render_feedback_pose: Optional[CameraPose] = None,
+    save_freq: int = 1000,
+    test_freq: int = 1000,
+    feedback_freq: int = 100,
+    summary_freq: int = 10,
+    apply_diffuse_render_regularization: bool = True,
+    num_workers: int = 4,
+    verbose_rendering: bool = True,
+    fast_debug_mode: bool = False,
+    lpips_weight: float = 0.0,
+) -> VolumetricModel:
+    if not isinstance(vol_mod.thre3d_repr, VoxelGrid) or vol_mod.render_procedure != render_sh_voxel_grid:
+        raise AssertionError("this train procedure needs an SH-based VoxelGrid volumetric model")
+    if lpips_weight != 0.0:
+        raise NotImplementedError("LPIPS needs the external `lpips` network; not part of this build")
+    device = vol_mod.device
+    output_dir = Path(output_dir)
+    model_dir = output_dir / "saved_models"
+    model_dir.mkdir(exist_ok=True, parents=True)
+
+    grid_sizes = compute_thre3d_grid_sizes(vol_mod.thre3d_repr.grid_dims, num_stages, scale_factor)
+    stage_datasets = [train_dataset.downsampled(scale_factor ** (num_stages - 1 - s)).to(device) for s in range(num_stages)]
+
+    with torch.no_grad():
+        vol_mod.thre3d_repr = scale_voxel_grid_with_required_output_size(vol_mod.thre3d_repr, grid_sizes[0])
+        random_initializer(vol_mod.thre3d_repr.densities)
+        random_initializer(vol_mod.thre3d_repr.features)
+
+    extra_info = {CAMERA_BOUNDS: train_dataset.camera_bounds, CAMERA_INTRINSICS: train_dataset.camera_intrinsics,
+                  HEMISPHERICAL_RADIUS: train_dataset.get_hemispherical_radius_estimate()}
+    global_step, trained = 0, 0.0
+    gen = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+    for stage in range(1, num_stages + 1):
+        data = stage_datasets[stage - 1]
+        intr = data.camera_intrinsics
+        lr = learning_rate * (stagewise_lr_decay_gamma ** (stage - 1))
+        optimizer = VoxeAdam([{"params": vol_mod.thre3d_repr.parameters(), "lr": lr}], betas=(0.9, 0.999))
+        scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_decay_gamma_per_stage)
+        log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
+        for it in range(1, num_iterations_per_stage + 1):
+            t0 = time.perf_counter()
+            picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).tolist()
+            rays = collate_rays([
+                flatten_rays(cast_rays(intr, CameraPose(data.poses[i][:, :3], data.poses[i][:, 3:]), device=device))
+                for i in picks
+            ])
+            pixels = torch.cat([data.images[i].permute(1, 2, 0).reshape(-1, data.images.shape[1]) for i in picks])
+            rays_batch, pixels_batch = sample_random_rays_and_pixels_synchronously(rays, pixels, ray_batch_size)
+
+            specular = vol_mod.render_rays(rays_batch).colour
+            loss = torch.nn.functional.l1_loss(specular, pixels_batch)
+            psnr = mse2psnr(torch.nn.functional.mse_loss(specular.detach(), pixels_batch))
+            if apply_diffuse_render_regularization:
+                diffuse = vol_mod.render_rays(rays_batch, render_diffuse=True).colour
+                loss = loss + torch.nn.functional.l1_loss(diffuse, pixels_batch)
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            global_step += 1
+            trained += time.perf_counter() - t0
+            if global_step % summary_freq == 0 or it in (1, num_iterations_per_stage):
+                log.info(f"Stage: {stage} Global Iteration: {global_step} Stage Iteration: {it} "
+                         f"loss: {float(loss.detach()): .3f} psnr: {float(psnr): .3f}")
+            if it % lr_decay_steps_per_stage == 0:
+                scheduler.step()
+            if it % save_freq == 0 and not fast_debug_mode:
+                torch.save(vol_mod.get_save_info(extra_info), model_dir / f"model_stage_{stage}_iter_{it}.pth")
+        if stage != num_stages:
+            with torch.no_grad():
+                vol_mod.thre3d_repr = scale_voxel_grid_with_required_output_size(vol_mod.thre3d_repr, grid_sizes[stage])
+    torch.save(vol_mod.get_save_info(extra_info), model_dir / "model_final.pth")
+    log.info(f"Training complete; time spent actually training: {trained:.1f} s")
+    return vol_mod
