@@ -161,9 +161,22 @@ def main():
     else:
         kname, kbytes, kms = "render_fwd_kernel<3,1,1>", bytes_fwd, ms_fwd
     achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    # HBM traffic of that kernel: PMC counters cannot be read from inside this process; they are collected by
+    # tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS script) and committed
+    # as profiles/*_pmc_summary.json.  Only reported for the configuration they were measured on.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter) == (160, 400, 256, "random", 0.0, False)
+    if default_cfg and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))["kernels"]
+        key = "voxe::render_bwd_tile_kernel<3, true, true>" if ms_bwd >= ms_fwd else "voxe::render_fwd_kernel<3, 1, 1>"
+        if key in pmc and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
+            # KiB -> bytes; FETCH_SIZE counts 64 B per 128 B request on gfx950 (MI355X_MICROARCH.md, HBM section)
+            traffic = int((2.0 * pmc[key]["FETCH_SIZE"] + pmc[key]["WRITE_SIZE"]) * 1024)
+            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB)"
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kname, "alg_bytes_per_launch": int(kbytes), "launch_ms": round(kms, 4),
         "phases_ms": {"pack": round(prof["ms_pack"] / max(prof["n_pack"], 1), 4), "fwd": round(ms_fwd, 4),
                       "memset": round(prof["ms_memset"] / max(prof["n_memset"], 1), 4), "bwd": round(ms_bwd, 4),

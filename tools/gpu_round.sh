@@ -1,0 +1,22 @@
+#!/bin/bash
+# Full evidence run for a round: GPU tests, smoke, bench lines, rocprofv3 kernel stats, PMC summary.
+#   gpurun --timeout 2400 -- bash tools/gpu_round.sh r01
+set -u
+TAG=${1:-r01}
+export TMPDIR=/tmp
+O=gpurun_out/$TAG
+mkdir -p $O
+nproc > $O/host.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $O/host.txt
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $O/pytest_gpu.log
+timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $O/smoke.log
+timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_400.json
+timeout 300 python bench.py --scene sphere --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_400_sphere.json
+timeout 300 python bench.py --image 100 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_100.json
+timeout 300 python bench.py --grid 256 --image 800 --no-cpu-baseline --steps 10 2>/dev/null | tail -1 > $O/bench_256_800.json
+timeout 300 env VOXE_BWD_MODE=scatter python bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $O/bench_400_scatter_bwd.json
+timeout 300 python bench.py --term-eps 1e-4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_400_term1e-4.json
+for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1
+cd $GRAFT_REPO_ROOT
+head -8 $O/prof/${TAG}_kernel_stats.csv | cut -c1-200
+bash tools/gpu_pmc.sh > $O/pmc.txt 2>&1; tail -3 $O/pmc.txt | cut -c1-300
