@@ -168,6 +168,19 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Point query -- VoxelGrid.forward / forward_attn  thre3d_reprs/voxels.py:287-406
+ *   points [N,3] world coordinates  ->  out [N,F+1] = (trilinear features f_0..f_{F-1}, post(trilinear pre(d*scale)))
+ *   NOT masked by the AABB (the reference masks later, process.py:80-84): zero padding outside the grid.
+ *   Backward: d_out [N,F+1] -> d_densities / d_features (either may be NULL), accumulate as above.
+ *   workspace: >= voxe_workspace_bytes(grid, NULL, 0); cfg-less, so packed-grid reuse is an explicit flag.
+ * ---------------------------------------------------------------------------------------------- */
+int voxe_query_fwd(const VoxeGridDesc* grid, const float* points, int64_t N, float* out,
+                   int32_t reuse_packed_grid, void* workspace, size_t workspace_bytes, void* stream);
+int voxe_query_bwd(const VoxeGridDesc* grid, const float* points, int64_t N, const float* d_out,
+                   float* d_densities, float* d_features, int32_t accumulate, int32_t reuse_packed_grid,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-sample probe (test hook for the bit-exact index-math contract): for ray r, sample k writes
  *   idx  [R,S,3] int32  floor() voxel index of the low trilinear corner (may be -1 or N-1.. out of range)
  *   inside [R,S] uint8  strict AABB test (voxels.py:263-285)
@@ -225,6 +238,9 @@ int voxe_cpu_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                         const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
                         const float* d_colour, const float* d_depth, const float* d_acc,
                         float* d_densities, float* d_features, int32_t accumulate);
+int voxe_cpu_query_fwd(const VoxeGridDesc* grid, const float* points, int64_t N, float* out);
+int voxe_cpu_query_bwd(const VoxeGridDesc* grid, const float* points, int64_t N, const float* d_out,
+                       float* d_densities, float* d_features, int32_t accumulate);
 int voxe_cpu_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                           const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
                           int32_t* idx, uint8_t* inside, float* zvals, float* sigma, float* rad);

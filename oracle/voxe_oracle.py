@@ -185,6 +185,24 @@ def sample_probe(grid: Grid, cfg: abi.VoxeRenderCfg, rays_o, rays_d, jitter=None
     return {"idx": idx, "inside": inside.astype(bool), "z": z, "sigma": sigma, "rad": rad}
 
 
+def query_fwd(grid: Grid, points):
+    points = _f32(points)
+    N, F = points.shape[0], grid.features.shape[-1]
+    out = np.empty((N, F + 1), np.float32)
+    g = grid.desc()
+    _check(lib().voxe_cpu_query_fwd(C.byref(g), points.ctypes.data, N, out.ctypes.data), "query_fwd")
+    return out
+
+
+def query_bwd(grid: Grid, points, d_out):
+    points, d_out = _f32(points), _f32(d_out)
+    gd, gf = np.zeros_like(grid.densities), np.zeros_like(grid.features)
+    g = grid.desc()
+    _check(lib().voxe_cpu_query_bwd(C.byref(g), points.ctypes.data, points.shape[0], d_out.ctypes.data,
+                                    gd.ctypes.data, gf.ctypes.data, 0), "query_bwd")
+    return gd, gf
+
+
 def dcl_fwd_bwd(a, b, grad_scale: float = 1.0):
     a, b = _f32(a), _f32(b)
     loss = np.empty((1,), np.float32)

@@ -205,3 +205,15 @@ def test_frames_psnr():
         img = vo.render_fwd(grid, cfg, o, d)["colour"].reshape(int(h), int(w), 3)
         assert psnr(img, g["frames"][i]) > 100.0  # i.e. identical to ~1e-6
         assert np.linalg.norm(img - g["frames"][i]) / np.linalg.norm(g["frames"][i]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,kind", [("aniso", "softplus"), ("cube", "softplus"), ("abs", "abs"), ("relu", "relu")])
+def test_point_query_forward_and_grads(tag, kind):
+    """VoxelGrid.forward on all probe points (inside AND outside the AABB: the query is not masked) + autograd."""
+    g = load_golden("voxel_forward.npz")
+    grid = grid_from_golden(g, tag + "_", kind)
+    out = vo.query_fwd(grid, g[tag + "_points"])
+    np.testing.assert_allclose(out, g[tag + "_values"], rtol=2e-6, atol=2e-6)
+    gd, gf = vo.query_bwd(grid, g[tag + "_points"], g[tag + "_g_out"])
+    assert rel_l2(gd, g[tag + "_grad_densities"]) < 1e-5
+    assert rel_l2(gf, g[tag + "_grad_features"]) < 1e-6

@@ -210,6 +210,10 @@ def g4_voxel_forward():
             val = vg(pts)
             npts = vg._normalize_points(pts)
             inside = vg.test_inside_volume(pts)
+        # autograd of the point query: loss = sum(forward(points) * G)
+        gq = torch.randn(val.shape, generator=g)
+        gd, gf = torch.autograd.grad((vg(pts) * gq).sum(), [vg.densities, vg.features])
+        out[tag + "_g_out"], out[tag + "_grad_densities"], out[tag + "_grad_features"] = np_(gq), np_(gd), np_(gf)
         out.update(grid_arrays(vg, tag + "_"))
         out[tag + "_points"] = np_(pts)
         out[tag + "_values"] = np_(val)

@@ -302,6 +302,73 @@ int voxe_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
   return finish();
 }
 
+namespace {
+int validate_grid_only(const VoxeGridDesc* g) {
+  if (!g || !g->densities || !g->features) return VOXE_ERR_NULL_POINTER;
+  if (g->X <= 0 || g->Y <= 0 || g->Z <= 0 || g->F <= 0) return VOXE_ERR_BAD_SHAPE;
+  const int C = g->F + 1;
+  if (C != 2 && C != 4 && C != 13 && C != 28 && C != 49) return VOXE_ERR_BAD_SHAPE;
+  if ((long long)g->X * g->Y * g->Z * C >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
+  if (g->density_pre_act != VOXE_ACT_IDENTITY && g->density_pre_act != VOXE_ACT_ABS) return VOXE_ERR_UNSUPPORTED;
+  if (g->density_post_act != VOXE_ACT_IDENTITY && g->density_post_act != VOXE_ACT_RELU &&
+      g->density_post_act != VOXE_ACT_SOFTPLUS)
+    return VOXE_ERR_UNSUPPORTED;
+  return VOXE_OK;
+}
+void grid_to_dev(const VoxeGridDesc* g, DevGrid* dg) {
+  dg->X = g->X; dg->Y = g->Y; dg->Z = g->Z;
+  for (int a = 0; a < 3; ++a) {
+    dg->lo[a] = g->aabb_lo[a]; dg->hi[a] = g->aabb_hi[a];
+    dg->scale[a] = g->norm_scale[a]; dg->bias[a] = g->norm_bias[a];
+  }
+  dg->density_scale = g->density_scale;
+  dg->pre_act = g->density_pre_act; dg->post_act = g->density_post_act;
+}
+}  // namespace
+
+int voxe_query_fwd(const VoxeGridDesc* grid, const float* points, int64_t N, float* out,
+                   int32_t reuse_packed_grid, void* workspace, size_t workspace_bytes, void* stream) {
+  const int st = validate_grid_only(grid);
+  if (st) return st;
+  if (N < 0) return VOXE_ERR_BAD_SHAPE;
+  if (N > 0 && (!points || !out)) return VOXE_ERR_NULL_POINTER;
+  const WsLayout l = ws_layout(grid, nullptr, 0);
+  if (!workspace || workspace_bytes < l.fwd_total) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* packed = (float*)((char*)workspace + l.packed_off);
+  if (!reuse_packed_grid) launch_pack_any(grid, packed, s);
+  if (N == 0) return finish();
+  DevGrid dg;
+  grid_to_dev(grid, &dg);
+  launch_query(dg, grid->F + 1, packed, points, N, out, nullptr, nullptr, false, false, s);
+  return finish();
+}
+
+int voxe_query_bwd(const VoxeGridDesc* grid, const float* points, int64_t N, const float* d_out,
+                   float* d_densities, float* d_features, int32_t accumulate, int32_t reuse_packed_grid,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  const int st = validate_grid_only(grid);
+  if (st) return st;
+  if (N < 0) return VOXE_ERR_BAD_SHAPE;
+  if (N > 0 && (!points || !d_out)) return VOXE_ERR_NULL_POINTER;
+  if (!d_densities && !d_features) return VOXE_OK;
+  const WsLayout l = ws_layout(grid, nullptr, 0);
+  if (!workspace || workspace_bytes < l.total) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  float* packed = (float*)((char*)workspace + l.packed_off);
+  float* gpacked = (float*)((char*)workspace + l.grad_off);
+  if (!reuse_packed_grid) launch_pack_any(grid, packed, s);
+  if (hipMemsetAsync(gpacked, 0, l.state_off - l.grad_off, s) != hipSuccess) return VOXE_ERR_LAUNCH;
+  if (N > 0) {
+    DevGrid dg;
+    grid_to_dev(grid, &dg);
+    launch_query(dg, grid->F + 1, packed, points, N, nullptr, d_out, gpacked, d_densities != nullptr,
+                 d_features != nullptr, s);
+  }
+  launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, s);
+  return finish();
+}
+
 size_t voxe_dcl_scratch_bytes(int64_t n) { return dcl_scratch_bytes(n); }
 
 int voxe_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale, float* loss_out,

@@ -37,6 +37,10 @@ void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const B
 void launch_probe(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const ProbeArgs& a,
                   hipStream_t st);
 
+// point query (out != nullptr: forward; else backward into gpacked)
+void launch_query(const DevGrid& g, int C, const float* packed, const float* points, long long N, float* out,
+                  const float* d_out, float* gpacked, bool want_d, bool want_f, hipStream_t st);
+
 // voxe_render_tile.hip: LDS-window backward for image-ordered SH-0 / attention renders
 bool tile_bwd_supported(const DevCfg& c, int deg);
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st);

@@ -312,6 +312,92 @@ __global__ __launch_bounds__(256) void sample_probe_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Point query: VoxelGrid.forward / forward_attn (voxels.py:287-406), un-masked, + its backward.
+// One thread per point; same footprint / cell code as the renderer (indices bit-exact by construction).
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void query_fwd_kernel(DevGrid g, const float* __restrict__ packed,
+                                                        const float* __restrict__ points, long long N,
+                                                        float* __restrict__ out) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
+  Footprint fp;
+  footprint(g, p, fp);
+  Cell cell;
+  make_cell(g, fp, cell);
+  const CellAddr ad = cell_addr(g, cell);
+  float acc[C];
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) acc[ch] = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = (cell.w[0][k & 1] * cell.w[1][(k >> 1) & 1]) * cell.w[2][k >> 2];
+    const float* __restrict__ src = packed + (long long)(ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz) * C;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) acc[ch] = fmaf(src[ch], w, acc[ch]);
+  }
+  acc[C - 1] = post_activate(g.post_act, acc[C - 1]);
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) out[n * C + ch] = acc[ch];
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void query_bwd_kernel(DevGrid g, const float* __restrict__ packed,
+                                                        const float* __restrict__ points, long long N,
+                                                        const float* __restrict__ d_out,
+                                                        float* __restrict__ gpacked, int want_d, int want_f) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float p[3] = {points[3 * n], points[3 * n + 1], points[3 * n + 2]};
+  Footprint fp;
+  footprint(g, p, fp);
+  Cell cell;
+  make_cell(g, fp, cell);
+  const CellAddr ad = cell_addr(g, cell);
+  float v = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = (cell.w[0][k & 1] * cell.w[1][(k >> 1) & 1]) * cell.w[2][k >> 2];
+    v = fmaf(packed[(long long)(ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz) * C + (C - 1)], w, v);
+  }
+  float value, dpost;
+  post_activate_vg(g.post_act, v, value, dpost);
+  const float dv = d_out[n * C + (C - 1)] * dpost;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = (cell.w[0][k & 1] * cell.w[1][(k >> 1) & 1]) * cell.w[2][k >> 2];
+    if (w != 0.0f) {
+      float* __restrict__ dst = gpacked + (long long)(ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz) * C;
+      if (want_f) {
+#pragma unroll
+        for (int ch = 0; ch < C - 1; ++ch) atomicAdd(dst + ch, d_out[n * C + ch] * w);
+      }
+      if (want_d) atomicAdd(dst + (C - 1), dv * w);
+    }
+  }
+}
+
+template <int C>
+static void launch_query_t(const DevGrid& g, const float* packed, const float* points, long long N, float* out,
+                           const float* d_out, float* gpacked, bool want_d, bool want_f, hipStream_t st) {
+  const int nb = (int)((N + 255) / 256);
+  if (out) query_fwd_kernel<C><<<nb, 256, 0, st>>>(g, packed, points, N, out);
+  else query_bwd_kernel<C><<<nb, 256, 0, st>>>(g, packed, points, N, d_out, gpacked, want_d, want_f);
+}
+
+void launch_query(const DevGrid& g, int C, const float* packed, const float* points, long long N, float* out,
+                  const float* d_out, float* gpacked, bool want_d, bool want_f, hipStream_t st) {
+  switch (C) {
+    case 2: launch_query_t<2>(g, packed, points, N, out, d_out, gpacked, want_d, want_f, st); break;
+    case 4: launch_query_t<4>(g, packed, points, N, out, d_out, gpacked, want_d, want_f, st); break;
+    case 13: launch_query_t<13>(g, packed, points, N, out, d_out, gpacked, want_d, want_f, st); break;
+    case 28: launch_query_t<28>(g, packed, points, N, out, d_out, gpacked, want_d, want_f, st); break;
+    case 49: launch_query_t<49>(g, packed, points, N, out, d_out, gpacked, want_d, want_f, st); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host-side launchers (called from voxe_api.hip)
 // ------------------------------------------------------------------------------------------------
 static inline int blocks_for(const DevCfg& c) {

@@ -235,17 +235,24 @@ class VoxelGrid(Module):
             new.__dict__[k] = {} if k == "_voxe_workspaces" else copy.deepcopy(v, memo)
         return new
 
+    def _query(self, points: Tensor, features: Tensor, densities: Tensor, attn: bool) -> Tensor:
+        out = _ops.query_points(self.voxe_grid_spec(attn=attn), densities, features, points,
+                                workspace=self.voxe_workspace("query_attn" if attn else "query"))
+        # the reference squeezes its grid_sample outputs (voxels.py:316,331): a single point loses its axis
+        return out.reshape(-1) if points.shape[0] == 1 and not attn else out
+
     def forward(self, points: Tensor, viewdirs: Optional[Tensor] = None) -> Tensor:
-        raise NotImplementedError(
-            "VoxelGrid.forward(points) (per-point torch grid_sample, reference voxels.py:287-342) is fused "
-            "into the HIP render kernels; render through render_sh_voxel_grid / VolumetricModel.render_rays"
-        )
+        """[N,3] world points -> [N, F+1] = cat(trilinear features, post-activated trilinear density), zero padding
+        outside the grid, NOT masked by the AABB (voxels.py:287-342).  Runs the HIP point-query kernel; differentiable
+        w.r.t. the grid tensors.  (The renderer does not go through this: sampling is fused into its kernels.)"""
+        return self._query(points, self._features, self._densities, attn=False)
 
     def forward_attn(self, points: Tensor, viewdirs: Optional[Tensor] = None, orig_densities=False) -> Tensor:
-        raise NotImplementedError(
-            "VoxelGrid.forward_attn(points) (reference voxels.py:344-406) is fused into the HIP render "
-            "kernels; render through render_sh_voxel_grid_attn / VolumetricModel.render_rays_attn"
-        )
+        """like forward() with the attention grid as the feature: [N, 2] = (attn, density) (voxels.py:344-406)"""
+        if self.attn is None:
+            raise VoxeError("this VoxelGrid has no attention grid (attn is None)")
+        densities = self.orig_densities.detach().to(self.attn.device) if orig_densities else self._densities
+        return self._query(points, self.attn, densities, attn=True)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -98,7 +98,13 @@ _COMMON = {
 # the CPU twin's render_bwd does not take the forward outputs (colour, depth, acc): it recomputes
 _CPU_RENDER_BWD = [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32]
 
+# point query: the HIP flavour takes (reuse_packed_grid, workspace, bytes, stream) after the common arguments
+_QUERY_COMMON_FWD = [_GD, _P, C.c_int64, _P]
+_QUERY_COMMON_BWD = [_GD, _P, C.c_int64, _P, _P, _P, C.c_int32]
+
 HIP_ONLY = {
+    "query_fwd": (C.c_int, _QUERY_COMMON_FWD + [C.c_int32, _P, C.c_size_t, _P]),
+    "query_bwd": (C.c_int, _QUERY_COMMON_BWD + [C.c_int32, _P, C.c_size_t, _P]),
     "abi_version": (C.c_int, []),
     "strerror": (C.c_char_p, [C.c_int]),
     "device_check": (C.c_int, [C.c_char_p, C.c_size_t]),
@@ -110,6 +116,8 @@ HIP_ONLY = {
 }
 
 CPU_ONLY = {
+    "query_fwd": (C.c_int, _QUERY_COMMON_FWD),
+    "query_bwd": (C.c_int, _QUERY_COMMON_BWD),
     "num_threads": (C.c_int, []),
     "jitter_uniform": (C.c_float, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32]),
 }
