@@ -283,6 +283,24 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
             ab0[s] = a0 * kLat + b0 + 21 * (key & 7);  // + the per-layer rotation of layer_pos()
           }
           if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
+            // Lanes rotate through the corners (rot) AND through the channels (crot): the lanes of one wave
+            // instruction then spread over 8 corners x C channel planes, so lanes that share a voxel rarely hit
+            // the same LDS address / bank in the same instruction.
+            constexpr bool kAllCh = WANT_D && WANT_F;
+            float gr[C];
+            int poff[C];
+            if constexpr (kAllCh && C == 4) {
+              const int crot = lane >> 1 & 3;
+              const bool r1 = crot & 1, r2 = crot & 2;
+              // gr[j] = gch[(j + crot) & 3], poff[j] = plane offset of that channel
+              const float a0 = r1 ? gch[1] : gch[0], a1 = r1 ? gch[2] : gch[1], a2 = r1 ? gch[3] : gch[2], a3 = r1 ? gch[0] : gch[3];
+              gr[0] = r2 ? a2 : a0; gr[1] = r2 ? a3 : a1; gr[2] = r2 ? a0 : a2; gr[3] = r2 ? a1 : a3;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) poff[j] = ((j + crot) & 3) * kPlane;
+            } else {
+#pragma unroll
+              for (int j = 0; j < C; ++j) { gr[j] = gch[j]; poff[j] = j * kPlane; }
+            }
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
               const int cidx = (cc + rot) & 7;
@@ -291,8 +309,8 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
               const int idx = (cm ? lofs[1] : lofs[0]) + (((cm ? ab0[1] : ab0[0]) + (cu ? kLat : 0) + (cv ? 1 : 0)) & 63);
 #pragma unroll
               for (int ch = 0; ch < C; ++ch) {
-                if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
-                  __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                  __hip_atomic_fetch_add(&win[poff[ch] + idx], (double)(gr[ch] * wgt), __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);
               }
             }
