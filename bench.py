@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=200, help="side of the image the CPU oracle is timed on")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--no-jitter", action="store_true")
+    ap.add_argument("--camera", type=int, default=3, help="index of the synthetic camera (of 100) rendered by rank 0")
     return ap.parse_args()
 
 
@@ -89,7 +90,7 @@ def main():
     exp_avg, exp_avg_sq = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
 
     # weak scaling: every rank renders its own camera (cameras rank, rank + world, ... of the 100-view set)
-    yaw, pitch = synth_pose_angles(3 + rank, 100)
+    yaw, pitch = synth_pose_angles(args.camera + rank, 100)
     pose = pose_spherical(yaw, pitch, RADIUS)
     rays_o, rays_d = ops.cast_rays(HW, HW, focal_for(HW), pose.rotation, pose.translation, dev)
     R = rays_o.shape[0]
@@ -166,7 +167,7 @@ def main():
     # as profiles/*_pmc_summary.json.  Only reported for the configuration they were measured on.
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter) == (160, 400, 256, "random", 0.0, False)
+    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera) == (160, 400, 256, "random", 0.0, False, 3)
     if default_cfg and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))["kernels"]
         key = "voxe::render_bwd_tile_kernel<3, true, true>" if ms_bwd >= ms_fwd else "voxe::render_fwd_kernel<3, 1, 1>"
@@ -203,7 +204,7 @@ def main():
         dt = time.perf_counter() - t1
         cpu_baseline = {
             "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": vo.num_threads(), "kind": "port",
-            "sample": f"{hw}x{hw} rays of camera 3 (same {G}^3 grid, S={S}, jitter on), 1 forward + 1 backward "
+            "sample": f"{hw}x{hw} rays of camera {args.camera} (same {G}^3 grid, S={S}, jitter on), 1 forward + 1 backward "
                       f"of oracle/voxe_cpu.c with OpenMP, {dt:.1f} s",
         }
 

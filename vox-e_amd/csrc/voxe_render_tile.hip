@@ -66,14 +66,14 @@ struct Window {
   __device__ __forceinline__ int off_v(int im) const { return (int)floorf(Av + Bv * (float)im) - 3; }
   // storage position of lateral cell (a, b) inside its layer: rotated per layer so that the same (a, b)
   // of neighbouring layers lands in different LDS banks
-  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + 21 * (key & 7)) & 63; }
+  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + 21 * (key & (kRing - 1))) & 63; }
 };
 template <int C>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
                                             const Window& w, int key, int lane) {
   const int im = w.sgn * key;
   const int offu = w.off_u(im), offv = w.off_v(im);
-  const int lbase = (key & 7) * kLayerSlots;
+  const int lbase = (key & (kRing - 1)) * kLayerSlots;
   constexpr int kPerInstr = 64 / C;  // voxels per wave instruction (C == 4 -> 16, C == 2 -> 32)
 #pragma unroll
   for (int j = 0; j < kLayerSlots / kPerInstr; ++j) {
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
   w.base = wave_min_i32(first_key);
   __syncthreads();  // window zeroed
 
-  const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // corner rotation: neighbours in the tile differ
+  const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // per-lane corner permutation: neighbours in the tile differ
   for (int k = kmin; k <= kmax; ++k) {
     const bool on = has && (k >= k_lo) && (k <= k_hi);
     if (on) {
@@ -279,22 +279,34 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
             const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
             fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
                    ((unsigned)b0 < (unsigned)(kLat - 1));
-            lofs[s] = (key & 7) * kLayerSlots;
-            ab0[s] = a0 * kLat + b0 + 21 * (key & 7);  // + the per-layer rotation of layer_pos()
+            lofs[s] = (key & (kRing - 1)) * kLayerSlots;
+            ab0[s] = a0 * kLat + b0 + 21 * (key & (kRing - 1));  // + the per-layer rotation of layer_pos()
           }
           if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
-            // Lanes rotate through the corners (rot) AND through the channels (crot): the lanes of one wave
-            // instruction then spread over 8 corners x C channel planes, so lanes that share a voxel rarely hit
-            // the same LDS address / bank in the same instruction.
+            // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
+            // (crot): the lanes of one wave instruction then spread over 8 corners x C channel planes, so lanes that
+            // share a voxel rarely hit the same LDS address / bank in the same instruction.  With an XOR the
+            // corner bits of instruction cc are (constant bit) ^ (lane bit): every operand pair is swapped ONCE per
+            // sample ("A" = value used where the constant bit is 0, "B" where it is 1) and the unrolled loop below
+            // contains no selects at all.
             constexpr bool kAllCh = WANT_D && WANT_F;
+            const bool r0 = rot & 1, r1 = rot & 2, r2 = rot & 4;
+            const float wmA = r0 ? wm[1] : wm[0], wmB = r0 ? wm[0] : wm[1];
+            const float wuA = r1 ? wu[1] : wu[0], wuB = r1 ? wu[0] : wu[1];
+            const float wvA = r2 ? wv[1] : wv[0], wvB = r2 ? wv[0] : wv[1];
+            const int lofA = r0 ? lofs[1] : lofs[0], lofB = r0 ? lofs[0] : lofs[1];
+            const int abA = r0 ? ab0[1] : ab0[0], abB = r0 ? ab0[0] : ab0[1];
+            const int uA = r1 ? kLat : 0, uB = kLat - uA, vA = r2 ? 1 : 0, vB = 1 - vA;
+            const float wmu[4] = {wmA * wuA, wmB * wuA, wmA * wuB, wmB * wuB};       // [cm + 2 cu]
+            const int abu[4] = {abA + uA, abB + uA, abA + uB, abB + uB};
             float gr[C];
             int poff[C];
             if constexpr (kAllCh && C == 4) {
               const int crot = lane >> 1 & 3;
-              const bool r1 = crot & 1, r2 = crot & 2;
+              const bool c1 = crot & 1, c2 = crot & 2;
               // gr[j] = gch[(j + crot) & 3], poff[j] = plane offset of that channel
-              const float a0 = r1 ? gch[1] : gch[0], a1 = r1 ? gch[2] : gch[1], a2 = r1 ? gch[3] : gch[2], a3 = r1 ? gch[0] : gch[3];
-              gr[0] = r2 ? a2 : a0; gr[1] = r2 ? a3 : a1; gr[2] = r2 ? a0 : a2; gr[3] = r2 ? a1 : a3;
+              const float a0 = c1 ? gch[1] : gch[0], a1 = c1 ? gch[2] : gch[1], a2 = c1 ? gch[3] : gch[2], a3 = c1 ? gch[0] : gch[3];
+              gr[0] = c2 ? a2 : a0; gr[1] = c2 ? a3 : a1; gr[2] = c2 ? a0 : a2; gr[3] = c2 ? a1 : a3;
 #pragma unroll
               for (int j = 0; j < 4; ++j) poff[j] = ((j + crot) & 3) * kPlane;
             } else {
@@ -303,10 +315,9 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
             }
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
-              const int cidx = (cc + rot) & 7;
-              const bool cm = cidx & 1, cu = cidx & 2, cv = cidx & 4;
-              const float wgt = ((cm ? wm[1] : wm[0]) * (cu ? wu[1] : wu[0])) * (cv ? wv[1] : wv[0]);
-              const int idx = (cm ? lofs[1] : lofs[0]) + (((cm ? ab0[1] : ab0[0]) + (cu ? kLat : 0) + (cv ? 1 : 0)) & 63);
+              const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;  // compile-time bits of this instruction
+              const float wgt = wmu[bm + 2 * bu] * (bv ? wvB : wvA);
+              const int idx = (bm ? lofB : lofA) + ((abu[bm + 2 * bu] + (bv ? vB : vA)) & 63);
 #pragma unroll
               for (int ch = 0; ch < C; ++ch) {
                 if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
                 const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
                                    ((unsigned)b < (unsigned)kLat);
                 if (inwin) {
-                  const int idx = (key & 7) * kLayerSlots + w.layer_pos(key, a * kLat + b);
+                  const int idx = (key & (kRing - 1)) * kLayerSlots + w.layer_pos(key, a * kLat + b);
 #pragma unroll
                   for (int ch = 0; ch < C; ++ch) {
                     if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
