@@ -90,7 +90,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, fwd_total, total;
+  size_t packed_off, grad_off, state_off, seg_off, fwd_total, total;
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t nvox = (size_t)g->X * g->Y * g->Z;
@@ -102,8 +102,11 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   l.packed_off = 0;
   l.grad_off = bytes;
   l.state_off = 2 * bytes;
-  l.fwd_total = bytes;  // the forward alone needs only the packed grid (states are written when they fit)
-  l.total = 2 * bytes + state;
+  // partial results of the depth-segmented forward: nseg x (cout + 3) floats per ray
+  const size_t seg = align_up((size_t)nseg * (size_t)(cout + 3) * (size_t)(R > 0 ? R : 0) * sizeof(float), 256);
+  l.seg_off = 2 * bytes + state;
+  l.fwd_total = bytes;  // the forward alone needs only the packed grid (states / segments are used when they fit)
+  l.total = 2 * bytes + state + seg;
   return l;
 }
 
@@ -229,7 +232,8 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   float* state = nullptr;
   if (tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd() && workspace_bytes >= l.total)
     state = (float*)((char*)workspace + l.state_off);
-  FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state};
+  float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
+  FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
   { PhaseTimer t(PH_FWD, s); launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s); }
   return finish();
 }
@@ -265,7 +269,8 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     if (tiled && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
-      FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state};
+      FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
+                (float*)((char*)workspace + l.seg_off)};
       launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, s);
     }
     PhaseTimer t(PH_BWD, s);

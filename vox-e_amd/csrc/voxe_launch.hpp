@@ -11,6 +11,7 @@ struct FwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter;
   float *colour, *depth, *acc, *disparity;
   float* ray_state;  // per-ray depth-segment states (nullable): see ray_state_index()
+  float* segbuf;     // per-ray per-segment partial results of the segmented forward (nullable)
 };
 struct BwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc;

@@ -167,6 +167,125 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Depth-segmented forward: one 400x400 image is only ~2500 waves, too few to hide the gather latency on
+// 1024 SIMDs, and one thread marching all S samples is a long dependent chain.  Compositing is associative:
+// segment s (samples [s*kSegLen, (s+1)*kSegLen)) computes, with a LOCAL transmittance starting at 1,
+//   Tseg = prod (1 - alpha_k),  csum = sum col_k alpha_k Tloc_k,  asum = sum alpha_k Tloc_k,  dsum = sum z_k alpha_k Tloc_k
+// in its own thread (8x more waves), and render_fwd_combine_kernel folds the segments front to back:
+//   T_start(s) = prod_{s' < s} Tseg(s'),  colour = sum_s T_start(s) csum(s), ...
+// The combine pass also emits the per-ray segment-start states the segmented backward consumes.
+// (Used when term_eps == 0: early termination is inherently sequential.)
+// segbuf layout: [segment][component][ray], components (Tseg, csum[COUT], asum, dsum).
+// ------------------------------------------------------------------------------------------------
+template <int COUT, int NCM, int NCU>
+__global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c,
+                                                             const float* __restrict__ packed,
+                                                             const float* __restrict__ rays_o,
+                                                             const float* __restrict__ rays_d,
+                                                             const float* __restrict__ jitter,
+                                                             float* __restrict__ segbuf) {
+  constexpr int NC = COUT + 3;
+  const int nseg = num_segments(c.S);
+  // blocks: segment-major within a tile (consecutive blocks = the segments of one tile)
+  const int seg = blockIdx.x % nseg;
+  long long r;
+  if (!map_ray_block(c, blockIdx.x / nseg, gridDim.x / nseg, r)) return;
+  RayCtx<COUT, NCM, NCU> rc;
+  rc.init(g, c, r, rays_o, rays_d, jitter);
+  const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;
+  const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
+
+  float csum[COUT];
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  if (k_lo <= k_hi) {
+    float z_next = rc.dg.z(k_lo);
+    for (int k = k_lo; k <= k_hi; ++k) {
+      const float z = z_next;
+      const bool last = (k == c.S - 1);
+      if (!last) z_next = rc.dg.z(k + 1);
+      float p[3];
+      rc.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      if (!fp.inside) continue;
+      Cell cell;
+      make_cell(g, fp, cell);
+      float v, rad[COUT];
+      gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
+      const float sigma = post_activate(g.post_act, v);
+      const float dl = last ? kInfinity : (z_next - z);
+      const float delta = dl * rc.dnorm;
+      const float e = fast_exp(-(sigma * delta));
+      const float alpha = 1.0f - e;
+      const float om = 1.0f - alpha;
+      const float w = alpha * T;
+      T = T * om;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), w, csum[ch]);
+      asum = asum + w;
+      dsum = fmaf(z, w, dsum);
+    }
+  }
+  const long long base = (long long)seg * NC;
+  segbuf[(base + 0) * c.R + r] = T;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) segbuf[(base + 1 + ch) * c.R + r] = csum[ch];
+  segbuf[(base + 1 + COUT) * c.R + r] = asum;
+  segbuf[(base + 2 + COUT) * c.R + r] = dsum;
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void render_fwd_combine_kernel(DevCfg c, const float* __restrict__ segbuf,
+                                                                 float* __restrict__ colour,
+                                                                 float* __restrict__ depth,
+                                                                 float* __restrict__ acc,
+                                                                 float* __restrict__ disparity,
+                                                                 float* __restrict__ ray_state) {
+  constexpr int NC = COUT + 3;
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= c.R) return;
+  const int nseg = num_segments(c.S);
+  float csum[COUT];
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  for (int s = 0; s < nseg; ++s) {
+    if (ray_state && s > 0) {  // state BEFORE segment s == boundary s
+      ray_state[ray_state_index(s, 0, NC, c.R, r)] = T;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) ray_state[ray_state_index(s, 1 + ch, NC, c.R, r)] = csum[ch];
+      ray_state[ray_state_index(s, 1 + COUT, NC, c.R, r)] = asum;
+      ray_state[ray_state_index(s, 2 + COUT, NC, c.R, r)] = dsum;
+    }
+    const long long base = (long long)s * NC;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(T, segbuf[(base + 1 + ch) * c.R + r], csum[ch]);
+    asum = fmaf(T, segbuf[(base + 1 + COUT) * c.R + r], asum);
+    dsum = fmaf(T, segbuf[(base + 2 + COUT) * c.R + r], dsum);
+    T = T * segbuf[(base + 0) * c.R + r];
+  }
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) {
+    float col = csum[ch];
+    if (c.white) {
+      float bk = 1.0f - asum;
+      if (c.attn) bk = bk * 0.0f;
+      col = col + bk;
+    }
+    if (colour) colour[r * COUT + ch] = col;
+  }
+  if (depth) depth[r] = dsum;
+  if (acc) acc[r] = asum;
+  if (disparity) {
+    const float q = dsum / asum;
+    const float m = (q != q) ? q : (q > kZeroPlus ? q : kZeroPlus);
+    disparity[r] = 1.0f / m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward: recompute the march, turn (d_colour, d_depth, d_acc) into per-sample gradients with the
 // prefix/total form of the suffix sum, scatter-add to the packed gradient grid.
 //   dL/dw_k    = sum_c g_c col_kc - [white & !attn] sum_c g_c + g_depth z_k + g_acc
@@ -427,6 +546,18 @@ static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d
 
 template <int COUT, int NCM, int NCU>
 static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
+  const int nseg = num_segments(c.S);
+  // With few rays (a 100x100 image is 40 blocks) the chip is starved: split the march into depth segments.
+  // At 400x400 there are enough waves and the segmented variant is ~20 % slower (per-segment ray setup, extra
+  // partial-result traffic, more lock-step waste), so it is used below kSegFwdMaxRays only.
+  constexpr long long kSegFwdMaxRays = 65536;
+  if (a.segbuf && nseg > 1 && !(c.term_eps > 0.0f) && c.R <= kSegFwdMaxRays) {
+    render_fwd_seg_kernel<COUT, NCM, NCU><<<blocks_for(c) * nseg, 256, 0, st>>>(
+        g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
+    render_fwd_combine_kernel<COUT><<<(int)((c.R + 255) / 256), 256, 0, st>>>(
+        c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
+    return;
+  }
   render_fwd_kernel<COUT, NCM, NCU><<<blocks_for(c), 256, 0, st>>>(
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
 }

@@ -30,17 +30,19 @@ __device__ __forceinline__ long long ray_state_index(int boundary, int comp, int
 //   mode 2: row interleave -- XCD x walks tile rows x, x+8, x+16, ...: balances the XCDs when the work per
 //           row varies (image centre vs borders) at the price of every XCD touching the whole frustum
 // Tiles >= nt (padding of the launch) are reported as -1.
-__device__ __forceinline__ int logical_tile(const DevCfg& c, int ntx, int nty) {
-  const int b = blockIdx.x;
+__device__ __forceinline__ int logical_tile_of(const DevCfg& c, int b, int nblocks, int ntx, int nty) {
   if (c.map_mode == 1) return b < ntx * nty ? b : -1;
   const int x = b & 7, slot = b >> 3;
   if (c.map_mode == 2) {
     const int row = x + 8 * (slot / ntx), col = slot % ntx;
     return row < nty ? row * ntx + col : -1;
   }
-  const int per = gridDim.x >> 3;  // host launches a multiple of 8 blocks
+  const int per = nblocks >> 3;  // host launches a multiple of 8 blocks
   const int t = x * per + slot;
   return t < ntx * nty ? t : -1;
+}
+__device__ __forceinline__ int logical_tile(const DevCfg& c, int ntx, int nty) {
+  return logical_tile_of(c, blockIdx.x, gridDim.x, ntx, nty);
 }
 
 // number of blocks to launch for nt = ntx * nty tiles under the mapping mode
@@ -50,13 +52,15 @@ static inline int blocks_for_tiles(int map_mode, long long ntx, long long nty) {
   return (int)((ntx * nty + 7) / 8 * 8);
 }
 
-__device__ __forceinline__ bool map_ray(const DevCfg& c, long long& r) {
+// b / nblocks: this block's index among the `nblocks` ray blocks of the launch (a kernel that runs several
+// blocks per ray block, e.g. one per depth segment, passes blockIdx.x / n and gridDim.x / n).
+__device__ __forceinline__ bool map_ray_block(const DevCfg& c, int b, int nblocks, long long& r) {
   const int tid = threadIdx.x;
   if (c.image_width > 0) {
     const int W = c.image_width;
     const int H = (int)(c.R / W);
     const int ntx = (W + 15) >> 4, nty = (H + 15) >> 4;
-    const int logical = logical_tile(c, ntx, nty);
+    const int logical = logical_tile_of(c, b, nblocks, ntx, nty);
     if (logical < 0) return false;
     const int ty = logical / ntx, tx = logical - ty * ntx;
     const int wave = tid >> 6, lane = tid & 63;
@@ -67,10 +71,13 @@ __device__ __forceinline__ bool map_ray(const DevCfg& c, long long& r) {
     return true;
   }
   const int nt = (int)((c.R + 255) / 256);
-  const int logical = logical_tile(c, 1, nt);
+  const int logical = logical_tile_of(c, b, nblocks, 1, nt);
   if (logical < 0) return false;
   r = (long long)logical * 256 + tid;
   return r < c.R;
+}
+__device__ __forceinline__ bool map_ray(const DevCfg& c, long long& r) {
+  return map_ray_block(c, blockIdx.x, gridDim.x, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -138,18 +145,22 @@ __device__ __forceinline__ void gather(const DevGrid& g, const float* __restrict
   for (int i = 0; i < COUT * NCU; ++i) f[i] = 0.0f;
   v = 0.0f;
   if constexpr (C == 4) {
+    // packed math: (r,g) and (b,sigma) pairs go through v_pk_fma_f32 (2 FMAs per issue slot)
+    typedef float v2f __attribute__((ext_vector_type(2)));
     float4 t[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       t[k] = reinterpret_cast<const float4*>(packed)[ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz];
+    v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float w = wxy[k & 3] * cell.w[2][k >> 2];
-      f[0] = fmaf(t[k].x, w, f[0]);
-      f[1] = fmaf(t[k].y, w, f[1]);
-      f[2] = fmaf(t[k].z, w, f[2]);
-      v = fmaf(t[k].w, w, v);
+      const v2f ww = {w, w};
+      const v2f a = {t[k].x, t[k].y}, b = {t[k].z, t[k].w};
+      rg = __builtin_elementwise_fma(a, ww, rg);
+      bs = __builtin_elementwise_fma(b, ww, bs);
     }
+    f[0] = rg.x; f[1] = rg.y; f[2] = bs.x; v = bs.y;
   } else if constexpr (C == 2) {
     float2 t[8];
 #pragma unroll

@@ -119,264 +119,298 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
 
   RayCtx<COUT, 1, 1> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
-  const int k_lo = max(rc.k_lo, ks);          // this lane's samples inside the segment
-  int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
-  bool has = k_lo <= k_hi;
-  // state at the segment start (transmittance + partial sums of the forward), see save_state()
-  float T = 1.0f, pre_c[COUT], pre_a = 0.0f, pre_d = 0.0f;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = 0.0f;
-  if (has && seg > 0) {
-    constexpr int NC = COUT + 3;
-    T = ray_state[ray_state_index(seg, 0, NC, c.R, r)];
-#pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
-    pre_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
-    pre_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
-    if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
-  }
-  const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
-  const int kmax = wave_max_i32(has ? k_hi : -1);
-  if (kmin > kmax) return;  // wave-uniform: no ray of the tile meets the volume
 
-  // ---- window geometry from a reference ray (the lane next to the tile centre, if it has samples) ----
-  Window w;
+  // ---- pixel footprint: does the 8x8 tile fit the 8x8 lateral LDS window? ------------------------------
+  // Low-resolution images have pixels farther apart than a voxel; then the tile is processed as four 4x4
+  // quadrants (16 lanes each) in consecutive passes over the same window, so the gradient is still combined in
+  // LDS instead of falling back to one global atomic per corner and channel.  (Wave-uniform decision.)
+  int npass = 1;
   {
-    const unsigned long long hm = __ballot(has);
-    const int ref = ((hm >> 27) & 1ull) ? 27 : (__ffsll((long long)hm) - 1);
-    const int N[3] = {g.X, g.Y, g.Z};
-    float U0[3], DU[3];
+    const unsigned long long am = __ballot(alive);
+    if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
+      const int N[3] = {g.X, g.Y, g.Z};
+      const float zref = readlane_f32(rc.dg.zlin(ke), 0);
+      float ext = 0.0f;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
-      const float half = 0.5f * (float)N[a];
-      U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
-      DU[a] = rd * g.scale[a] * half;
-    }
-    const float ax = fabsf(DU[0]), ay = fabsf(DU[1]), az = fabsf(DU[2]);
-    w.m = (ax >= ay && ax >= az) ? 0 : ((ay >= az) ? 1 : 2);
-    w.u = (w.m == 0) ? 1 : 0;
-    w.v = (w.m == 2) ? 1 : 2;
-    const float DUm = (w.m == 0) ? DU[0] : ((w.m == 1) ? DU[1] : DU[2]);
-    const float U0m = (w.m == 0) ? U0[0] : ((w.m == 1) ? U0[1] : U0[2]);
-    const float DUu = (w.u == 0) ? DU[0] : DU[1], U0u = (w.u == 0) ? U0[0] : U0[1];
-    const float DUv = (w.v == 1) ? DU[1] : DU[2], U0v = (w.v == 1) ? U0[1] : U0[2];
-    w.sgn = (DUm < 0.0f) ? -1 : 1;
-    const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
-    w.Bu = DUu * inv; w.Au = U0u - w.Bu * U0m;
-    w.Bv = DUv * inv; w.Av = U0v - w.Bv * U0m;
-    const int sx = g.Y * g.Z, sy = g.Z;
-    w.stride_m = (w.m == 0) ? sx : ((w.m == 1) ? sy : 1);
-    w.stride_u = (w.u == 0) ? sx : sy;
-    w.stride_v = (w.v == 1) ? sy : 1;
-  }
-  // lowest layer key a sample with low-corner index pm can write (layers pm and pm + 1)
-  auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
-  auto pick = [&](const int (&t)[3], int axis) { return axis == 0 ? t[0] : (axis == 1 ? t[1] : t[2]); };
-
-  // ---- per-ray constants of the backward (see render_bwd_kernel) -------------------------------
-  float gc[COUT], gsum = 0.0f;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
-  const float gdep = d_depth ? d_depth[r] : 0.0f;
-  const float gacc = d_acc ? d_acc[r] : 0.0f;
-  const bool white = c.white && !c.attn;
-  const float asum = acc[r];
-  float total = gdep * depth[r] + gacc * asum;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) {
-    const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
-    total += gc[ch] * csum;
-  }
-  if (white) total -= gsum * asum;
-  // prefix = sum_{j < segment start} dL/dw_j w_j from the saved partial sums
-  float prefix = gdep * pre_d + gacc * pre_a;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
-  if (white) prefix -= gsum * pre_a;
-
-  // first sample of every ray (rolling: z_cur / fp_cur always describe sample max(k, k_lo))
-  float z_cur = 0.0f;
-  Footprint fp_cur;
-  fp_cur.inside = false;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
-  int first_key = INT_MAX;
-  if (has) {
-    z_cur = rc.dg.z(k_lo);
-    float p[3];
-    rc.point(z_cur, p);
-    footprint(g, p, fp_cur);
-    first_key = minkey(pick(fp_cur.i0, w.m));
-  }
-  w.base = wave_min_i32(first_key);
-  __syncthreads();  // window zeroed
-
-  const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // per-lane corner permutation: neighbours in the tile differ
-  for (int k = kmin; k <= kmax; ++k) {
-    const bool on = has && (k >= k_lo) && (k <= k_hi);
-    if (on) {
-      const float z = z_cur;
-      const Footprint fp = fp_cur;
-      const bool last = (k == c.S - 1);
-      float z_next = z;
-      if (!last) {
-        z_next = rc.dg.z(k + 1);
-        float pn[3];
-        rc.point(z_next, pn);
-        footprint(g, pn, fp_cur);
-        z_cur = z_next;
+      for (int a = 0; a < 3; ++a) {
+        const float s = g.scale[a] * 0.5f * (float)N[a];
+        const float d0 = readlane_f32(rc.d[a], 0), dx = readlane_f32(rc.d[a], 1) - d0, dy = readlane_f32(rc.d[a], 8) - d0;
+        ext = fmaxf(ext, 7.0f * (fabsf(dx) + fabsf(dy)) * fabsf(s) * zref);
       }
-      if (fp.inside) {
-        Cell cell;
-        make_cell(g, fp, cell);
-        float v, rad[COUT];
-        gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
-        float sigma, dpost;
-        post_activate_vg(g.post_act, v, sigma, dpost);
-        const float dl = last ? kInfinity : (z_next - z);
-        const float delta = dl * rc.dnorm;
-        const float e = fast_exp(-(sigma * delta));
-        const float alpha = 1.0f - e;
-        const float om = 1.0f - alpha;
-        const float wk = alpha * T;
-        float col[COUT], dldw = fmaf(gdep, z, gacc);
-#pragma unroll
-        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
-        if (white) dldw -= gsum;
-        prefix = fmaf(dldw, wk, prefix);
-        const float suffix = last ? 0.0f : (total - prefix);
-        const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
-        const float dsig = (delta * e) * fmaf(T, dldw, -tail);
-        // per-channel gradient of the packed texel: (d rad_c * C0 ..., d v)
-        float gch[C];
-        bool any = false;
-#pragma unroll
-        for (int ch = 0; ch < COUT; ++ch) {
-          gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
-          any = any || (gch[ch] != 0.0f);
-        }
-        gch[COUT] = WANT_D ? dsig * dpost : 0.0f;
-        any = any || (gch[COUT] != 0.0f);
-        T = T * om;
+      if (ext > 5.5f) npass = 4;
+    }
+  }
+  auto run_pass = [&](const bool alive_q, const int centre_lane) {
+    rc.dg.kc = INT_MIN;                        // fresh rolling depth window for this pass
+    const int k_lo = max(rc.k_lo, ks);          // this lane's samples inside the segment
+    int k_hi = alive_q ? min(rc.k_hi, ke) : k_lo - 1;
+    bool has = k_lo <= k_hi;
+    // state at the segment start (transmittance + partial sums of the forward), see save_state()
+    float T = 1.0f, pre_c[COUT], pre_a = 0.0f, pre_d = 0.0f;
+  #pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = 0.0f;
+    if (has && seg > 0) {
+      constexpr int NC = COUT + 3;
+      T = ray_state[ray_state_index(seg, 0, NC, c.R, r)];
+  #pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
+      pre_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
+      pre_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
+      if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
+    }
+    const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
+    const int kmax = wave_max_i32(has ? k_hi : -1);
+    if (kmin > kmax) return;  // wave-uniform: no ray of this pass meets the volume in this segment
 
-        if (any) {
-          // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
-          const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
-          float wm[2], wu[2], wv[2];
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            wm[s] = (w.m == 0) ? cell.w[0][s] : ((w.m == 1) ? cell.w[1][s] : cell.w[2][s]);
-            wu[s] = (w.u == 0) ? cell.w[0][s] : cell.w[1][s];
-            wv[s] = (w.v == 1) ? cell.w[1][s] : cell.w[2][s];
+    // ---- window geometry from a reference ray (the lane next to the tile centre, if it has samples) ----
+    Window w;
+    {
+      const unsigned long long hm = __ballot(has);
+      const int ref = ((hm >> centre_lane) & 1ull) ? centre_lane : (__ffsll((long long)hm) - 1);
+      const int N[3] = {g.X, g.Y, g.Z};
+      float U0[3], DU[3];
+  #pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
+        const float half = 0.5f * (float)N[a];
+        U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
+        DU[a] = rd * g.scale[a] * half;
+      }
+      const float ax = fabsf(DU[0]), ay = fabsf(DU[1]), az = fabsf(DU[2]);
+      w.m = (ax >= ay && ax >= az) ? 0 : ((ay >= az) ? 1 : 2);
+      w.u = (w.m == 0) ? 1 : 0;
+      w.v = (w.m == 2) ? 1 : 2;
+      const float DUm = (w.m == 0) ? DU[0] : ((w.m == 1) ? DU[1] : DU[2]);
+      const float U0m = (w.m == 0) ? U0[0] : ((w.m == 1) ? U0[1] : U0[2]);
+      const float DUu = (w.u == 0) ? DU[0] : DU[1], U0u = (w.u == 0) ? U0[0] : U0[1];
+      const float DUv = (w.v == 1) ? DU[1] : DU[2], U0v = (w.v == 1) ? U0[1] : U0[2];
+      w.sgn = (DUm < 0.0f) ? -1 : 1;
+      const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
+      w.Bu = DUu * inv; w.Au = U0u - w.Bu * U0m;
+      w.Bv = DUv * inv; w.Av = U0v - w.Bv * U0m;
+      const int sx = g.Y * g.Z, sy = g.Z;
+      w.stride_m = (w.m == 0) ? sx : ((w.m == 1) ? sy : 1);
+      w.stride_u = (w.u == 0) ? sx : sy;
+      w.stride_v = (w.v == 1) ? sy : 1;
+    }
+    // lowest layer key a sample with low-corner index pm can write (layers pm and pm + 1)
+    auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
+    auto pick = [&](const int (&t)[3], int axis) { return axis == 0 ? t[0] : (axis == 1 ? t[1] : t[2]); };
+
+    // ---- per-ray constants of the backward (see render_bwd_kernel) -------------------------------
+    float gc[COUT], gsum = 0.0f;
+  #pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
+    const float gdep = d_depth ? d_depth[r] : 0.0f;
+    const float gacc = d_acc ? d_acc[r] : 0.0f;
+    const bool white = c.white && !c.attn;
+    const float asum = acc[r];
+    float total = gdep * depth[r] + gacc * asum;
+  #pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) {
+      const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
+      total += gc[ch] * csum;
+    }
+    if (white) total -= gsum * asum;
+    // prefix = sum_{j < segment start} dL/dw_j w_j from the saved partial sums
+    float prefix = gdep * pre_d + gacc * pre_a;
+  #pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
+    if (white) prefix -= gsum * pre_a;
+
+    // first sample of every ray (rolling: z_cur / fp_cur always describe sample max(k, k_lo))
+    float z_cur = 0.0f;
+    Footprint fp_cur;
+    fp_cur.inside = false;
+  #pragma unroll
+    for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
+    int first_key = INT_MAX;
+    if (has) {
+      z_cur = rc.dg.z(k_lo);
+      float p[3];
+      rc.point(z_cur, p);
+      footprint(g, p, fp_cur);
+      first_key = minkey(pick(fp_cur.i0, w.m));
+    }
+    w.base = wave_min_i32(first_key);
+    __syncthreads();  // window zeroed
+
+    const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // per-lane corner permutation: neighbours in the tile differ
+    for (int k = kmin; k <= kmax; ++k) {
+      const bool on = has && (k >= k_lo) && (k <= k_hi);
+      if (on) {
+        const float z = z_cur;
+        const Footprint fp = fp_cur;
+        const bool last = (k == c.S - 1);
+        float z_next = z;
+        if (!last) {
+          z_next = rc.dg.z(k + 1);
+          float pn[3];
+          rc.point(z_next, pn);
+          footprint(g, pn, fp_cur);
+          z_cur = z_next;
+        }
+        if (fp.inside) {
+          Cell cell;
+          make_cell(g, fp, cell);
+          float v, rad[COUT];
+          gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
+          float sigma, dpost;
+          post_activate_vg(g.post_act, v, sigma, dpost);
+          const float dl = last ? kInfinity : (z_next - z);
+          const float delta = dl * rc.dnorm;
+          const float e = fast_exp(-(sigma * delta));
+          const float alpha = 1.0f - e;
+          const float om = 1.0f - alpha;
+          const float wk = alpha * T;
+          float col[COUT], dldw = fmaf(gdep, z, gacc);
+  #pragma unroll
+          for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
+          if (white) dldw -= gsum;
+          prefix = fmaf(dldw, wk, prefix);
+          const float suffix = last ? 0.0f : (total - prefix);
+          const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+          const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+          // per-channel gradient of the packed texel: (d rad_c * C0 ..., d v)
+          float gch[C];
+          bool any = false;
+  #pragma unroll
+          for (int ch = 0; ch < COUT; ++ch) {
+            gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
+            any = any || (gch[ch] != 0.0f);
           }
-          // per layer (cm = 0, 1): ring slot, lateral position of corner (cu, cv) = (0, 0), window test
-          int lofs[2], ab0[2];
-          bool fits = true;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int im = pm + s, key = w.sgn * im;
-            const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
-            fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
-                   ((unsigned)b0 < (unsigned)(kLat - 1));
-            lofs[s] = (key & (kRing - 1)) * kLayerSlots;
-            ab0[s] = a0 * kLat + b0 + 21 * (key & (kRing - 1));  // + the per-layer rotation of layer_pos()
-          }
-          if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
-            // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
-            // (crot): the lanes of one wave instruction then spread over 8 corners x C channel planes, so lanes that
-            // share a voxel rarely hit the same LDS address / bank in the same instruction.  With an XOR the
-            // corner bits of instruction cc are (constant bit) ^ (lane bit): every operand pair is swapped ONCE per
-            // sample ("A" = value used where the constant bit is 0, "B" where it is 1) and the unrolled loop below
-            // contains no selects at all.
-            constexpr bool kAllCh = WANT_D && WANT_F;
-            const bool r0 = rot & 1, r1 = rot & 2, r2 = rot & 4;
-            const float wmA = r0 ? wm[1] : wm[0], wmB = r0 ? wm[0] : wm[1];
-            const float wuA = r1 ? wu[1] : wu[0], wuB = r1 ? wu[0] : wu[1];
-            const float wvA = r2 ? wv[1] : wv[0], wvB = r2 ? wv[0] : wv[1];
-            const int lofA = r0 ? lofs[1] : lofs[0], lofB = r0 ? lofs[0] : lofs[1];
-            const int abA = r0 ? ab0[1] : ab0[0], abB = r0 ? ab0[0] : ab0[1];
-            const int uA = r1 ? kLat : 0, uB = kLat - uA, vA = r2 ? 1 : 0, vB = 1 - vA;
-            const float wmu[4] = {wmA * wuA, wmB * wuA, wmA * wuB, wmB * wuB};       // [cm + 2 cu]
-            const int abu[4] = {abA + uA, abB + uA, abA + uB, abB + uB};
-            float gr[C];
-            int poff[C];
-            if constexpr (kAllCh && C == 4) {
-              const int crot = lane >> 1 & 3;
-              const bool c1 = crot & 1, c2 = crot & 2;
-              // gr[j] = gch[(j + crot) & 3], poff[j] = plane offset of that channel
-              const float a0 = c1 ? gch[1] : gch[0], a1 = c1 ? gch[2] : gch[1], a2 = c1 ? gch[3] : gch[2], a3 = c1 ? gch[0] : gch[3];
-              gr[0] = c2 ? a2 : a0; gr[1] = c2 ? a3 : a1; gr[2] = c2 ? a0 : a2; gr[3] = c2 ? a1 : a3;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) poff[j] = ((j + crot) & 3) * kPlane;
-            } else {
-#pragma unroll
-              for (int j = 0; j < C; ++j) { gr[j] = gch[j]; poff[j] = j * kPlane; }
+          gch[COUT] = WANT_D ? dsig * dpost : 0.0f;
+          any = any || (gch[COUT] != 0.0f);
+          T = T * om;
+
+          if (any) {
+            // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
+            const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
+            float wm[2], wu[2], wv[2];
+  #pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              wm[s] = (w.m == 0) ? cell.w[0][s] : ((w.m == 1) ? cell.w[1][s] : cell.w[2][s]);
+              wu[s] = (w.u == 0) ? cell.w[0][s] : cell.w[1][s];
+              wv[s] = (w.v == 1) ? cell.w[1][s] : cell.w[2][s];
             }
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;  // compile-time bits of this instruction
-              const float wgt = wmu[bm + 2 * bu] * (bv ? wvB : wvA);
-              const int idx = (bm ? lofB : lofA) + ((abu[bm + 2 * bu] + (bv ? vB : vA)) & 63);
-#pragma unroll
-              for (int ch = 0; ch < C; ++ch) {
-                if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
-                  __hip_atomic_fetch_add(&win[poff[ch] + idx], (double)(gr[ch] * wgt), __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+            // per layer (cm = 0, 1): ring slot, lateral position of corner (cu, cv) = (0, 0), window test
+            int lofs[2], ab0[2];
+            bool fits = true;
+  #pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const int im = pm + s, key = w.sgn * im;
+              const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
+              fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
+                     ((unsigned)b0 < (unsigned)(kLat - 1));
+              lofs[s] = (key & (kRing - 1)) * kLayerSlots;
+              ab0[s] = a0 * kLat + b0 + 21 * (key & (kRing - 1));  // + the per-layer rotation of layer_pos()
+            }
+            if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
+              // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
+              // (crot): the lanes of one wave instruction then spread over 8 corners x C channel planes, so lanes that
+              // share a voxel rarely hit the same LDS address / bank in the same instruction.  With an XOR the
+              // corner bits of instruction cc are (constant bit) ^ (lane bit): every operand pair is swapped ONCE per
+              // sample ("A" = value used where the constant bit is 0, "B" where it is 1) and the unrolled loop below
+              // contains no selects at all.
+              constexpr bool kAllCh = WANT_D && WANT_F;
+              const bool r0 = rot & 1, r1 = rot & 2, r2 = rot & 4;
+              const float wmA = r0 ? wm[1] : wm[0], wmB = r0 ? wm[0] : wm[1];
+              const float wuA = r1 ? wu[1] : wu[0], wuB = r1 ? wu[0] : wu[1];
+              const float wvA = r2 ? wv[1] : wv[0], wvB = r2 ? wv[0] : wv[1];
+              const int lofA = r0 ? lofs[1] : lofs[0], lofB = r0 ? lofs[0] : lofs[1];
+              const int abA = r0 ? ab0[1] : ab0[0], abB = r0 ? ab0[0] : ab0[1];
+              const int uA = r1 ? kLat : 0, uB = kLat - uA, vA = r2 ? 1 : 0, vB = 1 - vA;
+              const float wmu[4] = {wmA * wuA, wmB * wuA, wmA * wuB, wmB * wuB};       // [cm + 2 cu]
+              const int abu[4] = {abA + uA, abB + uA, abA + uB, abB + uB};
+              float gr[C];
+              int poff[C];
+              if constexpr (kAllCh && C == 4) {
+                const int crot = lane >> 1 & 3;
+                const bool c1 = crot & 1, c2 = crot & 2;
+                // gr[j] = gch[(j + crot) & 3], poff[j] = plane offset of that channel
+                const float a0 = c1 ? gch[1] : gch[0], a1 = c1 ? gch[2] : gch[1], a2 = c1 ? gch[3] : gch[2], a3 = c1 ? gch[0] : gch[3];
+                gr[0] = c2 ? a2 : a0; gr[1] = c2 ? a3 : a1; gr[2] = c2 ? a0 : a2; gr[3] = c2 ? a1 : a3;
+  #pragma unroll
+                for (int j = 0; j < 4; ++j) poff[j] = ((j + crot) & 3) * kPlane;
+              } else {
+  #pragma unroll
+                for (int j = 0; j < C; ++j) { gr[j] = gch[j]; poff[j] = j * kPlane; }
               }
-            }
-          } else {  // some corner outside the window: per-corner test, global scatter for the outsiders (rare)
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
-              const float wgt = (wm[cm] * wu[cu]) * wv[cv];
-              if (wgt != 0.0f) {
-                const int im = pm + cm, iu = pu + cu, iv = pv + cv;
-                const int key = w.sgn * im;
-                const int a = iu - w.off_u(im), b = iv - w.off_v(im);
-                const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
-                                   ((unsigned)b < (unsigned)kLat);
-                if (inwin) {
-                  const int idx = (key & (kRing - 1)) * kLayerSlots + w.layer_pos(key, a * kLat + b);
-#pragma unroll
-                  for (int ch = 0; ch < C; ++ch) {
-                    if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
-                      __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_WORKGROUP);
-                  }
-                } else {
-                  const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
-#pragma unroll
-                  for (int ch = 0; ch < C; ++ch) {
-                    if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)) atomicAdd(gpacked + vox * C + ch, gch[ch] * wgt);
+  #pragma unroll
+              for (int cc = 0; cc < 8; ++cc) {
+                const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;  // compile-time bits of this instruction
+                const float wgt = wmu[bm + 2 * bu] * (bv ? wvB : wvA);
+                const int idx = (bm ? lofB : lofA) + ((abu[bm + 2 * bu] + (bv ? vB : vA)) & 63);
+  #pragma unroll
+                for (int ch = 0; ch < C; ++ch) {
+                  if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                    __hip_atomic_fetch_add(&win[poff[ch] + idx], (double)(gr[ch] * wgt), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+              }
+            } else {  // some corner outside the window: per-corner test, global scatter for the outsiders (rare)
+  #pragma unroll
+              for (int cc = 0; cc < 8; ++cc) {
+                const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
+                const float wgt = (wm[cm] * wu[cu]) * wv[cv];
+                if (wgt != 0.0f) {
+                  const int im = pm + cm, iu = pu + cu, iv = pv + cv;
+                  const int key = w.sgn * im;
+                  const int a = iu - w.off_u(im), b = iv - w.off_v(im);
+                  const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
+                                     ((unsigned)b < (unsigned)kLat);
+                  if (inwin) {
+                    const int idx = (key & (kRing - 1)) * kLayerSlots + w.layer_pos(key, a * kLat + b);
+  #pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                      if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                        __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                  } else {
+                    const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+  #pragma unroll
+                    for (int ch = 0; ch < C; ++ch) {
+                      if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)) atomicAdd(gpacked + vox * C + ch, gch[ch] * wgt);
+                    }
                   }
                 }
               }
             }
           }
+          if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k;
         }
-        if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k;
+      }
+      // ---- slide the window: flush every layer no lane can reach any more ---------------------------
+      int lb = INT_MAX;
+      if (has) {
+        if (k + 1 < k_lo) lb = first_key;
+        else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
+      }
+      const int newbase = wave_min_i32(lb);
+      if (newbase > w.base) {  // wave-uniform
+        __syncthreads();
+        const long long adv = (long long)newbase - (long long)w.base;
+        const int nflush = adv < kRing ? (int)adv : kRing;
+        for (int i = 0; i < nflush; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
+        w.base = newbase;
+        __syncthreads();
       }
     }
-    // ---- slide the window: flush every layer no lane can reach any more ---------------------------
-    int lb = INT_MAX;
-    if (has) {
-      if (k + 1 < k_lo) lb = first_key;
-      else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
+    __syncthreads();
+    if (w.base != INT_MAX) {
+      for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
     }
-    const int newbase = wave_min_i32(lb);
-    if (newbase > w.base) {  // wave-uniform
-      __syncthreads();
-      const long long adv = (long long)newbase - (long long)w.base;
-      const int nflush = adv < kRing ? (int)adv : kRing;
-      for (int i = 0; i < nflush; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
-      w.base = newbase;
+
+  };
+  if (npass == 1) {
+    run_pass(alive, 27);
+  } else {
+    for (int q = 0; q < 4; ++q) {
+      // quadrant q = pixels [4 (q & 1), +4) x [4 (q >> 1), +4); its centre-most lane is (lx0 + 2, ly0 + 2)
+      run_pass(alive && (((lane >> 2) & 1) + 2 * ((lane >> 5) & 1)) == q, 18 + 4 * (q & 1) + 32 * (q >> 1));
       __syncthreads();
     }
-  }
-  __syncthreads();
-  if (w.base != INT_MAX) {
-    for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
   }
 }
 
