@@ -55,6 +55,12 @@ def _worker(rank, world, port, results):
     full = torch.arange(H * W * 3, dtype=torch.float32).view(H, W, 3)
     img = parallel.all_gather_rows(full[lo:hi].clone(), H)
     assert torch.equal(img, full)
+    # differentiable gather: every rank evaluates the same loss on the full image, gets its band's gradient
+    band = full[lo:hi].clone().requires_grad_(True)
+    whole = parallel.gather_image_rows(band, H)
+    weight = torch.linspace(0.0, 1.0, H * W * 3).view(H, W, 3)
+    (whole * weight).sum().backward()
+    assert torch.equal(band.grad, weight[lo:hi])
     results[rank] = True
     dist.destroy_process_group()
 

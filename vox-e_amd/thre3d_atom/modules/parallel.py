@@ -75,6 +75,30 @@ class FlatGrid:
             dist.broadcast(self.param, src=src)
 
 
+class _GatherRows(torch.autograd.Function):
+    """Differentiable all-gather of row bands: forward = all_gather_rows, backward = this rank's band of the
+    incoming gradient (every rank evaluates the SAME loss on the SAME full image, so no reduction is needed)."""
+
+    @staticmethod
+    def forward(ctx, local, height, align):
+        rank, world = world_info()
+        ctx.band = shard_rows(height, rank, world, align)
+        return all_gather_rows(local.detach(), height, align)
+
+    @staticmethod
+    def backward(ctx, grad_full):
+        lo, hi = ctx.band
+        return grad_full[lo:hi].contiguous(), None, None
+
+
+def gather_image_rows(local: torch.Tensor, height: int, align: int = 8) -> torch.Tensor:
+    """[rows_r, W, C] band of this rank -> full [H, W, C] image on every rank, differentiable (see _GatherRows)."""
+    _, world = world_info()
+    if world == 1:
+        return local
+    return _GatherRows.apply(local, height, align)
+
+
 def all_gather_rows(local: torch.Tensor, height: int, align: int = 8) -> torch.Tensor:
     """Gather per-rank row bands [rows_r, W, C] (bands from shard_rows) into the full [H, W, C] image
     on every rank (used to hand the complete render to the SD UNet in ray-sharded SDS)."""

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
+from thre3d_atom.modules import parallel
 from thre3d_atom.modules.optim import VoxeAdam
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
@@ -154,6 +155,21 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
                                          t_sched_gamma=sds_t_gamma, directional=not uncoupled_mode)
 
     grid = sds_vol_mod.thre3d_repr
+    # ---- ray-sharded data parallelism (one process per GPU; no-op for a single process) ---------------------
+    # Every rank holds a replica of the grid, renders ITS band of image rows, the bands are all-gathered so that
+    # every rank runs the identical guidance step on the full image (same seeds => same timestep / noise), the
+    # gradient w.r.t. its own band flows back through the HIP backward and the grid gradient is summed with one
+    # RCCL all-reduce.  Whole-grid regularisers are identical on all ranks, hence scaled by 1 / world.
+    rank, world = parallel.world_info()
+    flat = parallel.FlatGrid(grid) if world > 1 else None
+    if flat is not None:
+        flat.broadcast_param(0)
+        # identical random poses / diffusion timesteps / noise on every rank: share rank 0's seed
+        seed = torch.tensor([int(torch.initial_seed() % (2 ** 31))], dtype=torch.int64, device=device)
+        torch.distributed.broadcast(seed, src=0)
+        torch.manual_seed(int(seed.item()))
+        np.random.seed(int(seed.item()))
+    row_lo, row_hi = parallel.shard_rows(im_h, rank, world)
     optimizer = VoxeAdam([{"params": grid.parameters(), "lr": learning_rate}], betas=(0.9, 0.999))
     lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_gamma)
     extra_info = {CAMERA_BOUNDS: camera_bounds, CAMERA_INTRINSICS: camera_intrinsics, HEMISPHERICAL_RADIUS: extra_radius}
@@ -175,29 +191,46 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
             else:
                 pose, direction, _, _ = get_random_pose(hemispherical_radius)
                 direction_batch = [direction]
-            rays_batch = flatten_rays(cast_rays(intr, pose, device=device))
+            full_rays = cast_rays(intr, pose, device=device)
+            if world > 1:  # this rank's band of rows (a smaller image-ordered ray batch)
+                from thre3d_atom.rendering.volumetric.render_interface import Rays
+
+                band = Rays(full_rays.origins[row_lo:row_hi], full_rays.directions[row_lo:row_hi],
+                            image_shape=(row_hi - row_lo, im_w))
+                rays_batch = flatten_rays(band)
+            else:
+                rays_batch = flatten_rays(full_rays)
 
         rendered = sds_vol_mod.render_rays(rays_batch)
+        colour = rendered.colour
+        if world > 1:
+            colour = parallel.gather_image_rows(colour.reshape(row_hi - row_lo, im_w, -1), im_h).reshape(im_h * im_w, -1)
+        reg_scale = 1.0 / world
         total_loss = 0
         if do_sds:
-            total_loss = total_loss + guidance.training_step(rendered.colour, im_h, im_w, directions=direction_batch,
+            total_loss = total_loss + guidance.training_step(colour, im_h, im_w, directions=direction_batch,
                                                              global_step=global_step)
         if uncoupled_mode:
             fit = torch.nn.functional.mse_loss if uncoupled_l2_mode else torch.nn.functional.l1_loss
-            total_loss = total_loss + fit(rendered.colour, pixels_batch) * density_correlation_weight
+            total_loss = total_loss + fit(colour, pixels_batch) * density_correlation_weight
         else:
             dcl, _ = density_correlation_loss_fn(grid.densities, regular_density, l2_mode=l2_mode, l1_mode=l1_mode)
-            total_loss = total_loss + dcl * density_correlation_weight
+            total_loss = total_loss + dcl * (density_correlation_weight * reg_scale)
         if feature_correlation_weight > 0.0:
-            total_loss = total_loss + _feature_correlation_loss(grid.features, regular_features) * feature_correlation_weight
+            total_loss = total_loss + _feature_correlation_loss(grid.features, regular_features) * (feature_correlation_weight * reg_scale)
         if tv_density_weight > 0:
-            total_loss = total_loss + _tv_loss_on_grid(torch.relu(grid.densities)) * tv_density_weight
+            total_loss = total_loss + _tv_loss_on_grid(torch.relu(grid.densities)) * (tv_density_weight * reg_scale)
         if tv_features_weight > 0:
-            total_loss = total_loss + _tv_loss_on_grid(grid.features) * tv_features_weight
+            total_loss = total_loss + _tv_loss_on_grid(grid.features) * (tv_features_weight * reg_scale)
 
+        if flat is not None:
+            flat.zero_grad()
         total_loss.backward()
+        if flat is not None:
+            flat.all_reduce_grad()      # sum of the per-band render gradients (+ world x regulariser / world)
         optimizer.step()
-        optimizer.zero_grad()
+        if flat is None:
+            optimizer.zero_grad()
         trained_time += time.perf_counter() - last
 
         if global_step % summary_freq == 0 or global_step in (1, num_iterations):
@@ -205,6 +238,9 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
         if global_step % lr_freq == 0 and global_step >= lr_decay_start:
             lr_scheduler.step()
             log.info(f"Adjusted learning rate | learning rates: {[g['lr'] for g in optimizer.param_groups]}")
+        if rank != 0:
+            last = time.perf_counter()
+            continue
         if global_step % feedback_freq == 0 or global_step in (1, num_iterations):
             log.info(f"TIME CHECK: time spent actually training till now: {timedelta(seconds=trained_time)}")
             _write_feedback(sds_vol_mod, render_feedback_pose or pose, intr, render_dir / f"sds_{global_step}.png")
@@ -212,7 +248,8 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
             torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / f"model_iter_{global_step}.pth")
         last = time.perf_counter()
 
-    torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / "model_final.pth")
+    if rank == 0:
+        torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / "model_final.pth")
     log.info("Training complete")
     return sds_vol_mod
 
