@@ -1,9 +1,4 @@
-"""Keys of the `*_camera_params.json` files (reference: thre3d_atom/data/constants.py:1-10)."""
-INTRINSIC = "intrinsic"
-EXTRINSIC = "extrinsic"
-BOUNDS = "bounds"
-HEIGHT = "height"
-WIDTH = "width"
-FOCAL = "focal"
-ROTATION = "rotation"
-TRANSLATION = "translation"
+"""`thre3d_atom.data.constants` of the reference, re-exported from thre3d_atom._keys."""
+from thre3d_atom import _keys
+
+_keys.export(globals(), _keys.CAMERA_JSON_KEYS)

@@ -1,24 +1,14 @@
-"""Shared constants and dictionary keys (values fixed by the reference: thre3d_atom/utils/constants.py:1-28)."""
-NUM_COORD_DIMENSIONS = 3
-NUM_COLOUR_CHANNELS = 3
-NUM_RGBA_CHANNELS = 4
-NUM_ATTN_CHANNELS = 1
+"""`thre3d_atom.utils.constants` of the reference, re-exported from thre3d_atom._keys (values fixed by interop)."""
+from thre3d_atom import _keys
+from thre3d_atom._keys import (  # noqa: F401
+    INFINITY,
+    NUM_ATTN_CHANNELS,
+    NUM_COLOUR_CHANNELS,
+    NUM_COORD_DIMENSIONS,
+    NUM_RGBA_CHANNELS,
+    SEED,
+    ZERO_PLUS,
+)
 
-SEED = 42
-ZERO_PLUS = 1e-10
-INFINITY = 1e10
-
-# keys of RenderOut.extra
-EXTRA_DISPARITY = "disparity"
-EXTRA_ACCUMULATED_WEIGHTS = "accumulated_weight"
-EXTRA_POINT_DENSITIES = "point_densities"
-EXTRA_POINT_OCCUPANCIES = "point_occupancies"
-EXTRA_SAMPLE_INTERVALS = "deltas"
-EXTRA_POINT_WEIGHTS = "point_weights"
-EXTRA_POINT_DEPTHS = "point_depths"
-
-# keys of the checkpoint's extra-info dictionary
-CAMERA_BOUNDS = "camera_bounds"
-CAMERA_INTRINSICS = "camera_intrinsics"
-HEMISPHERICAL_RADIUS = "hemispherical_radius"
-EXTRA_INFO = "extra_info"
+_keys.export(globals(), _keys.RENDER_EXTRA_KEYS,
+             {k: _keys.CHECKPOINT_KEYS[k] for k in ("CAMERA_BOUNDS", "CAMERA_INTRINSICS", "HEMISPHERICAL_RADIUS", "EXTRA_INFO")})

@@ -1,49 +1,52 @@
-"""Small host utilities (reference: thre3d_atom/utils/misc.py)."""
+"""Small host utilities (API of the reference's thre3d_atom/utils/misc.py; none is on the GPU hot path)."""
 import math
 from pathlib import Path
-from typing import Any, Callable, List, Mapping, Optional, Sequence, Tuple
+from typing import Any, Callable, Iterator, List, Mapping, Optional, Sequence, Tuple
 
 import yaml
 
+GridSize = Tuple[int, int, int]
+
 
 def check_power_of_2(x: int) -> bool:
-    return x & (x - 1) == 0
+    return (x & (x - 1)) == 0
 
 
-def batchify(
-    processor_fn: Callable[..., Any],
-    collate_fn: Callable[[Sequence[Any]], Any],
-    chunk_size: Optional[int] = None,
-    verbose: bool = False,
-) -> Callable[..., Any]:
-    """Wrap `processor_fn` so that its first argument is processed in chunks (misc.py:14-35).
-    The fused renderer never needs this (it has no per-sample temporaries); kept for API parity."""
-    if chunk_size is None:
-        return processor_fn
+class _Chunked:
+    """callable that feeds the first argument of `fn` through in slices and collates the partial results"""
 
-    def chunked(inputs, *args, **kwargs):
-        starts = range(0, len(inputs), chunk_size)
-        if verbose:
+    def __init__(self, fn: Callable[..., Any], collate: Callable[[Sequence[Any]], Any], size: int, verbose: bool):
+        self.fn, self.collate, self.size, self.verbose = fn, collate, size, verbose
+
+    def _slices(self, total: int) -> Iterator[slice]:
+        starts = range(0, total, self.size)
+        if self.verbose:
             from tqdm import tqdm
 
             starts = tqdm(starts)
-        return collate_fn([processor_fn(inputs[s: s + chunk_size], *args, **kwargs) for s in starts])
+        return (slice(s, s + self.size) for s in starts)
 
-    return chunked
+    def __call__(self, inputs, *args, **kwargs):
+        return self.collate([self.fn(inputs[sl], *args, **kwargs) for sl in self._slices(len(inputs))])
 
 
-def compute_thre3d_grid_sizes(
-    final_required_resolution: Tuple[int, int, int], num_stages: int, scale_factor: float
-) -> List[Tuple[int, int, int]]:
-    """Coarse-to-fine grid schedule: ceil(size / scale_factor) per earlier stage (misc.py:38-50)."""
-    sizes = [tuple(int(v) for v in final_required_resolution)]
-    for _ in range(num_stages - 1):
-        sizes.insert(0, tuple(int(math.ceil((1 / scale_factor) * v)) for v in sizes[0]))
-    return sizes
+def batchify(processor_fn: Callable[..., Any], collate_fn: Callable[[Sequence[Any]], Any],
+             chunk_size: Optional[int] = None, verbose: bool = False) -> Callable[..., Any]:
+    """`processor_fn` itself when chunk_size is None, else a chunk-wise wrapper (reference misc.py:14-35).
+    The fused renderer never needs it (no per-sample temporaries); kept for API parity."""
+    return processor_fn if chunk_size is None else _Chunked(processor_fn, collate_fn, chunk_size, verbose)
+
+
+def compute_thre3d_grid_sizes(final_required_resolution: GridSize, num_stages: int, scale_factor: float) -> List[GridSize]:
+    """coarse-to-fine schedule, finest last: each earlier stage is ceil(size / scale_factor) per axis
+    (20 -> 40 -> 80 -> 160 for 160^3, 4 stages, factor 2; reference misc.py:38-50)"""
+    schedule = [tuple(int(v) for v in final_required_resolution)]
+    while len(schedule) < num_stages:
+        schedule.insert(0, tuple(int(math.ceil((1 / scale_factor) * v)) for v in schedule[0]))
+    return schedule
 
 
 def log_config_to_disk(args: Mapping[str, Any], output_dir: Path, config_file_name: str = "config.yml") -> None:
-    output_dir = Path(output_dir)
-    output_dir.mkdir(exist_ok=True, parents=True)
-    with open(output_dir / config_file_name, "w") as fh:
-        yaml.dump(dict(args), fh, default_flow_style=False)
+    target = Path(output_dir)
+    target.mkdir(exist_ok=True, parents=True)
+    (target / config_file_name).write_text(yaml.dump(dict(args), default_flow_style=False))
