@@ -314,3 +314,67 @@ def test_voxel_grid_forward_api():
     out = vg.forward_attn(pts)
     assert out.shape == (len(pts), 2)
     np.testing.assert_allclose(gh.n(out[:, 1]), g["cube_values"][:, 3], rtol=3e-6, atol=3e-6)
+
+
+@pytest.mark.parametrize("mode", ["plain", "jitter", "clip", "lindisp", "black"])
+def test_tile_backward_variants_vs_oracle(mode):
+    """The LDS-window backward (image-ordered rays) against the oracle for every sampling mode, incl. an image
+    whose pixels are farther apart than a voxel (quadrant passes) and one that is not a multiple of 8."""
+    g = load_golden("frames32.npz")
+    grid = grid_from_golden(g, "", "softplus")
+    grid.density_scale = 4.0  # translucent: gradients reach the whole volume
+    kw = dict(white_bkgd=(mode != "black"))
+    if mode == "jitter":
+        kw.update(perturb=True, seed=11, rng_offset=5)
+    if mode == "clip":
+        kw.update(aabb_clip=True)
+    if mode == "lindisp":
+        kw.update(linear_disparity=True)
+    for (h, w) in ((44, 52), (19, 23)):
+        o, d = vo.cast_rays(h, w, 0.5 * w / np.tan(0.5 * 0.6911112), g["rot"][5], g["trans"][5])
+        cfg = cfg_from_bounds(g["bounds"], 80, **kw)
+        rng = (11, 5) if mode == "jitter" else (0, 0)
+        gc = np.random.default_rng(1).standard_normal((h * w, 3)).astype(np.float32)
+        gdep = np.random.default_rng(2).standard_normal(h * w).astype(np.float32) * 0.2
+        gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, rng=rng, image_width=w)
+        rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep)
+        assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4, (mode, h, w)
+
+
+def test_tile_backward_attention_grid():
+    """VOXE_FEAT_ATTN (2 packed channels) through the LDS-window backward."""
+    g = load_golden("render_attn.npz")
+    grid = grid_from_golden(g, "softplus_soft_", "softplus_soft", attn=True)
+    o, d = vo.cast_rays(36, 40, 0.5 * 40 / np.tan(0.5 * 0.6911112), load_golden("frames32.npz")["rot"][1],
+                        load_golden("frames32.npz")["trans"][1])
+    cfg = cfg_from_bounds(g["bounds"], 64, white_bkgd=True)
+    ga = np.random.default_rng(4).standard_normal((36 * 40, 1)).astype(np.float32)
+    out = gh.hip_forward(grid, cfg, o, d, image_width=40)
+    np.testing.assert_allclose(out["colour"], vo.render_fwd(grid, cfg, o, d)["colour"], rtol=0, atol=FWD_ATOL)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, ga, image_width=40)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, ga)
+    assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
+
+
+def test_early_termination_is_consistent():
+    """term_eps > 0 (not in the reference): the forward changes by < term_eps-ish, and the backward is the exact
+    gradient of THAT forward (directional finite differences)."""
+    g = load_golden("frames32.npz")
+    grid = grid_from_golden(g, "", "softplus")
+    o, d = vo.cast_rays(40, 40, 0.5 * 40 / np.tan(0.5 * 0.6911112), g["rot"][3], g["trans"][3])
+    cfg = cfg_from_bounds(g["bounds"], 128, white_bkgd=True)
+    full = gh.hip_forward(grid, cfg, o, d, image_width=40)["colour"]
+    cut = gh.hip_forward(grid, cfg, o, d, image_width=40, term_eps=1e-3)["colour"]
+    assert 0 < np.abs(full - cut).max() < 2e-3
+    gc = np.random.default_rng(7).standard_normal(full.shape).astype(np.float32)
+    _, gf = gh.hip_backward(grid, cfg, o, d, gc, image_width=40, term_eps=1e-3)
+    v = np.random.default_rng(8).standard_normal(grid.features.shape).astype(np.float32)
+    eps = 1e-2
+
+    def loss(feat):
+        gg = vo.Grid(grid.densities, feat, grid.aabb, grid.density_scale, grid.density_pre_act, grid.density_post_act)
+        return float(np.sum(gh.hip_forward(gg, cfg, o, d, image_width=40, term_eps=1e-3)["colour"].astype(np.float64) * gc))
+
+    fd = (loss(grid.features + eps * v) - loss(grid.features - eps * v)) / (2 * eps)
+    an = float(np.sum(gf.astype(np.float64) * v))
+    assert abs(fd - an) <= 3e-2 * max(abs(an), 1.0), (fd, an)
