@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=200, help="side of the image the CPU oracle is timed on")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--no-jitter", action="store_true")
+    ap.add_argument("--ray-order", choices=["image", "linear", "random"], default="image",
+                    help="image: row-major image rays with the width hint (LDS-window backward); linear: same rays without the "
+                         "hint; random: the rays in a random permutation (what a random-ray training batch looks like)")
     ap.add_argument("--camera", type=int, default=3, help="index of the synthetic camera (of 100) rendered by rank 0")
     return ap.parse_args()
 
@@ -94,8 +97,12 @@ def main():
     pose = pose_spherical(yaw, pitch, RADIUS)
     rays_o, rays_d = ops.cast_rays(HW, HW, focal_for(HW), pose.rotation, pose.translation, dev)
     R = rays_o.shape[0]
+    if args.ray_order == "random":
+        perm = torch.randperm(R, generator=torch.Generator().manual_seed(7)).to(dev)
+        rays_o, rays_d = rays_o[perm].contiguous(), rays_d[perm].contiguous()
+    hint = HW if args.ray_order == "image" else 0
     params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=not args.no_jitter, white_bkgd=True,
-                              term_eps=args.term_eps, image_width=HW)
+                              term_eps=args.term_eps, image_width=hint)
     gen = torch.Generator().manual_seed(43 + rank)
     g_colour = torch.randn((R, 3), generator=gen).to(dev)
     colour = torch.empty((R, 3), dtype=torch.float32, device=dev)
@@ -105,7 +112,7 @@ def main():
     ws = ops.Workspace()
 
     # in-AABB sample count of this camera (un-jittered depths), outside the timed region
-    probe_params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=HW)
+    probe_params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=hint)
     inside = ops.sample_probe(spec, probe_params, dens, feat, rays_o, rays_d, outputs=("inside",))["inside"]
     s_in_total = int(inside.sum().item())
     del inside
@@ -158,7 +165,8 @@ def main():
     bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
     bytes_bwd = s_in_total * 256 + R * (24 + 12 + 20)
     if ms_bwd >= ms_fwd:
-        kname, kbytes, kms = "render_bwd_tile_kernel<3,true,true>", bytes_bwd, ms_bwd
+        bwd_name = "render_bwd_tile_kernel<3,true,true>" if args.ray_order == "image" else "render_bwd_packed_scatter_kernel<3,true,true>"
+        kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
         kname, kbytes, kms = "render_fwd_kernel<3,1,1>", bytes_fwd, ms_fwd
     achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
@@ -167,7 +175,7 @@ def main():
     # as profiles/*_pmc_summary.json.  Only reported for the configuration they were measured on.
     traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera) == (160, 400, 256, "random", 0.0, False, 3)
+    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, args.ray_order) == (160, 400, 256, "random", 0.0, False, 3, "image")
     if default_cfg and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))["kernels"]
         key = "voxe::render_bwd_tile_kernel<3, true, true>" if ms_bwd >= ms_fwd else "voxe::render_fwd_kernel<3, 1, 1>"
@@ -216,7 +224,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{G}^3 SH-0 softplus ReLU-field grid ({args.scene}), one {HW}x{HW} camera per GPU, "
-                            f"S={S}, jitter {'off' if args.no_jitter else 'on'}, white bkgd; step = render fwd + bwd"
+                            f"S={S}, jitter {'off' if args.no_jitter else 'on'}, white bkgd, ray order {args.ray_order}; step = render fwd + bwd"
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
                             f"{'' if args.no_adam else ' + Adam'}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,

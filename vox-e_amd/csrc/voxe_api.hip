@@ -276,6 +276,8 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     PhaseTimer t(PH_BWD, s);
     if (tiled)
       launch_bwd_tile(dg, dc, a, s);
+    else if (packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd())
+      launch_bwd_packed_scatter(dg, dc, a, s);
     else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
   }

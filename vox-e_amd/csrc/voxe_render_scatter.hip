@@ -1,0 +1,175 @@
+// voxe_render_scatter.hip -- backward render kernel for rays in ARBITRARY order (random ray batches of the
+// reconstruction trainer, ray lists without image structure): line-dense global atomics.
+//
+// Unordered rays share no voxels inside a wave, so there is nothing to combine on chip (the LDS-window kernel
+// does not apply); the scatter is bound by the ~20 G atomic cache-line REQUESTS/s of the memory side
+// (profiles/r01_microbench_atomics.md), and one request can carry up to 16 dwords.  render_bwd_kernel issues
+// one request per (corner, channel, lane).  Here every wave stages its 64 samples' footprints in LDS and
+// re-reads them transposed, so that the lanes of one atomic instruction are
+//     (sample s, z-corner cz, channel ch)      ->  8 samples x [2 z-neighbours x 4 channels = 32 contiguous bytes]
+// i.e. one request per (sample, x/y corner) instead of eight: ~8x fewer requests for the same adds.
+// Per-ray math: identical to render_bwd_kernel / render_bwd_tile_kernel.
+#include <limits.h>
+
+#include "voxe_device.hpp"
+#include "voxe_launch.hpp"
+#include "voxe_render_common.hpp"
+
+namespace voxe {
+
+template <int COUT, bool WANT_D, bool WANT_F>
+__global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
+    DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ jitter,
+    const float* __restrict__ colour, const float* __restrict__ depth,
+    const float* __restrict__ acc, const float* __restrict__ d_colour,
+    const float* __restrict__ d_depth, const float* __restrict__ d_acc,
+    float* __restrict__ gpacked) {
+  constexpr int C = COUT + 1;
+  constexpr int kLanesPerSample = 2 * C;                 // (z corner, channel)
+  constexpr int kSamplesPerInstr = 64 / kLanesPerSample;  // 8 (C = 4) or 16 (C = 2)
+  __shared__ int s_base[64];
+  __shared__ float s_w[8][64];
+  __shared__ float s_g[C][64];
+  const int lane = threadIdx.x;
+
+  const int nt = (int)((c.R + 63) / 64);
+  const int logical = logical_tile(c, 1, nt);
+  if (logical < 0) return;
+  const long long r0 = (long long)logical * 64 + lane;
+  const bool alive = r0 < c.R;
+  const long long r = alive ? r0 : 0;
+
+  RayCtx<COUT, 1, 1> rc;
+  rc.init(g, c, r, rays_o, rays_d, jitter);
+  const int k_lo = rc.k_lo;
+  int k_hi = alive ? rc.k_hi : k_lo - 1;
+  const bool has = k_lo <= k_hi;
+
+  float gc[COUT], gsum = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
+  const float gdep = d_depth ? d_depth[r] : 0.0f;
+  const float gacc = d_acc ? d_acc[r] : 0.0f;
+  const bool white = c.white && !c.attn;
+  const float asum = acc[r];
+  float total = gdep * depth[r] + gacc * asum;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) {
+    const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
+    total += gc[ch] * csum;
+  }
+  if (white) total -= gsum * asum;
+
+  // every lane walks ITS OWN sample range: iteration i handles sample k_lo + i of the lane
+  int trips = has ? (k_hi - k_lo + 1) : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off, 64));
+
+  const int sx = g.X > 1 ? g.Y * g.Z : 0, sy = g.Y > 1 ? g.Z : 0, sz = g.Z > 1 ? 1 : 0;
+  float prefix = 0.0f, T = 1.0f;
+  float z_next = has ? rc.dg.z(k_lo) : 0.0f;
+  for (int i = 0; i < trips; ++i) {
+    const int k = k_lo + i;
+    int base = -1;
+    float wc[8], gch[C];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wc[j] = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) gch[ch] = 0.0f;
+    if (has && k <= k_hi) {
+      const float z = z_next;
+      const bool last = (k == c.S - 1);
+      if (!last) z_next = rc.dg.z(k + 1);
+      float p[3];
+      rc.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      if (fp.inside) {
+        Cell cell;
+        make_cell(g, fp, cell);
+        float v, rad[COUT];
+        gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
+        float sigma, dpost;
+        post_activate_vg(g.post_act, v, sigma, dpost);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float wk = alpha * T;
+        float col[COUT], dldw = fmaf(gdep, z, gacc);
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
+        if (white) dldw -= gsum;
+        prefix = fmaf(dldw, wk, prefix);
+        const float suffix = last ? 0.0f : (total - prefix);
+        const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+        const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+        bool any = false;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) {
+          gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
+          any = any || (gch[ch] != 0.0f);
+        }
+        gch[COUT] = WANT_D ? dsig * dpost : 0.0f;
+        any = any || (gch[COUT] != 0.0f);
+        T = T * om;
+        if (any) {
+          base = cell_addr(g, cell).base;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wc[j] = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
+        }
+        if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k;
+      }
+    }
+    if (__ballot(base >= 0) == 0ull) continue;  // wave-uniform: nothing to deposit this iteration
+    // ---- stage the 64 footprints, then deposit them transposed ------------------------------------
+    __syncthreads();
+    s_base[lane] = base;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_w[j][lane] = wc[j];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) s_g[ch][lane] = gch[ch];
+    __syncthreads();
+    const int cz = (lane / C) & 1, ch = lane % C;
+#pragma unroll
+    for (int grp = 0; grp < 64 / kSamplesPerInstr; ++grp) {
+      const int s = grp * kSamplesPerInstr + lane / kLanesPerSample;
+      const int b = s_base[s];
+      if (b >= 0) {
+        const float gv = s_g[ch][s];
+        if (gv != 0.0f) {
+#pragma unroll
+          for (int cxy = 0; cxy < 4; ++cxy) {
+            const float w = s_w[cxy + 4 * cz][s];
+            if (w != 0.0f)
+              atomicAdd(gpacked + (long long)(b + (cxy & 1) * sx + (cxy >> 1) * sy + cz * sz) * C + ch, gv * w);
+          }
+        }
+      }
+    }
+  }
+}
+
+bool packed_scatter_supported(int deg) { return deg == 0; }
+
+void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
+  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64);
+#define VOXE_PBWD(COUT, WD, WF)                                                                     \
+  render_bwd_packed_scatter_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                \
+      g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, \
+      a.d_acc, a.gpacked)
+  if (c.attn) {
+    if (a.want_d && a.want_f) VOXE_PBWD(1, true, true);
+    else if (a.want_d) VOXE_PBWD(1, true, false);
+    else VOXE_PBWD(1, false, true);
+  } else {
+    if (a.want_d && a.want_f) VOXE_PBWD(3, true, true);
+    else if (a.want_d) VOXE_PBWD(3, true, false);
+    else VOXE_PBWD(3, false, true);
+  }
+#undef VOXE_PBWD
+}
+
+}  // namespace voxe
