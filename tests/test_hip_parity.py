@@ -378,3 +378,27 @@ def test_early_termination_is_consistent():
     fd = (loss(grid.features + eps * v) - loss(grid.features - eps * v)) / (2 * eps)
     an = float(np.sum(gf.astype(np.float64) * v))
     assert abs(fd - an) <= 3e-2 * max(abs(an), 1.0), (fd, an)
+
+
+@pytest.mark.parametrize("dims", [(2, 2, 2), (1, 4, 3), (3, 1, 1), (1, 1, 1), (2, 9, 5)])
+def test_tiny_and_degenerate_grids(dims):
+    """Axes of size 1 / 2 exercise the zero-padding fold of make_cell (shifted corners, zero strides)."""
+    rng = np.random.default_rng(sum(dims))
+    aabb = [(-0.5 * n * 0.4, 0.5 * n * 0.4) for n in dims]
+    grid = vo.Grid(rng.uniform(-1, 1, (*dims, 1)), rng.uniform(-1, 1, (*dims, 3)), aabb, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    o = rng.uniform(-0.3, 0.3, (300, 3)).astype(np.float32) + np.array([0.0, 0.0, 2.5], np.float32)
+    d = np.array([0.0, 0.0, -1.0], np.float32) + rng.uniform(-0.35, 0.35, (300, 3)).astype(np.float32)
+    cfg = make_render_cfg(48, 0.5, 4.5, white_bkgd=True)
+    pr, po = gh.hip_probe(grid, cfg, o, d), vo.sample_probe(grid, cfg, o, d)
+    np.testing.assert_array_equal(pr["idx"], po["idx"])
+    np.testing.assert_array_equal(pr["inside"], po["inside"])
+    assert po["inside"].sum() > 50
+    out, ref = gh.hip_forward(grid, cfg, o, d), vo.render_fwd(grid, cfg, o, d)
+    np.testing.assert_allclose(out["colour"], ref["colour"], rtol=0, atol=FWD_ATOL)
+    gc = rng.standard_normal((300, 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
+    gd, gf = gh.hip_backward(grid, cfg, o[:256], d[:256], gc[:256], image_width=16)  # LDS-window kernel on the same rays
+    rd, rf = vo.render_bwd(grid, cfg, o[:256], d[:256], gc[:256])
+    assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
