@@ -63,14 +63,11 @@ __host__ __device__ inline float jitter_uniform(uint32_t base, int k) {
 // for VALUES (alpha, softplus, sigmoid); the voxel-index arithmetic never goes through them.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-// exp(x) = 2^(x log2 e) with the product carried in two floats (keeps ~1-2 ulp for |x| up to ~100)
-__device__ __forceinline__ float fast_exp(float x) {
-  constexpr float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f, kLn2 = 0.693147182464599609375f;
-  const float t = x * kL2eHi;
-  const float r = fmaf(x, kL2eLo, fmaf(x, kL2eHi, -t));
-  const float e0 = __builtin_amdgcn_exp2f(t);
-  return fmaf(e0, r * kLn2, e0);
-}
+// exp(x) = 2^(x log2 e): one multiply + v_exp_f32.  The rounding of the product costs a relative error of
+// |x| * 6e-8 in the result, i.e. <= 1e-6 for |x| <= 16 (beyond that exp(-|x|) < 1e-7 and only its order of
+// magnitude matters to alpha / sigmoid / softplus).  A compensated two-float product was measured to buy no
+// accuracy that survives the float32 compositing and costs 4 more instructions per call on an issue-bound kernel.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 // log1p(t) for t in [0, 1]
 __device__ __forceinline__ float fast_log1p01(float t) {
   constexpr float kLn2 = 0.693147182464599609375f;
@@ -294,6 +291,21 @@ __device__ __forceinline__ void make_cell(const DevGrid& g, const Footprint& f, 
     c.i[a] = lo ? 0 : (hi ? max(N[a] - 2, 0) : i0);
     c.w[a][0] = lo ? ((i0 == -1) ? w1 : 0.0f) : (hi ? (wide ? 0.0f : w0_at_top) : w0);
     c.w[a][1] = lo ? 0.0f : (hi ? (wide ? w0_at_top : 0.0f) : w1);
+  }
+}
+
+// Interior test: the low corner and the +1 corner are in range on every axis (no zero padding involved).
+__device__ __forceinline__ bool cell_is_interior(const DevGrid& g, const Footprint& f) {
+  return ((unsigned)f.i0[0] < (unsigned)(g.X - 1)) && ((unsigned)f.i0[1] < (unsigned)(g.Y - 1)) &&
+         ((unsigned)f.i0[2] < (unsigned)(g.Z - 1));
+}
+// make_cell with a wave-uniform shortcut: away from the faces (almost every sample) the footprint IS the cell.
+__device__ __forceinline__ void make_cell_fast(const DevGrid& g, const Footprint& f, Cell& c) {
+  if (__builtin_amdgcn_ballot_w64(!cell_is_interior(g, f)) == 0ull) {  // all active lanes interior
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { c.i[a] = f.i0[a]; c.w[a][0] = f.w[a][0]; c.w[a][1] = f.w[a][1]; }
+  } else {
+    make_cell(g, f, c);
   }
 }
 

@@ -10,6 +10,8 @@
 // corner is ONE aligned 16-byte load for SH-0 (float4) / 8-byte load for the attention grid, and
 // the two z-neighbours of a corner pair are contiguous (32 B).  Gradients are accumulated in the
 // same packed layout and split back (with the pre-activation chain rule) by unpack_grad_kernel.
+#include <stdlib.h>
+
 #include "voxe_device.hpp"
 #include "voxe_launch.hpp"
 #include "voxe_render_common.hpp"
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
       footprint(g, p, fp);
       if (!fp.inside) continue;  // sigma = 0 -> alpha = 0 -> w = 0, T unchanged (process.py:83)
       Cell cell;
-      make_cell(g, fp, cell);
+      make_cell_fast(g, fp, cell);
       float v, rad[COUT];
       gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
       const float sigma = post_activate(g.post_act, v);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
 // segbuf layout: [segment][component][ray], components (Tseg, csum[COUT], asum, dsum).
 // ------------------------------------------------------------------------------------------------
 template <int COUT, int NCM, int NCU>
-__global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c,
+__global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c, int fseg,
                                                              const float* __restrict__ packed,
                                                              const float* __restrict__ rays_o,
                                                              const float* __restrict__ rays_d,
@@ -186,54 +188,62 @@ __global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c
                                                              float* __restrict__ segbuf) {
   constexpr int NC = COUT + 3;
   const int nseg = num_segments(c.S);
-  // blocks: segment-major within a tile (consecutive blocks = the segments of one tile)
-  const int seg = blockIdx.x % nseg;
+  // one thread = `fseg` consecutive depth segments of one ray (fseg = 1: finest split, used for small images)
+  const int ncoarse = (nseg + fseg - 1) / fseg;
+  // consecutive blocks = the coarse segments of one ray block, skewed by the ray-block index: hardware places
+  // block b on XCD b % 8, and an un-skewed map would give XCD j segment j of EVERY tile -- the first and last
+  // segments lie mostly outside the AABB, so those XCDs would idle while the middle ones do all the work.
+  const int cseg = (blockIdx.x + blockIdx.x / ncoarse) % ncoarse;
   long long r;
-  if (!map_ray_block(c, blockIdx.x / nseg, gridDim.x / nseg, r)) return;
+  if (!map_ray_block(c, blockIdx.x / ncoarse, gridDim.x / ncoarse, r)) return;
   RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
-  const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;
-  const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
-
-  float csum[COUT];
+  const int s_end = min(nseg, (cseg + 1) * fseg);
+  float z_next = 0.0f;
+  int z_for = -1;  // sample index z_next belongs to
+  for (int seg = cseg * fseg; seg < s_end; ++seg) {
+    const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;
+    const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
+    float csum[COUT];
 #pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
-  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
-  if (k_lo <= k_hi) {
-    float z_next = rc.dg.z(k_lo);
-    for (int k = k_lo; k <= k_hi; ++k) {
-      const float z = z_next;
-      const bool last = (k == c.S - 1);
-      if (!last) z_next = rc.dg.z(k + 1);
-      float p[3];
-      rc.point(z, p);
-      Footprint fp;
-      footprint(g, p, fp);
-      if (!fp.inside) continue;
-      Cell cell;
-      make_cell(g, fp, cell);
-      float v, rad[COUT];
-      gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
-      const float sigma = post_activate(g.post_act, v);
-      const float dl = last ? kInfinity : (z_next - z);
-      const float delta = dl * rc.dnorm;
-      const float e = fast_exp(-(sigma * delta));
-      const float alpha = 1.0f - e;
-      const float om = 1.0f - alpha;
-      const float w = alpha * T;
-      T = T * om;
+    for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
+    float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+    if (k_lo <= k_hi) {
+      if (z_for != k_lo) z_next = rc.dg.z(k_lo);
+      for (int k = k_lo; k <= k_hi; ++k) {
+        const float z = z_next;
+        const bool last = (k == c.S - 1);
+        if (!last) { z_next = rc.dg.z(k + 1); z_for = k + 1; }
+        float p[3];
+        rc.point(z, p);
+        Footprint fp;
+        footprint(g, p, fp);
+        if (!fp.inside) continue;
+        Cell cell;
+        make_cell_fast(g, fp, cell);
+        float v, rad[COUT];
+        gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
+        const float sigma = post_activate(g.post_act, v);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float w = alpha * T;
+        T = T * om;
 #pragma unroll
-      for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), w, csum[ch]);
-      asum = asum + w;
-      dsum = fmaf(z, w, dsum);
+        for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), w, csum[ch]);
+        asum = asum + w;
+        dsum = fmaf(z, w, dsum);
+      }
     }
-  }
-  const long long base = (long long)seg * NC;
-  segbuf[(base + 0) * c.R + r] = T;
+    const long long base = (long long)seg * NC;
+    segbuf[(base + 0) * c.R + r] = T;
 #pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) segbuf[(base + 1 + ch) * c.R + r] = csum[ch];
-  segbuf[(base + 1 + COUT) * c.R + r] = asum;
-  segbuf[(base + 2 + COUT) * c.R + r] = dsum;
+    for (int ch = 0; ch < COUT; ++ch) segbuf[(base + 1 + ch) * c.R + r] = csum[ch];
+    segbuf[(base + 1 + COUT) * c.R + r] = asum;
+    segbuf[(base + 2 + COUT) * c.R + r] = dsum;
+  }
 }
 
 template <int COUT>
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(
     footprint(g, p, fp);
     if (!fp.inside) continue;
     Cell cell;
-    make_cell(g, fp, cell);
+    make_cell_fast(g, fp, cell);
     float v, rad[COUT];
     gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
     float sigma, dpost;
@@ -550,10 +560,13 @@ static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hi
   // With few rays (a 100x100 image is 40 blocks) the chip is starved: split the march into depth segments.
   // At 400x400 there are enough waves and the segmented variant is ~20 % slower (per-segment ray setup, extra
   // partial-result traffic, more lock-step waste), so it is used below kSegFwdMaxRays only.
-  constexpr long long kSegFwdMaxRays = 65536;
-  if (a.segbuf && nseg > 1 && !(c.term_eps > 0.0f) && c.R <= kSegFwdMaxRays) {
-    render_fwd_seg_kernel<COUT, NCM, NCU><<<blocks_for(c) * nseg, 256, 0, st>>>(
-        g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
+  if (a.segbuf && nseg > 1 && !(c.term_eps > 0.0f)) {
+    static const int env_fseg = [] { const char* e = getenv("VOXE_FSEG"); return e ? atoi(e) : 0; }();
+    int fseg = c.R <= 65536 ? 1 : 4;
+    if (env_fseg > 0) fseg = env_fseg;
+    const int ncoarse = (nseg + fseg - 1) / fseg;
+    render_fwd_seg_kernel<COUT, NCM, NCU><<<blocks_for(c) * ncoarse, 256, 0, st>>>(
+        g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
     render_fwd_combine_kernel<COUT><<<(int)((c.R + 255) / 256), 256, 0, st>>>(
         c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
     return;

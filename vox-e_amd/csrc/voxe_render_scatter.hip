@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
       footprint(g, p, fp);
       if (fp.inside) {
         Cell cell;
-        make_cell(g, fp, cell);
+        make_cell_fast(g, fp, cell);
         float v, rad[COUT];
         gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
         float sigma, dpost;

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
         }
         if (fp.inside) {
           Cell cell;
-          make_cell(g, fp, cell);
+          make_cell_fast(g, fp, cell);
           float v, rad[COUT];
           gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
           float sigma, dpost;
