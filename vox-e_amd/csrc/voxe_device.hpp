@@ -310,12 +310,15 @@ __device__ __forceinline__ void make_cell_fast(const DevGrid& g, const Footprint
 }
 
 // linear voxel index of the cell's low corner and the strides of the +1 corners
+// (unsigned: indices are non-negative, so 64-bit addresses need no sign extension; 24-bit multiplies are full
+// rate on CDNA while 32-bit integer multiplies are not -- grid dims are far below 2^24, the voxel count below 2^31)
 struct CellAddr {
-  int base, sx, sy, sz;
+  unsigned base, sx, sy, sz;
 };
 __device__ __forceinline__ CellAddr cell_addr(const DevGrid& g, const Cell& c) {
   CellAddr a;
-  a.base = (c.i[0] * g.Y + c.i[1]) * g.Z + c.i[2];
+  // operands of the 24-bit multiplies: ix, Y < 2^24 and ix*Y + iy < X*Y < 2^24 (validated on the host)
+  a.base = __umul24(__umul24((unsigned)c.i[0], (unsigned)g.Y) + (unsigned)c.i[1], (unsigned)g.Z) + (unsigned)c.i[2];
   a.sx = g.X > 1 ? g.Y * g.Z : 0;
   a.sy = g.Y > 1 ? g.Z : 0;
   a.sz = g.Z > 1 ? 1 : 0;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
         any = any || (gch[COUT] != 0.0f);
         T = T * om;
         if (any) {
-          base = cell_addr(g, cell).base;
+          base = (int)cell_addr(g, cell).base;
 #pragma unroll
           for (int j = 0; j < 8; ++j) wc[j] = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
         }
