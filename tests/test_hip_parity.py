@@ -402,3 +402,23 @@ def test_tiny_and_degenerate_grids(dims):
     gd, gf = gh.hip_backward(grid, cfg, o[:256], d[:256], gc[:256], image_width=16)  # LDS-window kernel on the same rays
     rd, rf = vo.render_bwd(grid, cfg, o[:256], d[:256], gc[:256])
     assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
+
+
+@pytest.mark.parametrize("S", [33, 100, 1024])
+def test_sample_counts_across_segment_boundaries(S):
+    """S not a multiple of the 32-sample depth segment, and the 1024-sample inference setting
+    (render_num_samples_per_ray): segmented forward + segmented backward vs the oracle."""
+    g = load_golden("frames32.npz")
+    grid = grid_from_golden(g, "", "softplus")
+    grid.density_scale = 3.0
+    h, w = 40, 48
+    o, d = vo.cast_rays(h, w, 0.5 * w / np.tan(0.5 * 0.6911112), g["rot"][6], g["trans"][6])
+    cfg = cfg_from_bounds(g["bounds"], S, white_bkgd=True, perturb=True, seed=3, rng_offset=9)
+    out = gh.hip_forward(grid, cfg, o, d, rng=(3, 9), image_width=w)
+    ref = vo.render_fwd(grid, cfg, o, d)
+    np.testing.assert_allclose(out["colour"], ref["colour"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["depth"], ref["depth"], rtol=1e-5, atol=1e-5)
+    gc = np.random.default_rng(S).standard_normal((h * w, 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(3, 9), image_width=w)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
