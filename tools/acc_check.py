@@ -1,5 +1,10 @@
-import sys, os
-sys.path[:0] = ["/root/repo/vox-e_amd", "/root/repo/tests", "/root/repo"]
+"""Accuracy of the two backward kernels vs the double-precision oracle (density / feature gradients, rel-L2)
+on a 120x120 view of the 160^3 BASELINE grids.   gpurun -- python tools/acc_check.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), ROOT]
 import numpy as np, torch
 import gpu_helpers as gh
 from helpers import rel_l2

@@ -2,7 +2,7 @@
 the whole-grid passes.  Tensors are plumbing (device memory + streams); all compute is in the HIP
 library.  Nothing here falls back to torch ops or to the CPU oracle."""
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
 import torch
