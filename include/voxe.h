@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 2
+#define VOXE_ABI_VERSION 3
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -226,6 +226,56 @@ int voxe_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, i
                             float* dst, int32_t X2, int32_t Y2, int32_t Z2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Refinement stage: 3-D grid graph cut and connected components.
+ * Integer / byte work on whole grids; results are bit-exact between libvoxe_hip.so and the oracle.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* capacity quantum: an n-link of affinity exp(-l2/sigma) == 1 gets VOXE_GRAPH_CAP_ONE units per contribution */
+#define VOXE_GRAPH_CAP_ONE (1 << 28)
+/* direction order of the six n-link capacity planes */
+enum { VOXE_DIR_XP = 0, VOXE_DIR_XM = 1, VOXE_DIR_YP = 2, VOXE_DIR_YM = 3, VOXE_DIR_ZP = 4, VOXE_DIR_ZM = 5 };
+
+/* Graph construction of build_graph   modules/refinement_functions.py:182-287
+ *   density_grid [X,Y,Z], feature_grid [X,Y,Z,F] (= sigmoid(_features), :378; pooled grids in the
+ *   down-sampled branch :189-196).
+ *   nodes      : dilate_yz = 1 -> `MaxPool3d(3, 1, 1)(densities[X,Y,Z,1]) > 0` (:186,:200): a 4-D input makes X the
+ *                channel axis, so the dilation runs over the Y-Z plane only;  0 -> `density_grid > 0` (:194);
+ *   n-links    : node i adds an edge (w, w) to each of its 6 neighbours n with density_grid[n] > 0 (:261-287),
+ *                w = K * exp(-l2(feature_i - feature_n) / sigma); a pair of nodes therefore carries
+ *                w * ([density_i > 0] + [density_n > 0]) in both directions.  The reference's bounds test (:264-266)
+ *                compares every coordinate of n with x, y AND z, i.e. with min(X,Y,Z): on non-cubic grids a voxel
+ *                with a coordinate >= min(X,Y,Z) is never visited as a neighbour (reproduced);  K scales every capacity alike
+ *                and, with infinite seed t-links only (:252-257), cannot change the cut: capacities are stored as
+ *                integers  llrint(exp(-l2/sigma) * VOXE_GRAPH_CAP_ONE) * multiplicity.
+ *   node_mask u8 [X,Y,Z];  cap int32 [6,X,Y,Z] (VOXE_DIR_* planes; 0 where there is no edge).            */
+int voxe_graph_build(const float* density_grid, const float* feature_grid,
+                     int32_t X, int32_t Y, int32_t Z, int32_t F, float sigma, int32_t dilate_yz,
+                     uint8_t* node_mask, int32_t* cap, void* stream);
+
+/* g.maxflow() + g.get_segment()   modules/refinement_functions.py:289-294   (PyMaxflow 1.x, Boykov-Kolmogorov)
+ *   terminal int8 [X,Y,Z]: +1 = add_tedge(inf, 0) ("edit" seed, source), -1 = add_tedge(0, inf) ("object" seed,
+ *   sink), 0 = no t-link.  cap is consumed (holds the residual capacities on return).
+ *   segment u8 [X,Y,Z]: 255 = not a node, 1 = the node can still reach a sink seed in the residual graph of a
+ *   maximum flow (BK's sink tree, get_segment == 1), 0 = otherwise (get_segment == 0, "edit").  That set is the
+ *   same for every maximum flow, so any exact solver yields the same labels.
+ *   flow int64[1]: value of the maximum flow in capacity units.
+ *   BLOCKING: synchronises `stream` (the iteration count is data dependent).                             */
+size_t voxe_graphcut_scratch_bytes(int32_t X, int32_t Y, int32_t Z);
+int voxe_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_t* cap,
+                  int32_t X, int32_t Y, int32_t Z, uint8_t* segment, int64_t* flow,
+                  void* scratch, size_t scratch_bytes, void* stream);
+
+/* cc3d.largest_k(mask, k, connectivity=26, delta=0)   edit_pretrained_relu_field.py:384-389,411-416
+ *   mask u8 [X,Y,Z] (non-zero = foreground).  labels int32 [X,Y,Z]: 0 = background or a component that is not
+ *   among the k largest; the M = min(k, N) largest components are numbered 1..M in ascending size (the largest
+ *   is M; equal sizes: the component whose first voxel in memory order comes first counts as larger).
+ *   num_components int32[1] = N (all 26-connected components).                                            */
+size_t voxe_cc_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t k);
+int voxe_cc_largest_k(const uint8_t* mask, int32_t X, int32_t Y, int32_t Z, int32_t k,
+                      int32_t* labels, int32_t* num_components,
+                      void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * CPU twin == the oracle (oracle/voxe_cpu.c). Same semantics, HOST pointers, no stream/workspace.
  * TEST INFRASTRUCTURE ONLY: never linked into libvoxe_hip.so, never called by the product path.
  * ---------------------------------------------------------------------------------------------- */
@@ -252,6 +302,13 @@ int voxe_cpu_adam_step(float* param, const float* grad, float* exp_avg, float* e
                        int64_t n, float lr, float beta1, float beta2, float eps, int64_t step);
 int voxe_cpu_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, int32_t C,
                                 float* dst, int32_t X2, int32_t Y2, int32_t Z2);
+int voxe_cpu_graph_build(const float* density_grid, const float* feature_grid,
+                         int32_t X, int32_t Y, int32_t Z, int32_t F, float sigma, int32_t dilate_yz,
+                         uint8_t* node_mask, int32_t* cap);
+int voxe_cpu_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_t* cap,
+                      int32_t X, int32_t Y, int32_t Z, uint8_t* segment, int64_t* flow);
+int voxe_cpu_cc_largest_k(const uint8_t* mask, int32_t X, int32_t Y, int32_t Z, int32_t k,
+                          int32_t* labels, int32_t* num_components);
 /* number of OpenMP threads the oracle will use (1 when built without OpenMP) */
 int voxe_cpu_num_threads(void);
 /* jitter value the HIP kernels draw for (seed, offset, ray, sample): lets tests replay the stream */

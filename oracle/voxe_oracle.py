@@ -30,12 +30,12 @@ _lib = None
 
 def build(force: bool = False) -> str:
     """Compile the C restatement with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "voxe_cpu.c")
-    hdr = os.path.join(_ROOT, "include", "voxe.h")
+    deps = [os.path.join(_HERE, "voxe_cpu.c"), os.path.join(_HERE, "voxe_cpu_refine.c"),
+            os.path.join(_ROOT, "include", "voxe.h")]
     stale = (
         force
         or not os.path.exists(_LIB_PATH)
-        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+        or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(d) for d in deps)
     )
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libvoxe_oracle.so"], stdout=subprocess.DEVNULL)
@@ -238,3 +238,41 @@ def upsample_trilinear(src, out_size):
     _check(lib().voxe_cpu_upsample_trilinear(src.ctypes.data, X, Y, Z, Cn, dst.ctypes.data, X2, Y2, Z2),
            "upsample")
     return dst
+
+
+# ---- refinement stage -------------------------------------------------------------------------------------
+def graph_build(density_grid, feature_grid, sigma: float = 0.1, dilate_yz: bool = True):
+    """-> node_mask u8 [X,Y,Z], cap int32 [6,X,Y,Z]"""
+    dens = _f32(density_grid).reshape(np.asarray(density_grid).shape[:3])
+    feat = _f32(feature_grid)
+    X, Y, Z = dens.shape
+    F = feat.shape[-1]
+    node = np.empty((X, Y, Z), np.uint8)
+    cap = np.empty((6, X, Y, Z), np.int32)
+    _check(lib().voxe_cpu_graph_build(dens.ctypes.data, feat.ctypes.data, X, Y, Z, F, float(sigma),
+                                      int(bool(dilate_yz)), node.ctypes.data, cap.ctypes.data), "graph_build")
+    return node, cap
+
+
+def graphcut(node_mask, terminal, cap):
+    """-> segment u8 [X,Y,Z] (255 = no node), flow (int), residual capacities"""
+    node = np.ascontiguousarray(node_mask, dtype=np.uint8)
+    term = np.ascontiguousarray(terminal, dtype=np.int8)
+    res = np.array(cap, dtype=np.int32, order="C", copy=True)
+    X, Y, Z = node.shape
+    seg = np.empty((X, Y, Z), np.uint8)
+    flow = np.zeros((1,), np.int64)
+    _check(lib().voxe_cpu_graphcut(node.ctypes.data, term.ctypes.data, res.ctypes.data, X, Y, Z,
+                                   seg.ctypes.data, flow.ctypes.data), "graphcut")
+    return seg, int(flow[0]), res
+
+
+def cc_largest_k(mask, k: int):
+    """-> labels int32 [X,Y,Z], number of 26-connected components"""
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    X, Y, Z = m.shape
+    labels = np.empty((X, Y, Z), np.int32)
+    n = np.zeros((1,), np.int32)
+    _check(lib().voxe_cpu_cc_largest_k(m.ctypes.data, X, Y, Z, int(k), labels.ctypes.data, n.ctypes.data),
+           "cc_largest_k")
+    return labels, int(n[0])

@@ -31,3 +31,21 @@ def sphere_grid(side: int, world: float = 3.0, radius: float = 1.0):
     dens = torch.where(r < radius, torch.tensor(1.0), torch.tensor(-1.0))[..., None].contiguous()
     feat = torch.stack([torch.sin(2.0 * x), torch.cos(3.0 * y), torch.sin(2.5 * z + 1.0)], dim=-1).contiguous()
     return dens, feat
+
+
+def refine_scene(side: int, seed: int = 5, n_obj: int = 5000):
+    """Refinement-stage scene: the solid sphere with a textured colour field; "edit" seeds on its cap (z > 0.8),
+    `n_obj` random "object" seeds in the lower part (z < 0.2).  -> densities [S,S,S,1], sigmoid colours [S,S,S,3],
+    seed coordinates (bool mask of edit seeds, int array [n,3] of object seeds)"""
+    import numpy as np
+
+    dens, feat = sphere_grid(side)
+    g = torch.Generator().manual_seed(seed)
+    col = torch.sigmoid(feat + 0.3 * torch.randn(feat.shape, generator=g))
+    ax = (np.arange(side) + 0.5) / side * 3.0 - 1.5
+    z = np.broadcast_to(ax[None, None, :], (side,) * 3)
+    inside = dens[..., 0].numpy() > 0
+    edit = inside & (z > 0.8)
+    cand = np.argwhere(inside & (z < 0.2))
+    pick = cand[np.random.default_rng(seed).permutation(len(cand))[:n_obj]]
+    return dens, col.contiguous(), edit, pick

@@ -418,6 +418,92 @@ def g12_frames():
     save("frames32.npz", **out)
 
 
+def g13_refinement():
+    """Refinement stage (modules/refinement_functions.py): the graph `build_graph` constructs (:182-287) and
+    `calc_loss_on_attn_grid` (:42-76).  The module imports two packages this image lacks: `wandb` (logging only,
+    never reached with log_wandb=False) and `maxflow` (PyMaxflow).  `maxflow` is replaced by a RECORDING stand-in:
+    it logs add_nodes / add_tedge / add_edge and solves nothing (maxflow() -> 0, get_segment() -> 0), so the
+    fixture pins the graph CONSTRUCTION only; the min-cut solver is pinned elsewhere (scipy / brute force)."""
+    recorded = []
+
+    class _RecGraph:
+        def __class_getitem__(cls, item):
+            return cls
+
+        def __init__(self):
+            self.tedges, self.edges, self.n = [], [], 0
+            recorded.append(self)
+
+        def add_nodes(self, n):
+            self.n = int(n)
+            return np.arange(self.n)
+
+        def add_tedge(self, i, s, t):
+            self.tedges.append((int(i), float(s), float(t)))
+
+        def add_edge(self, i, j, c, rc):
+            self.edges.append((int(i), int(j), float(c), float(rc)))
+
+        def maxflow(self):
+            return 0.0
+
+        def get_segment(self, i):
+            return 0
+
+    mf = types.ModuleType("maxflow")
+    mf.Graph = _RecGraph
+    sys.modules.setdefault("maxflow", mf)
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    from thre3d_atom.modules.refinement_functions import build_graph, calc_loss_on_attn_grid  # noqa: E402
+
+    out = {}
+    g = torch.Generator().manual_seed(13)
+
+    def scene(dims, fill):
+        dens = torch.empty(*dims, 1).uniform_(-1.0, fill, generator=g)
+        feat = torch.sigmoid(torch.empty(*dims, 3).uniform_(-2, 2, generator=g))  # refinement_functions.py:378
+        edit = torch.empty(*dims, 1).uniform_(-1, 1, generator=g)
+        obj = torch.empty(*dims, 1).uniform_(-1, 1, generator=g)
+        return dens, feat, edit, obj
+
+    cases = {
+        # enough edit voxels -> thresholded edit seeds + random object seeds
+        "a": dict(dims=(6, 7, 8), fill=0.25, kw=dict(K=5.0, sigma=0.1, edit_mask_thresh=0.9, num_obj_voxels_thresh=12,
+                                                    min_num_edit_voxels=2, top_k_edit_thresh=5, top_k_obj_thresh=4)),
+        # too few edit voxels -> top-k fallback for both seed sets
+        "b": dict(dims=(5, 6, 7), fill=0.4, kw=dict(K=5.0, sigma=0.1, edit_mask_thresh=0.999, num_obj_voxels_thresh=10,
+                                                   min_num_edit_voxels=50, top_k_edit_thresh=6, top_k_obj_thresh=5)),
+        # down-sampled grid branch (max / average pooling by 4)
+        "c": dict(dims=(16, 16, 16), fill=0.01, kw=dict(K=5.0, sigma=0.1, edit_mask_thresh=0.9, num_obj_voxels_thresh=8,
+                                                       min_num_edit_voxels=2, top_k_edit_thresh=5, top_k_obj_thresh=4,
+                                                       downsample_grid=True, downsample_factor=4)),
+    }
+    for tag, case in cases.items():
+        dens, feat, edit, obj = scene(case["dims"], case["fill"])
+        torch.manual_seed(1300 + ord(tag))
+        with torch.no_grad():
+            _, idx_values = build_graph(feat, dens, edit, obj, **case["kw"])
+        rec = recorded[-1]
+        out[f"{tag}_densities"], out[f"{tag}_features"] = np_(dens), np_(feat)
+        out[f"{tag}_edit_attn"], out[f"{tag}_obj_attn"] = np_(edit), np_(obj)
+        out[f"{tag}_seed"] = np.array(1300 + ord(tag))
+        out[f"{tag}_node_idx"] = idx_values.numpy().astype(np.int32)
+        out[f"{tag}_tedges"] = np.array(rec.tedges, dtype=np.float64).reshape(-1, 3)
+        out[f"{tag}_edges"] = np.array(rec.edges, dtype=np.float64).reshape(-1, 4)
+        for k, v in case["kw"].items():
+            out[f"{tag}_kw_{k}"] = np.array(v)
+
+    # masked-L1 attention loss + gradient
+    for tag, (h, w) in {"a": (12, 10), "b": (7, 9)}.items():
+        render = (torch.empty(h * w, 1).uniform_(-0.5, 1.0, generator=g)).requires_grad_(True)
+        amap = torch.empty(h, w).uniform_(0, 1, generator=g)
+        loss = calc_loss_on_attn_grid(render, amap, token="edit", global_step=1)
+        (gr,) = torch.autograd.grad(loss, render)
+        out[f"loss_{tag}_render"], out[f"loss_{tag}_map"] = np_(render), np_(amap)
+        out[f"loss_{tag}_value"], out[f"loss_{tag}_grad"] = np_(loss), np_(gr)
+    save("refine_graph.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -431,3 +517,4 @@ if __name__ == "__main__":
     g10_upsample()
     g11_checkpoint()
     g12_frames()
+    g13_refinement()

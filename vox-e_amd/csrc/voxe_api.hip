@@ -420,4 +420,45 @@ int voxe_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, i
   return finish();
 }
 
+// ---- refinement stage ------------------------------------------------------------------------------
+static bool refine_dims_ok(int32_t X, int32_t Y, int32_t Z) {
+  return X > 0 && Y > 0 && Z > 0 && (long long)X * Y * Z < (1ll << 30);
+}
+
+int voxe_graph_build(const float* density_grid, const float* feature_grid, int32_t X, int32_t Y, int32_t Z,
+                     int32_t F, float sigma, int32_t dilate_yz, uint8_t* node_mask, int32_t* cap, void* stream) {
+  if (!density_grid || !feature_grid || !node_mask || !cap) return VOXE_ERR_NULL_POINTER;
+  if (!refine_dims_ok(X, Y, Z) || F <= 0 || !(sigma > 0.0f)) return VOXE_ERR_BAD_SHAPE;
+  launch_graph_build(density_grid, feature_grid, X, Y, Z, F, sigma, dilate_yz ? 1 : 0, node_mask, cap,
+                     (hipStream_t)stream);
+  return finish();
+}
+
+size_t voxe_graphcut_scratch_bytes(int32_t X, int32_t Y, int32_t Z) {
+  return refine_dims_ok(X, Y, Z) ? graphcut_scratch_bytes(X, Y, Z) : 0;
+}
+
+int voxe_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_t* cap, int32_t X, int32_t Y, int32_t Z,
+                  uint8_t* segment, int64_t* flow, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!node_mask || !terminal || !cap || !segment || !flow) return VOXE_ERR_NULL_POINTER;
+  if (!refine_dims_ok(X, Y, Z)) return VOXE_ERR_BAD_SHAPE;
+  if (!scratch || scratch_bytes < graphcut_scratch_bytes(X, Y, Z)) return VOXE_ERR_WORKSPACE;
+  if (run_graphcut(node_mask, terminal, cap, X, Y, Z, segment, flow, scratch, (hipStream_t)stream) != hipSuccess)
+    return VOXE_ERR_LAUNCH;
+  return finish();
+}
+
+size_t voxe_cc_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t k) {
+  return refine_dims_ok(X, Y, Z) && k >= 0 ? cc_scratch_bytes(X, Y, Z, k) : 0;
+}
+
+int voxe_cc_largest_k(const uint8_t* mask, int32_t X, int32_t Y, int32_t Z, int32_t k, int32_t* labels,
+                      int32_t* num_components, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!mask || !labels || !num_components) return VOXE_ERR_NULL_POINTER;
+  if (!refine_dims_ok(X, Y, Z) || k < 0 || k > 4096) return VOXE_ERR_BAD_SHAPE;
+  if (!scratch || scratch_bytes < cc_scratch_bytes(X, Y, Z, k)) return VOXE_ERR_WORKSPACE;
+  launch_cc_largest_k(mask, X, Y, Z, k, labels, num_components, scratch, (hipStream_t)stream);
+  return finish();
+}
+
 }  // extern "C"

@@ -64,4 +64,15 @@ void launch_adam(float* param, const float* grad, float* m, float* v, long long 
 void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, int X2, int Y2, int Z2,
                      hipStream_t st);
 
+
+// voxe_refine.hip: graph construction / minimum cut / connected components of the refinement stage
+void launch_graph_build(const float* dens, const float* feat, int X, int Y, int Z, int F, float sigma,
+                        int dilate_yz, uint8_t* node_mask, int32_t* cap, hipStream_t stream);
+size_t graphcut_scratch_bytes(int X, int Y, int Z);
+hipError_t run_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_t* cap, int X, int Y, int Z,
+                        uint8_t* segment, int64_t* flow, void* scratch, hipStream_t stream);
+size_t cc_scratch_bytes(int X, int Y, int Z, int k);
+void launch_cc_largest_k(const uint8_t* mask, int X, int Y, int Z, int k, int32_t* labels, int32_t* ncomp,
+                         void* scratch, hipStream_t stream);
+
 }  // namespace voxe

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # VoxeStatus
 OK = 0
@@ -93,7 +93,14 @@ _COMMON = {
     "tv_fwd_bwd": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int32], True, True),
     "adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64], False, True),
     "upsample_trilinear": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32], False, True),
+    # refinement stage (graph cut / connected components)
+    "graph_build": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P], False, True),
+    "graphcut": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P], True, True),
+    "cc_largest_k": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P], True, True),
 }
+
+GRAPH_CAP_ONE = 1 << 28
+DIR_XP, DIR_XM, DIR_YP, DIR_YM, DIR_ZP, DIR_ZM = range(6)
 
 # the CPU twin's render_bwd does not take the forward outputs (colour, depth, acc): it recomputes
 _CPU_RENDER_BWD = [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_int32]
@@ -111,6 +118,8 @@ HIP_ONLY = {
     "workspace_bytes": (C.c_size_t, [_GD, _RC, C.c_int64]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "graphcut_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "cc_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "profile_enable": (C.c_int, [C.c_int32]),
     "profile_read": (C.c_int, [C.POINTER(VoxeProfile)]),
 }

@@ -423,6 +423,75 @@ def upsample_trilinear(src: torch.Tensor, out_size: Sequence[int]) -> torch.Tens
     return dst
 
 
+# ---- refinement stage: grid graph cut / connected components -----------------------------------------------
+def graph_build(density_grid: torch.Tensor, feature_grid: torch.Tensor, sigma: float = 0.1,
+                dilate_yz: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Nodes and quantised n-link capacities of the refinement graph
+    (thre3d_atom/modules/refinement_functions.py:182-287).  density_grid [X,Y,Z(,1)], feature_grid [X,Y,Z,F]
+    -> node_mask uint8 [X,Y,Z], cap int32 [6,X,Y,Z] (abi.DIR_* planes, abi.GRAPH_CAP_ONE units)."""
+    require_device(density_grid, "graph_build")
+    require_device(feature_grid, "graph_build")
+    dens = f32c(density_grid)
+    feat = f32c(feature_grid)
+    X, Y, Z = (int(v) for v in dens.shape[:3])
+    if dens.numel() != X * Y * Z or feat.dim() != 4 or tuple(feat.shape[:3]) != (X, Y, Z):
+        raise VoxeError(f"graph_build: density grid {tuple(dens.shape)} / feature grid {tuple(feat.shape)} mismatch")
+    device = dens.device
+    ensure_gfx950(device)
+    with torch.cuda.device(device):
+        node = torch.empty((X, Y, Z), dtype=torch.uint8, device=device)
+        cap = torch.empty((6, X, Y, Z), dtype=torch.int32, device=device)
+        check(lib().voxe_graph_build(ptr(dens), ptr(feat), X, Y, Z, int(feat.shape[3]), float(sigma),
+                                     int(bool(dilate_yz)), ptr(node), ptr(cap), stream_ptr(device)),
+              "voxe_graph_build")
+    return node, cap
+
+
+def graphcut(node_mask: torch.Tensor, terminal: torch.Tensor, cap: torch.Tensor):
+    """Exact minimum cut of the voxel graph (g.maxflow() + get_segment, refinement_functions.py:289-294).
+    terminal int8 [X,Y,Z]: +1 edit (source) seed, -1 object (sink) seed.  `cap` is not modified.
+    -> segment uint8 [X,Y,Z] (0 edit / 1 object / 255 no node), flow value (python int, capacity units)."""
+    for t, name in ((node_mask, "node_mask"), (terminal, "terminal"), (cap, "cap")):
+        require_device(t, f"graphcut({name})")
+    X, Y, Z = (int(v) for v in node_mask.shape)
+    if node_mask.dtype != torch.uint8 or terminal.dtype != torch.int8 or cap.dtype != torch.int32:
+        raise VoxeError("graphcut: expected uint8 node_mask, int8 terminal, int32 cap")
+    if tuple(terminal.shape) != (X, Y, Z) or tuple(cap.shape) != (6, X, Y, Z):
+        raise VoxeError("graphcut: shape mismatch")
+    device = node_mask.device
+    ensure_gfx950(device)
+    with torch.cuda.device(device):
+        residual = cap.contiguous().clone()
+        node, term = node_mask.contiguous(), terminal.contiguous()
+        segment = torch.empty((X, Y, Z), dtype=torch.uint8, device=device)
+        flow = torch.zeros((1,), dtype=torch.int64, device=device)
+        nbytes = int(lib().voxe_graphcut_scratch_bytes(X, Y, Z))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        check(lib().voxe_graphcut(ptr(node), ptr(term), ptr(residual), X, Y, Z, ptr(segment), ptr(flow),
+                                  ptr(scratch), nbytes, stream_ptr(device)), "voxe_graphcut")
+    return segment, int(flow.item())
+
+
+def cc_largest_k(mask: torch.Tensor, k: int) -> Tuple[torch.Tensor, int]:
+    """cc3d.largest_k(mask, k, connectivity=26) (edit_pretrained_relu_field.py:384-389): int32 labels [X,Y,Z]
+    (the M = min(k, N) largest components numbered 1..M by ascending size) and N."""
+    require_device(mask, "cc_largest_k")
+    m = (mask != 0).to(torch.uint8).contiguous()
+    if m.dim() != 3:
+        raise VoxeError(f"cc_largest_k: expected a [X,Y,Z] mask, got {tuple(m.shape)}")
+    X, Y, Z = (int(v) for v in m.shape)
+    device = m.device
+    ensure_gfx950(device)
+    with torch.cuda.device(device):
+        labels = torch.empty((X, Y, Z), dtype=torch.int32, device=device)
+        ncomp = torch.zeros((1,), dtype=torch.int32, device=device)
+        nbytes = int(lib().voxe_cc_scratch_bytes(X, Y, Z, int(k)))
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        check(lib().voxe_cc_largest_k(ptr(m), X, Y, Z, int(k), ptr(labels), ptr(ncomp), ptr(scratch), nbytes,
+                                      stream_ptr(device)), "voxe_cc_largest_k")
+    return labels, int(ncomp.item())
+
+
 def profile_enable(on: bool = True) -> None:
     check(lib().voxe_profile_enable(int(on)), "voxe_profile_enable")
 
