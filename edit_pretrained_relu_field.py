@@ -2,8 +2,9 @@
 """Text-guided edit of a pre-trained ReLU/softplus field with score distillation (entry point kept from the
 reference's edit_pretrained_relu_field.py:234-319; option names of the global-edit stage).  The render
 forward/backward, the density-correlation regulariser and Adam run in the HIP library; Stable Diffusion
-(diffusers) runs under PyTorch-ROCm.  The local-edit refinement stage (cross-attention grids + graph cut,
-:321-427) is outside this build's scope."""
+(diffusers) runs under PyTorch-ROCm.  `--do_refinement` chains the local-edit refinement stage (attention grids +
+GPU graph cut, :321-373; also available stand-alone as refine_edited_relu_field.py) and `--post_process_scc`
+restores the original densities outside the largest connected component (:374-427, GPU component labelling)."""
 import copy
 import os
 import sys
@@ -14,9 +15,17 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "vox-e_amd"))
 
+from thre3d_atom.modules.attn_grid_trainer import refine_edited_relu_field  # noqa: E402
+from thre3d_atom.modules.refinement_functions import restore_outside_largest_component  # noqa: E402
 from thre3d_atom.modules.sds_trainer import train_sh_vox_grid_vol_mod_with_posed_images_and_sds  # noqa: E402
-from thre3d_atom.modules.volumetric_model import create_volumetric_model_from_saved_model  # noqa: E402
-from thre3d_atom.thre3d_reprs.voxels import create_voxel_grid_from_saved_info_dict  # noqa: E402
+from thre3d_atom.modules.volumetric_model import (  # noqa: E402
+    create_volumetric_model_from_saved_model,
+    create_volumetric_model_from_saved_model_attn,
+)
+from thre3d_atom.thre3d_reprs.voxels import (  # noqa: E402
+    create_voxel_grid_from_saved_info_dict,
+    create_voxel_grid_from_saved_info_dict_attn,
+)
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS  # noqa: E402
 from thre3d_atom.utils.imaging_utils import scale_camera_intrinsics  # noqa: E402
 from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
@@ -52,10 +61,26 @@ from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
 @click.option("--uncoupled_mode", type=click.BOOL, default=False, show_default=True)
 @click.option("--data_pose_mode", type=click.BOOL, default=False, show_default=True)
 @click.option("--do_refinement", type=click.BOOL, default=False, show_default=True)
+@click.option("--post_process_scc", type=click.BOOL, default=False, show_default=True,
+              help="restore the original densities outside the largest connected component of the edited field")
+@click.option("-eidx", "--edit_idx", type=click.STRING, default=None, help="refinement: 1-based token indices of the edit words")
+@click.option("-oidx", "--object_idx", type=click.INT, default=None, help="refinement: token index of the object")
+@click.option("-t", "--timestamp", type=click.INT, default=200, show_default=True, help="refinement: diffusion timestamp")
+@click.option("-a", "--hf_auth_token", type=click.STRING, default="", help="refinement: hugging face token (SD 1.4)")
+@click.option("--num_iterations_refine", type=click.INT, default=1500, show_default=True)
+@click.option("--learning_rate_refine", type=click.FLOAT, default=0.028, show_default=True)
+@click.option("--attn_tv_weight", type=click.FLOAT, default=0.01, show_default=True)
+@click.option("--kval", type=click.FLOAT, default=5.0, show_default=True)
+@click.option("--edit_mask_thresh", type=click.FLOAT, default=0.992, show_default=True)
+@click.option("--num_obj_voxels_thresh", type=click.INT, default=5000, show_default=True)
+@click.option("--min_num_edit_voxels", type=click.INT, default=300, show_default=True)
+@click.option("--top_k_edit_thresh", type=click.INT, default=300, show_default=True)
+@click.option("--top_k_obj_thresh", type=click.INT, default=200, show_default=True)
+@click.option("--downsample_refine_grid", type=click.BOOL, default=False, show_default=True)
 def main(**kwargs) -> None:
     cfg = type("Config", (), kwargs)
-    if cfg.do_refinement:
-        raise click.UsageError("the local-edit refinement stage is not part of this build (see module docstring)")
+    if cfg.do_refinement and not cfg.edit_idx:
+        raise click.UsageError("--do_refinement needs --edit_idx (token indices of the edit words in the prompt)")
     device = torch.device("cuda")
     output_path = Path(cfg.output_path)
     log_config_to_disk(kwargs, output_path)
@@ -84,6 +109,33 @@ def main(**kwargs) -> None:
         data_pose_mode=cfg.data_pose_mode, camera_intrinsics=intrinsics, camera_bounds=extra[CAMERA_BOUNDS],
         hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
     )
+    saved = output_path / "saved_models"
+    extra_info = {CAMERA_BOUNDS: extra[CAMERA_BOUNDS], CAMERA_INTRINSICS: intrinsics,
+                  HEMISPHERICAL_RADIUS: extra.get(HEMISPHERICAL_RADIUS, 4.0311)}
+    final_name = "model_final.pth"
+    if cfg.do_refinement:
+        attn_models = [create_volumetric_model_from_saved_model_attn(
+            saved / "model_final.pth", create_voxel_grid_from_saved_info_dict_attn, device=device)[0] for _ in range(3)]
+        refine_edited_relu_field(
+            vol_mod_edit=attn_models[0], vol_mod_object=attn_models[1], vol_mod_output=attn_models[2],
+            vol_mod_ref=ref_vol_mod, train_dataset=dataset, hf_auth_token=cfg.hf_auth_token, output_dir=output_path,
+            prompt=cfg.prompt, edit_idx=[int(i) for i in cfg.edit_idx.split()], object_idx=cfg.object_idx,
+            timestamp=cfg.timestamp, image_dims=None, num_iterations=cfg.num_iterations_refine,
+            learning_rate=cfg.learning_rate_refine, save_freq=cfg.save_frequency, feedback_freq=cfg.feedback_frequency,
+            summary_freq=cfg.summary_frequency, attn_tv_weight=cfg.attn_tv_weight, kval=cfg.kval,
+            edit_mask_thresh=cfg.edit_mask_thresh, num_obj_voxels_thresh=cfg.num_obj_voxels_thresh,
+            min_num_edit_voxels=cfg.min_num_edit_voxels, top_k_edit_thresh=cfg.top_k_edit_thresh,
+            top_k_obj_thresh=cfg.top_k_obj_thresh, data_pose_mode=cfg.data_pose_mode,
+            downsample_refine_grid=cfg.downsample_refine_grid, camera_intrinsics=intrinsics,
+            camera_bounds=extra[CAMERA_BOUNDS], hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
+        )
+        final_name = "model_final_refined.pth"
+    if cfg.post_process_scc:
+        loader = create_volumetric_model_from_saved_model_attn if cfg.do_refinement else create_volumetric_model_from_saved_model
+        creator = create_voxel_grid_from_saved_info_dict_attn if cfg.do_refinement else create_voxel_grid_from_saved_info_dict
+        vol_mod, _ = loader(saved / final_name, creator, device=device)
+        restore_outside_largest_component(vol_mod, ref_vol_mod, k=10)
+        torch.save(vol_mod.get_save_info(extra_info=extra_info), saved / final_name)
 
 
 if __name__ == "__main__":

@@ -474,7 +474,7 @@ def g13_refinement():
         "b": dict(dims=(5, 6, 7), fill=0.4, kw=dict(K=5.0, sigma=0.1, edit_mask_thresh=0.999, num_obj_voxels_thresh=10,
                                                    min_num_edit_voxels=50, top_k_edit_thresh=6, top_k_obj_thresh=5)),
         # down-sampled grid branch (max / average pooling by 4)
-        "c": dict(dims=(16, 16, 16), fill=0.01, kw=dict(K=5.0, sigma=0.1, edit_mask_thresh=0.9, num_obj_voxels_thresh=8,
+        "c": dict(dims=(16, 16, 16), fill=0.01, kw=dict(K=5.0, sigma=0.1, edit_mask_thresh=0.999, num_obj_voxels_thresh=8,
                                                        min_num_edit_voxels=2, top_k_edit_thresh=5, top_k_obj_thresh=4,
                                                        downsample_grid=True, downsample_factor=4)),
     }
