@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--scene", choices=["random", "sphere"], default="random")
     ap.add_argument("--term-eps", type=float, default=0.0, help="early ray termination (NOT in the reference); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=200, help="side of the image the CPU oracle is timed on")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="side of the image the CPU oracle is timed on (0: sized by a probe for ~5 s of wall time)")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--no-jitter", action="store_true")
     ap.add_argument("--ray-order", choices=["image", "linear", "random"], default="image",
@@ -201,19 +202,29 @@ def main():
         from oracle import voxe_oracle as vo
         from voxe_hip.desc import make_render_cfg
 
-        hw = args.cpu_sample
         grid = vo.Grid(dens_cpu.numpy(), feat_cpu.numpy(), aabb, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
-        o, d = vo.cast_rays(hw, hw, focal_for(hw), pose.rotation.numpy(), pose.translation.numpy())
         cfg = make_render_cfg(S, NEAR, FAR, perturb=not args.no_jitter, white_bkgd=True, seed=42, rng_offset=1)
-        gc = np.random.default_rng(43).standard_normal((hw * hw, 3)).astype(np.float32)
-        t1 = time.perf_counter()
-        vo.render_fwd(grid, cfg, o, d)
-        vo.render_bwd(grid, cfg, o, d, gc)
-        dt = time.perf_counter() - t1
+
+        def cpu_pass(hw):
+            o, d = vo.cast_rays(hw, hw, focal_for(hw), pose.rotation.numpy(), pose.translation.numpy())
+            gc = np.random.default_rng(43).standard_normal((hw * hw, 3)).astype(np.float32)
+            t1 = time.perf_counter()
+            vo.render_fwd(grid, cfg, o, d)
+            vo.render_bwd(grid, cfg, o, d, gc)
+            return time.perf_counter() - t1
+
+        # bounded sample: a 64x64 probe sizes the timed image for ~5 s of wall time (never more than the GPU's image)
+        hw = args.cpu_sample
+        if hw <= 0:
+            cpu_pass(64)                      # thread start-up / first touch
+            probe = cpu_pass(64)
+            hw = int(max(64, min(HW, 64 * (5.0 / max(probe, 1e-3)) ** 0.5)))
+        dt = cpu_pass(hw)
+        threads = vo.num_threads()
         cpu_baseline = {
-            "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": vo.num_threads(), "kind": "port",
+            "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{hw}x{hw} rays of camera {args.camera} (same {G}^3 grid, S={S}, jitter on), 1 forward + 1 backward "
-                      f"of oracle/voxe_cpu.c with OpenMP, {dt:.1f} s",
+                      f"of oracle/voxe_cpu.c with OpenMP: {dt:.1f} s wall x {threads} threads = {dt * threads:.0f} core-seconds",
         }
 
     if rank == 0:

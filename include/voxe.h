@@ -254,7 +254,8 @@ int voxe_graph_build(const float* density_grid, const float* feature_grid,
 
 /* g.maxflow() + g.get_segment()   modules/refinement_functions.py:289-294   (PyMaxflow 1.x, Boykov-Kolmogorov)
  *   terminal int8 [X,Y,Z]: +1 = add_tedge(inf, 0) ("edit" seed, source), -1 = add_tedge(0, inf) ("object" seed,
- *   sink), 0 = no t-link.  cap is consumed (holds the residual capacities on return).
+ *   sink), 0 = no t-link.  cap is consumed (holds the residual capacities on return); every capacity must be
+ *   <= 2^29 so that a residual (forward + reverse capacity of a pair) stays below 2^31.
  *   segment u8 [X,Y,Z]: 255 = not a node, 1 = the node can still reach a sink seed in the residual graph of a
  *   maximum flow (BK's sink tree, get_segment == 1), 0 = otherwise (get_segment == 0, "edit").  That set is the
  *   same for every maximum flow, so any exact solver yields the same labels.

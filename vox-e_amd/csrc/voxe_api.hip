@@ -12,14 +12,19 @@ using namespace voxe;
 
 namespace {
 
-// VOXE_BWD_MODE=scatter forces the plain global-atomic backward (A/B measurements, debugging)
-bool force_scatter_bwd() {
+// VOXE_BWD_MODE=scatter forces the plain global-atomic backward, =packed the line-dense scatter backward
+// (A/B measurements, debugging)
+int bwd_mode_override() {
   static const int mode = [] {
     const char* e = getenv("VOXE_BWD_MODE");
-    return (e && strcmp(e, "scatter") == 0) ? 1 : 0;
+    if (e && strcmp(e, "scatter") == 0) return 1;
+    if (e && strcmp(e, "packed") == 0) return 2;
+    return 0;
   }();
-  return mode == 1;
+  return mode;
 }
+bool force_scatter_bwd() { return bwd_mode_override() == 1; }
+bool force_no_tile_bwd() { return bwd_mode_override() != 0; }
 
 // VOXE_TILE_MAP = band (default) | linear | rows : block -> tile mapping (see logical_tile())
 int tile_map_mode() {
@@ -231,7 +236,7 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   make_dev(grid, cfg, R, v, &dg, &dc);
   // depth-segment states for the segmented backward, when that backward applies and the workspace holds them
   float* state = nullptr;
-  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd() && workspace_bytes >= l.total)
+  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd() && workspace_bytes >= l.total)
     state = (float*)((char*)workspace + l.state_off);
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
@@ -266,7 +271,7 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     make_dev(grid, cfg, R, v, &dg, &dc);
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               d_densities != nullptr, d_features != nullptr, state};
-    const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_scatter_bwd();
+    const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
     if (tiled && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
