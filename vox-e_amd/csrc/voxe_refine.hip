@@ -11,7 +11,7 @@
 // Minimum cut: lock-free push-relabel (one thread owns one voxel; only the owner lowers its excess and its
 // outgoing residual capacities, everybody else only raises them through atomics, heights are written by the
 // owner only) with exact global relabelling (Bellman-Ford sweeps from the sink seeds) between bursts of
-// push/relabel sweeps.  Only the first phase is needed: once no voxel that can still reach a sink seed holds
+// push/relabel sweeps; the iterative kernels run over a compacted list of the free nodes.  Only the first phase is needed: once no voxel that can still reach a sink seed holds
 // excess the preflow is maximum, and "can reach a sink seed in the residual graph" is the sink side of the
 // cut -- the same set Boykov-Kolmogorov's sink tree spans when PyMaxflow terminates.
 #include <hip/hip_runtime.h>
@@ -144,8 +144,23 @@ struct CutState {
   long long* excess;  // [N]
   int32_t* height;  // [N]
   long long* flow;  // [1] units absorbed by the sink seeds
-  int32_t* flags;   // [0] relabel changed, [1] active count
+  int32_t* flags;   // [0] relabel changed, [1] active count, [2] number of free nodes
+  int32_t* list;    // [n_free] voxels that are nodes without a t-link (the only ones that relax / push)
+  int n_free;
 };
+
+// wave-aggregated append of the free nodes to s.list (order is irrelevant to the exact result)
+__global__ __launch_bounds__(kThreads) void cut_compact_kernel(Dims g, CutState s) {
+  const int v = blockIdx.x * kThreads + threadIdx.x;
+  const bool keep = v < g.N && s.node[v] && s.term[v] == 0;
+  const unsigned long long b = __ballot(keep);
+  if (!b) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)b) - 1) base = atomicAdd(&s.flags[2], __popcll(b));
+  base = __shfl(base, __ffsll((long long)b) - 1, 64);
+  if (keep) s.list[base + __popcll(b & ((1ull << lane) - 1ull))] = v;
+}
 
 __global__ __launch_bounds__(kThreads) void cut_init_kernel(Dims g, CutState s) {
   const int v = blockIdx.x * kThreads + threadIdx.x;
@@ -156,6 +171,7 @@ __global__ __launch_bounds__(kThreads) void cut_init_kernel(Dims g, CutState s) 
     *s.flow = 0;
     s.flags[0] = 0;
     s.flags[1] = 0;
+    s.flags[2] = 0;
   }
 }
 
@@ -188,8 +204,9 @@ __global__ __launch_bounds__(kThreads) void relabel_init_kernel(Dims g, CutState
 // one Bellman-Ford relaxation sweep of "distance to a sink seed over residual edges" (in place, so a single
 // launch propagates many levels along the thread order); the fixed point is the exact BFS distance
 __global__ __launch_bounds__(kThreads) void relabel_sweep_kernel(Dims g, CutState s, int inner) {
-  const int v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= g.N || !s.node[v] || s.term[v] != 0) return;
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= s.n_free) return;
+  const int v = s.list[i];
   const Vox p = decode(g, v);
   int nb[6];
 #pragma unroll
@@ -214,16 +231,20 @@ __global__ __launch_bounds__(kThreads) void relabel_sweep_kernel(Dims g, CutStat
 }
 
 __global__ __launch_bounds__(kThreads) void count_active_kernel(Dims g, CutState s) {
-  const int v = blockIdx.x * kThreads + threadIdx.x;
+  const int i = blockIdx.x * kThreads + threadIdx.x;
   bool active = false;
-  if (v < g.N && s.node[v] && s.term[v] == 0) active = s.excess[v] > 0 && s.height[v] < g.N;
+  if (i < s.n_free) {
+    const int v = s.list[i];
+    active = s.excess[v] > 0 && s.height[v] < g.N;
+  }
   const unsigned long long b = __ballot(active);
   if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s.flags[1], __popcll(b));
 }
 
 __global__ __launch_bounds__(kThreads) void push_relabel_kernel(Dims g, CutState s, int inner) {
-  const int v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= g.N || !s.node[v] || s.term[v] != 0) return;
+  const int i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= s.n_free) return;
+  const int v = s.list[i];
   if (ld(&s.excess[v]) <= 0) return;
   const Vox p = decode(g, v);
   int nb[6];
@@ -286,6 +307,8 @@ __device__ __forceinline__ int uf_find(int* parent, int i) {
   for (;;) {
     const int q = ld(&parent[i]);
     if (q == i) return i;
+    const int qq = ld(&parent[q]);
+    if (qq != q) atomicMin(&parent[i], qq);  // path halving: qq is an ancestor of i with a smaller index
     i = q;
   }
 }
@@ -336,11 +359,23 @@ __global__ __launch_bounds__(kThreads) void cc_union_kernel(Dims g, int* __restr
 __global__ __launch_bounds__(kThreads) void cc_compress_kernel(Dims g, int* __restrict__ parent,
                                                                int* __restrict__ count, int* __restrict__ ncomp) {
   const int v = blockIdx.x * kThreads + threadIdx.x;
-  if (v >= g.N || ld(&parent[v]) < 0) return;
-  const int r = uf_find(parent, v);
-  if (r != v) st(&parent[v], r);  // r is an ancestor of v: concurrent finds through v stay valid
-  atomicAdd(&count[r], 1);
-  if (r == v) atomicAdd(ncomp, 1);
+  const bool fg = v < g.N && ld(&parent[v]) >= 0;
+  int r = -1;
+  if (fg) {
+    r = uf_find(parent, v);
+    if (r != v) st(&parent[v], r);  // r is an ancestor of v: concurrent finds through v stay valid
+    if (r == v) atomicAdd(ncomp, 1);
+  }
+  // size count, aggregated per wave: the lanes of a wave mostly share one root (a big component funnels
+  // hundreds of thousands of adds into ONE address otherwise)
+  unsigned long long todo = __ballot(fg);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int rl = __shfl(r, leader, 64);
+    const unsigned long long same = __ballot(fg && r == rl) & todo;
+    if ((threadIdx.x & 63) == leader) atomicAdd(&count[rl], __popcll(same));
+    todo &= ~same;
+  }
 }
 
 // round j: the not yet selected root with the largest (count, -index)
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(kThreads) void cc_select_kernel(Dims g, const int* 
     const unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  if ((threadIdx.x & 63) == 0 && key) atomicMax(&sel[j], key);
+  if ((threadIdx.x & 63) == 0 && key > ld(&sel[j])) atomicMax(&sel[j], key);
 }
 
 __global__ void cc_mark_kernel(int* __restrict__ count, const unsigned long long* __restrict__ sel, int j) {
@@ -400,7 +435,7 @@ void launch_graph_build(const float* dens, const float* feat, int X, int Y, int 
 
 size_t graphcut_scratch_bytes(int X, int Y, int Z) {
   const size_t n = (size_t)X * Y * Z;
-  return align256(n * sizeof(long long)) + align256(n * sizeof(int32_t)) + 256;
+  return align256(n * sizeof(long long)) + 2 * align256(n * sizeof(int32_t)) + 256;
 }
 
 // returns hipSuccess or the first failing runtime call
@@ -416,17 +451,25 @@ hipError_t run_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_
   base += align256((size_t)g.N * sizeof(long long));
   s.height = (int32_t*)base;
   base += align256((size_t)g.N * sizeof(int32_t));
+  s.list = (int32_t*)base;
+  base += align256((size_t)g.N * sizeof(int32_t));
   s.flow = (long long*)base;
   s.flags = (int32_t*)(base + 64);
+  s.n_free = 0;
   const int nb = blocks(g.N);
-
-  cut_init_kernel<<<nb, kThreads, 0, stream>>>(g, s);
-  cut_saturate_kernel<<<nb, kThreads, 0, stream>>>(g, s);
 
   int32_t host_flags[2];
   hipError_t err = hipSuccess;
-  const int kRelabelBatch = 8, kRelabelInner = 4;
-  int push_sweeps = 32;
+  cut_init_kernel<<<nb, kThreads, 0, stream>>>(g, s);
+  cut_compact_kernel<<<nb, kThreads, 0, stream>>>(g, s);
+  cut_saturate_kernel<<<nb, kThreads, 0, stream>>>(g, s);
+  if ((err = hipMemcpyAsync(&s.n_free, s.flags + 2, sizeof(int32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+    return err;
+  if ((err = hipStreamSynchronize(stream)) != hipSuccess) return err;
+  const int nf = blocks(s.n_free > 0 ? s.n_free : 1);  // the iterative kernels run over the free nodes only
+  int kRelabelBatch = 2, kRelabelInner = 16, push_sweeps = 16, push_inner = 32, push_max = 64;  // swept on hardware
+  if (const char* e = getenv("VOXE_CUT_PARAMS"))  // tuning hook: "relabel_batch,relabel_inner,push_sweeps,push_inner,push_max"
+    sscanf(e, "%d,%d,%d,%d,%d", &kRelabelBatch, &kRelabelInner, &push_sweeps, &push_inner, &push_max);
   long rounds = 0, relabel_launches = 0, push_launches = 0;
   for (;;) {
     ++rounds;
@@ -435,7 +478,7 @@ hipError_t run_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_
     for (;;) {
       if ((err = hipMemsetAsync(s.flags, 0, sizeof(int32_t), stream)) != hipSuccess) return err;
       for (int i = 0; i < kRelabelBatch; ++i)
-        relabel_sweep_kernel<<<nb, kThreads, 0, stream>>>(g, s, kRelabelInner);
+        relabel_sweep_kernel<<<nf, kThreads, 0, stream>>>(g, s, kRelabelInner);
       relabel_launches += kRelabelBatch;
       if ((err = hipMemcpyAsync(host_flags, s.flags, sizeof(int32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
         return err;
@@ -443,18 +486,18 @@ hipError_t run_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_
       if (!host_flags[0]) break;
     }
     if ((err = hipMemsetAsync(s.flags + 1, 0, sizeof(int32_t), stream)) != hipSuccess) return err;
-    count_active_kernel<<<nb, kThreads, 0, stream>>>(g, s);
+    count_active_kernel<<<nf, kThreads, 0, stream>>>(g, s);
     if ((err = hipMemcpyAsync(host_flags + 1, s.flags + 1, sizeof(int32_t), hipMemcpyDeviceToHost, stream)) !=
         hipSuccess)
       return err;
     if ((err = hipStreamSynchronize(stream)) != hipSuccess) return err;
     if (host_flags[1] == 0) break;
-    for (int i = 0; i < push_sweeps; ++i) push_relabel_kernel<<<nb, kThreads, 0, stream>>>(g, s, 8);
+    for (int i = 0; i < push_sweeps; ++i) push_relabel_kernel<<<nf, kThreads, 0, stream>>>(g, s, push_inner);
     push_launches += push_sweeps;
     if (getenv("VOXE_REFINE_VERBOSE"))
       fprintf(stderr, "[voxe_graphcut] round %ld: %d active voxels, %ld relabel / %ld push launches so far\n", rounds,
               host_flags[1], relabel_launches, push_launches);
-    if (push_sweeps < 512) push_sweeps *= 2;  // the tail moves little flow per relabel: lengthen the bursts
+    if (push_sweeps < push_max) push_sweeps *= 2;  // the tail moves little flow per relabel: lengthen the bursts
   }
   cut_finalize_kernel<<<nb, kThreads, 0, stream>>>(g, s, segment);
   if ((err = hipMemcpyAsync(flow, s.flow, sizeof(int64_t), hipMemcpyDeviceToDevice, stream)) != hipSuccess) return err;
