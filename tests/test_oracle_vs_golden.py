@@ -217,3 +217,31 @@ def test_point_query_forward_and_grads(tag, kind):
     gd, gf = vo.query_bwd(grid, g[tag + "_points"], g[tag + "_g_out"])
     assert rel_l2(gd, g[tag + "_grad_densities"]) < 1e-5
     assert rel_l2(gf, g[tag + "_grad_features"]) < 1e-6
+
+
+def test_edit_trajectory_oracle_vs_reference():
+    """12 Adam steps of a tint edit run by the reference (tests/golden/edit_trajectory.npz) replayed with the oracle's
+    forward, analytic backward and Adam: same losses, same edited frames (BASELINE: within 1e-3 L2)."""
+    z = load_golden("edit_trajectory.npz")
+    aabb = [tuple(r) for r in z["start_aabb"]]
+    grid = vo.Grid(z["start_densities"].copy(), z["start_features"].copy(), aabb, 100.0 / 3.0,
+                   abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    H, W, focal = int(z["hwf"][0]), int(z["hwf"][1]), float(z["hwf"][2])
+    cfg = make_render_cfg(int(z["samples"]), float(z["bounds"][0]), float(z["bounds"][1]), white_bkgd=True)
+    cams = [vo.cast_rays(H, W, focal, z["rot"][i], z["trans"][i]) for i in range(3)]
+    tint = z["tint"].astype(np.float32)
+    state = {n: (np.zeros_like(p), np.zeros_like(p)) for n, p in (("d", grid.densities), ("f", grid.features))}
+    for step in range(int(z["steps"])):
+        o, d = cams[step % 3]
+        col = vo.render_fwd(grid, cfg, o, d)["colour"]
+        diff = col - tint
+        loss = float((diff.astype(np.float64) ** 2).mean())
+        assert abs(loss - z["losses"][step]) < 2e-7, step
+        gd, gf = vo.render_bwd(grid, cfg, o, d, (2.0 / diff.size) * diff)
+        vo.adam_step(grid.densities, gd, *state["d"], 0.03, 0.9, 0.999, 1e-8, step + 1)
+        vo.adam_step(grid.features, gf, *state["f"], 0.03, 0.9, 0.999, 1e-8, step + 1)
+    for i, (o, d) in enumerate(cams):
+        frame = vo.render_fwd(grid, cfg, o, d)["colour"].reshape(H, W, 3)
+        l2 = float(np.sqrt(((frame - z["final_frames"][i]) ** 2).mean()))
+        assert l2 < 1e-5, (i, l2)          # BASELINE bar: 1e-3
+        assert psnr(frame, z["final_frames"][i]) > 90.0

@@ -504,6 +504,44 @@ def g13_refinement():
     save("refine_graph.npz", **out)
 
 
+def g14_edit_trajectory():
+    """A short edit run ENTIRELY by the reference: differentiable `VolumetricModel.render_rays` (jitter off) ->
+    image loss -> `torch.optim.Adam(betas=(0.9, 0.999))` (the optimiser of modules/sds_trainer.py:200-203,332-333),
+    cycling over 3 cameras.  The loss stands in for the SDS gradient (a flat-tint L2, like the stub guidance of the
+    GPU trainer tests).  Fixture = start grid, per-step losses, final grid, final frames: the build must land on the
+    same edited renders (BASELINE.json: "edited renders within 1e-3 L2 of reference")."""
+    out = {}
+    vg = make_grid((32, 32, 32), 3, 77, "softplus")
+    out.update(grid_arrays(vg, "start_"))
+    cfg = SHVoxGridRenderConfig(64, BOUNDS, perturb_sampled_points=False, white_bkgd=True)
+    vm = VolumetricModel(vg, render_sh_voxel_grid, cfg, device=torch.device("cpu"))
+    hw = 48
+    cams = [rays_for(hw, hw, i, 8) for i in (0, 3, 5)]
+    tint = torch.tensor([0.9, 0.2, 0.1])
+    opt = torch.optim.Adam([{"params": vg.parameters(), "lr": 0.03}], betas=(0.9, 0.999))
+    losses = []
+    steps = 12
+    for step in range(steps):
+        rays = cams[step % 3][0]
+        col = vm.render_rays(rays).colour
+        loss = ((col - tint) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    with torch.no_grad():
+        frames = [np_(vm.render_rays(c[0]).colour).reshape(hw, hw, 3) for c in cams]
+    out["hwf"] = np.array([hw, hw, focal_for(hw)], dtype=np.float64)
+    out["bounds"] = np.array(BOUNDS, dtype=np.float64)
+    out["rot"] = np.stack([np_(c[2].rotation) for c in cams])
+    out["trans"] = np.stack([np_(c[2].translation) for c in cams])
+    out["tint"], out["lr"], out["steps"], out["samples"] = tint.numpy(), np.array(0.03), np.array(steps), np.array(64)
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["final_densities"], out["final_features"] = np_(vg.densities), np_(vg.features)
+    out["final_frames"] = np.stack(frames).astype(np.float32)
+    save("edit_trajectory.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -518,3 +556,4 @@ if __name__ == "__main__":
     g11_checkpoint()
     g12_frames()
     g13_refinement()
+    g14_edit_trajectory()
