@@ -130,6 +130,14 @@ int voxe_profile_read(VoxeProfile* out);
 int voxe_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const float* trans,
                    float* rays_o, float* rays_d, void* stream);
 
+/* Rays of SELECTED pixels of K cameras sharing (H, W, focal): what the reconstruction trainer keeps of
+ *   cast_rays x K -> collate_rays -> randperm subset   (modules/trainers.py:290-313, misc.py:60-70,126-138)
+ * without materialising the K full images of rays.  poses: DEVICE [K,3,4] (rotation | translation);
+ * flat_index: DEVICE int64 [B], value = (camera * H + y) * W + x;  rays_o, rays_d: [B,3].  Arithmetic per pixel
+ * identical to voxe_cast_rays (bit-exact same rays).                                                       */
+int voxe_cast_rays_indexed(int32_t H, int32_t W, float focal, const float* poses, int32_t K,
+                           const int64_t* flat_index, int64_t B, float* rays_o, float* rays_d, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Volumetric render, forward -- replaces the whole chain
  *   render_sh_voxel_grid(_attn)            thre3d_reprs/renderers.py:50-163
@@ -282,6 +290,8 @@ int voxe_cc_largest_k(const uint8_t* mask, int32_t X, int32_t Y, int32_t Z, int3
  * ---------------------------------------------------------------------------------------------- */
 int voxe_cpu_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const float* trans,
                        float* rays_o, float* rays_d);
+int voxe_cpu_cast_rays_indexed(int32_t H, int32_t W, float focal, const float* poses, int32_t K,
+                               const int64_t* flat_index, int64_t B, float* rays_o, float* rays_d);
 int voxe_cpu_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                         const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
                         float* colour, float* depth, float* acc, float* disparity);

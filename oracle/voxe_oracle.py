@@ -129,6 +129,16 @@ def cast_rays(H: int, W: int, focal: float, rot, trans):
     return o, d
 
 
+def cast_rays_indexed(H: int, W: int, focal: float, poses, flat_index):
+    poses = _f32(poses).reshape(-1, 12)
+    idx = np.ascontiguousarray(flat_index, dtype=np.int64)
+    o = np.empty((idx.shape[0], 3), np.float32)
+    d = np.empty((idx.shape[0], 3), np.float32)
+    _check(lib().voxe_cpu_cast_rays_indexed(H, W, float(focal), poses.ctypes.data, poses.shape[0], idx.ctypes.data,
+                                            idx.shape[0], o.ctypes.data, d.ctypes.data), "cast_rays_indexed")
+    return o, d
+
+
 def render_fwd(grid: Grid, cfg: abi.VoxeRenderCfg, rays_o, rays_d, jitter=None):
     rays_o, rays_d = _f32(rays_o), _f32(rays_d)
     R = rays_o.shape[0]

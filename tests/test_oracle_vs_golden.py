@@ -245,3 +245,24 @@ def test_edit_trajectory_oracle_vs_reference():
         l2 = float(np.sqrt(((frame - z["final_frames"][i]) ** 2).mean()))
         assert l2 < 1e-5, (i, l2)          # BASELINE bar: 1e-3
         assert psnr(frame, z["final_frames"][i]) > 90.0
+
+
+def test_cast_rays_indexed_equals_full_cast():
+    """the oracle's selected-pixel ray generator == its full-image cast_rays (pinned to the reference above) + index"""
+    g = load_golden("cast_rays.npz")
+    H, W, focal = 23, 31, 40.5
+    rng = np.random.default_rng(3)
+    poses = []
+    for k in range(3):
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        poses.append(np.concatenate([q, rng.standard_normal((3, 1))], axis=1).astype(np.float32))
+    poses = np.stack(poses)
+    full_o, full_d = [], []
+    for p in poses:
+        o, d = vo.cast_rays(H, W, focal, p[:, :3], p[:, 3])
+        full_o.append(o), full_d.append(d)
+    full_o, full_d = np.concatenate(full_o), np.concatenate(full_d)
+    idx = rng.permutation(3 * H * W)[:500]
+    o, d = vo.cast_rays_indexed(H, W, focal, poses, idx)
+    assert np.array_equal(o, full_o[idx]) and np.array_equal(d, full_d[idx])
+    assert len(g.files) > 0

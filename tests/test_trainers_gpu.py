@@ -172,3 +172,29 @@ def test_edit_trajectory_matches_reference_run():
     # Adam divides by sqrt(v): voxels whose gradient is at rounding-noise level still move by ~lr, so the parameters
     # agree less tightly than the renders they produce
     assert np.linalg.norm(d - z["final_densities"]) / np.linalg.norm(z["final_densities"]) < 5e-4
+
+
+def test_selected_pixel_rays_equal_cast_collate_select():
+    """sample_random_rays_and_pixels_from_cameras == cast_rays per camera -> collate -> pixel concat -> randperm subset
+    (the reference's batch assembly), bit for bit, under the same RNG state"""
+    from thre3d_atom.rendering.volumetric.utils.misc import (
+        cast_rays, collate_rays, flatten_rays, sample_random_rays_and_pixels_from_cameras,
+        sample_random_rays_and_pixels_synchronously)
+    from thre3d_atom.utils.imaging_utils import CameraPose
+
+    g = torch.Generator().manual_seed(5)
+    intr = CameraIntrinsics(37, 53, 61.5)
+    poses = torch.stack([torch.cat([p.rotation, p.translation], dim=-1)
+                         for p in (pose_spherical(40.0 * i, -20.0 - 5 * i, 4.0311) for i in range(6))]).to(DEV)
+    images = torch.rand(6, 3, 37, 53, generator=g).to(DEV)
+    picks = [4, 1, 1, 5]
+    torch.manual_seed(77)
+    rays = collate_rays([flatten_rays(cast_rays(intr, CameraPose(poses[i][:, :3], poses[i][:, 3:]), device=DEV)) for i in picks])
+    pixels = torch.cat([images[i].permute(1, 2, 0).reshape(-1, 3) for i in picks])
+    want_rays, want_pix = sample_random_rays_and_pixels_synchronously(rays, pixels, 1000)
+    torch.manual_seed(77)
+    got_rays, got_pix = sample_random_rays_and_pixels_from_cameras(
+        intr, poses[torch.tensor(picks, device=DEV)], images, 1000, image_ids=torch.tensor(picks, device=DEV))
+    assert torch.equal(got_rays.origins, want_rays.origins)
+    assert torch.equal(got_rays.directions, want_rays.directions)
+    assert torch.equal(got_pix, want_pix)

@@ -213,6 +213,16 @@ int voxe_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const fl
   return finish();
 }
 
+int voxe_cast_rays_indexed(int32_t H, int32_t W, float focal, const float* poses, int32_t K,
+                           const int64_t* flat_index, int64_t B, float* rays_o, float* rays_d, void* stream) {
+  if (!poses || !flat_index || !rays_o || !rays_d) return VOXE_ERR_NULL_POINTER;
+  if (H <= 0 || W <= 0 || K <= 0 || B < 0) return VOXE_ERR_BAD_SHAPE;
+  if (B == 0) return VOXE_OK;
+  launch_cast_rays_indexed(H, W, focal, poses, K, (const long long*)flat_index, B, rays_o, rays_d,
+                           (hipStream_t)stream);
+  return finish();
+}
+
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
   return ws_layout(grid, cfg, R).total;

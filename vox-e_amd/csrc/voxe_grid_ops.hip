@@ -40,6 +40,36 @@ void launch_cast_rays(int H, int W, float focal, const float* rot, const float* 
   cast_rays_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(H, W, focal, p, rays_o, rays_d);
 }
 
+__global__ __launch_bounds__(256) void cast_rays_indexed_kernel(int H, int W, float focal, int K,
+                                                                const float* __restrict__ poses,
+                                                                const long long* __restrict__ flat_index, long long B,
+                                                                float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const long long f = flat_index[i];
+  const long long per = (long long)H * W;
+  long long cam = f / per;
+  const long long rem = f - cam * per;
+  cam = cam < 0 ? 0 : (cam >= K ? K - 1 : cam);  // the API validates the range; never read out of bounds
+  const int py = (int)(rem / W), px = (int)(rem - (long long)py * W);
+  const float* pose = poses + cam * 12;            // [3,4] = rotation | translation
+  const float x = (float)px + 0.5f, y = (float)py + 0.5f;
+  const float dx = (x - (float)W * 0.5f) / focal;
+  const float dy = -(y - (float)H * 0.5f) / focal;
+  const float dz = -1.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rays_d[3 * i + r] = pose[4 * r + 0] * dx + pose[4 * r + 1] * dy + pose[4 * r + 2] * dz;
+    rays_o[3 * i + r] = pose[4 * r + 3];
+  }
+}
+
+void launch_cast_rays_indexed(int H, int W, float focal, const float* poses, int K, const long long* flat_index,
+                              long long B, float* rays_o, float* rays_d, hipStream_t st) {
+  cast_rays_indexed_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>(H, W, focal, K, poses, flat_index, B, rays_o,
+                                                                    rays_d);
+}
+
 // ------------------------------------------------------------------------------------------------
 // block reduction helper (double): wave shuffle -> LDS -> lane 0
 // ------------------------------------------------------------------------------------------------

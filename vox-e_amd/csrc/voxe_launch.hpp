@@ -53,6 +53,8 @@ void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, const BwdArgs&
 // voxe_grid_ops.hip
 void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,
                       float* rays_d, hipStream_t st);
+void launch_cast_rays_indexed(int H, int W, float focal, const float* poses, int K, const long long* flat_index,
+                              long long B, float* rays_o, float* rays_d, hipStream_t st);
 size_t dcl_scratch_bytes(long long n);
 void launch_dcl(const float* a, const float* b, long long n, float grad_scale, float* loss_out,
                 float* d_a, int accumulate, void* scratch, hipStream_t st);

@@ -16,12 +16,7 @@ from torch import Tensor
 
 from thre3d_atom.modules.optim import VoxeAdam
 from thre3d_atom.modules.volumetric_model import VolumetricModel
-from thre3d_atom.rendering.volumetric.utils.misc import (
-    cast_rays,
-    collate_rays,
-    flatten_rays,
-    sample_random_rays_and_pixels_synchronously,
-)
+from thre3d_atom.rendering.volumetric.utils.misc import sample_random_rays_and_pixels_from_cameras
 from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid
 from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, scale_voxel_grid_with_required_output_size
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
@@ -87,13 +82,11 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
         for it in range(1, num_iterations_per_stage + 1):
             t0 = time.perf_counter()
-            picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).tolist()
-            rays = collate_rays([
-                flatten_rays(cast_rays(intr, CameraPose(data.poses[i][:, :3], data.poses[i][:, 3:]), device=device))
-                for i in picks
-            ])
-            pixels = torch.cat([data.images[i].permute(1, 2, 0).reshape(-1, data.images.shape[1]) for i in picks])
-            rays_batch, pixels_batch = sample_random_rays_and_pixels_synchronously(rays, pixels, ray_batch_size)
+            # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
+            # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
+            picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
+            rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
+                intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks)
 
             specular = vol_mod.render_rays(rays_batch).colour
             loss = torch.nn.functional.l1_loss(specular, pixels_batch)

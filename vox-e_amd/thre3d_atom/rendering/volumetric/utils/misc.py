@@ -66,6 +66,26 @@ def sample_random_rays_and_pixels_synchronously(rays: Rays, pixels: Tensor, samp
     return picked_rays, picked_pixels
 
 
+def sample_random_rays_and_pixels_from_cameras(camera_intrinsics: CameraIntrinsics, poses: Tensor, images: Tensor,
+                                               sample_size: int, image_ids: Any = None) -> Tuple[Rays, Tensor]:
+    """What the reconstruction loop keeps of `cast_rays` per camera -> `collate_rays` -> pixel concat ->
+    `sample_random_rays_and_pixels_synchronously` (modules/trainers.py:290-313), computed for the selected pixels
+    only: the same `randperm` draw picks flat (camera, y, x) indices, the HIP kernel casts just those rays and the
+    target pixels are gathered straight from `images`.  Bit-identical rays / pixels, no full-image ray buffers, no
+    host synchronisation.   poses [K,3,4] and images [N,C,H,W] on the GPU; `image_ids` [K] maps the K cameras to
+    rows of `images` (default: the first K)."""
+    height, width, focal = camera_intrinsics
+    K = int(poses.shape[0])
+    per = int(height) * int(width)
+    subset = torch.randperm(K * per, dtype=torch.long, device=images.device)[:sample_size]
+    origins, directions = _ops.cast_rays_indexed(height, width, focal, poses, subset)
+    cam = torch.div(subset, per, rounding_mode="floor")
+    rem = subset - cam * per
+    rows = cam if image_ids is None else torch.as_tensor(image_ids, device=images.device, dtype=torch.long)[cam]
+    pixels = images[rows, :, torch.div(rem, int(width), rounding_mode="floor"), rem % int(width)]
+    return Rays(origins, directions), pixels
+
+
 def sample_rays_and_pixels_synchronously(rays: Rays, pixels: Tensor, indices: Any, sample_size: int):
     """Image-level variant: rays [B,H,W,3], pixels [B,C,H,W]; returns flat rays/pixels of the picked
     images plus their dataset indices (misc.py:140-158)."""

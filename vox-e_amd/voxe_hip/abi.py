@@ -86,6 +86,7 @@ _RC = C.POINTER(VoxeRenderCfg)
 # name -> (restype, argtypes, takes_workspace, takes_stream); the oracle twin drops the last two groups
 _COMMON = {
     "cast_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], False, True),
+    "cast_rays_indexed": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _P, C.c_int32, _P, C.c_int64, _P, _P], False, True),
     "render_fwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P], True, True),
     "render_bwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32], True, True),
     "sample_probe": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P], True, True),

@@ -306,6 +306,27 @@ def cast_rays(height: int, width: int, focal: float, rotation, translation, devi
     return ro, rd
 
 
+def cast_rays_indexed(height: int, width: int, focal: float, poses: torch.Tensor,
+                      flat_index: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rays of selected pixels of K cameras: poses [K,3,4] and flat_index int64 [B] = (camera*H + y)*W + x, both on
+    the GPU; -> rays_o, rays_d [B,3].  No host synchronisation, no full-image ray buffers."""
+    require_device(poses, "cast_rays_indexed")
+    require_device(flat_index, "cast_rays_indexed")
+    if poses.dim() != 3 or tuple(poses.shape[1:]) != (3, 4) or flat_index.dtype != torch.int64 or flat_index.dim() != 1:
+        raise VoxeError("cast_rays_indexed: poses must be [K,3,4] float, flat_index int64 [B]")
+    device = poses.device
+    ensure_gfx950(device)
+    p = f32c(poses)
+    idx = flat_index.contiguous()
+    n = int(idx.shape[0])
+    with torch.cuda.device(device):
+        ro = torch.empty((n, 3), dtype=torch.float32, device=device)
+        rd = torch.empty((n, 3), dtype=torch.float32, device=device)
+        check(lib().voxe_cast_rays_indexed(int(height), int(width), float(focal), ptr(p), int(p.shape[0]), ptr(idx), n,
+                                           ptr(ro), ptr(rd), stream_ptr(device)), "voxe_cast_rays_indexed")
+    return ro, rd
+
+
 # ------------------------------------------------------------------------------------------------
 # whole-grid passes
 # ------------------------------------------------------------------------------------------------
