@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--term-eps", type=float, default=0.0, help="early ray termination (NOT in the reference); 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
-                    help="side of the image the CPU oracle is timed on (0: sized by a probe for ~5 s of wall time)")
+                    help="side of the image the CPU oracle is timed on (0: the full image if a probe says it fits ~30 s)")
     ap.add_argument("--no-adam", action="store_true")
     ap.add_argument("--no-jitter", action="store_true")
     ap.add_argument("--ray-order", choices=["image", "linear", "random"], default="image",
@@ -213,12 +213,13 @@ def main():
             vo.render_bwd(grid, cfg, o, d, gc)
             return time.perf_counter() - t1
 
-        # bounded sample: a 64x64 probe sizes the timed image for ~5 s of wall time (never more than the GPU's image)
+        # bounded sample: the GPU's full image when a 128x128 probe says it fits ~30 s of wall time, a smaller image otherwise
         hw = args.cpu_sample
         if hw <= 0:
             cpu_pass(64)                      # thread start-up / first touch
-            probe = cpu_pass(64)
-            hw = int(max(64, min(HW, 64 * (5.0 / max(probe, 1e-3)) ** 0.5)))
+            probe = cpu_pass(128)
+            full = probe * (HW / 128.0) ** 2  # upper bound: the per-call fixed cost (gradient grids) does not scale
+            hw = HW if full <= 30.0 else int(max(128, 128 * (20.0 / max(probe, 1e-3)) ** 0.5))
         dt = cpu_pass(hw)
         threads = vo.num_threads()
         cpu_baseline = {

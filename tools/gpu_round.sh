@@ -15,8 +15,13 @@ timeout 300 python bench.py --image 100 --no-cpu-baseline 2>/dev/null | tail -1 
 timeout 300 python bench.py --grid 256 --image 800 --no-cpu-baseline --steps 10 2>/dev/null | tail -1 > $O/bench_256_800.json
 timeout 300 env VOXE_BWD_MODE=scatter python bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $O/bench_400_scatter_bwd.json
 timeout 300 python bench.py --term-eps 1e-4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_400_term1e-4.json
+timeout 300 python bench.py --image 200 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_200.json
+timeout 300 python tools/refine_bench.py 160 2>/dev/null | tail -4 > $O/refine_bench.txt; cat $O/refine_bench.txt
+timeout 300 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench.txt; cat $O/recon_bench.txt
 for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_refine -o ${TAG}_refine -- python $GRAFT_REPO_ROOT/tools/refine_bench.py 160 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+head -12 $O/prof_refine/${TAG}_refine_kernel_stats.csv | cut -c1-160
 head -8 $O/prof/${TAG}_kernel_stats.csv | cut -c1-200
 bash tools/gpu_pmc.sh > $O/pmc.txt 2>&1; tail -3 $O/pmc.txt | cut -c1-300
