@@ -22,6 +22,7 @@
 // Gradient formulas: see render_bwd_kernel (voxe_render.hip).  Reference: autograd through
 // thre3d_atom/rendering/volumetric/{sample,process,accumulate}.py and thre3d_reprs/voxels.py.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "voxe_device.hpp"
 #include "voxe_launch.hpp"
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     const float* __restrict__ colour, const float* __restrict__ depth,
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
-    const float* __restrict__ ray_state, float* __restrict__ gpacked) {
+    const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit) {
   constexpr int C = COUT + 1;
   __shared__ double win[C * kPlane];
   const int lane = threadIdx.x;
@@ -108,9 +109,12 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
   const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
   // a block = (pixel tile, depth segment): the segments of one tile are consecutive logical indices
   const int nseg = num_segments(c.S);
-  const int logical = logical_tile(c, ntx * nseg, nty);
+  // qsplit == 4 (small images that leave the chip under-filled): the four quadrant passes of a tile run as four
+  // blocks side by side instead of one after the other
+  const int logical = logical_tile(c, ntx * nseg * qsplit, nty);
   if (logical < 0) return;  // launch padding (wave-uniform)
-  const int seg = logical % nseg, tile = logical / nseg;
+  const int quad = logical % qsplit, rest = logical / qsplit;
+  const int seg = rest % nseg, tile = rest / nseg;
   const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
   const int ty = tile / ntx, tx = tile - ty * ntx;
   const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
@@ -121,23 +125,28 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
   rc.init(g, c, r, rays_o, rays_d, jitter);
 
   // ---- pixel footprint: does the 8x8 tile fit the 8x8 lateral LDS window? ------------------------------
-  // Low-resolution images have pixels farther apart than a voxel; then the tile is processed as four 4x4
-  // quadrants (16 lanes each) in consecutive passes over the same window, so the gradient is still combined in
-  // LDS instead of falling back to one global atomic per corner and channel.  (Wave-uniform decision.)
-  int npass = 1;
+  // Lower-resolution images have pixels farther apart; a tile whose footprint exceeds the window is processed as two
+  // 8x4 / 4x8 halves (32 lanes each) or, failing that, four 4x4 quadrants (16 lanes each) in consecutive passes over
+  // the same window, so the gradient is still combined in LDS instead of falling back to one global atomic per
+  // corner and channel.  (Wave-uniform decision.)
+  // split: 0 = whole tile, 1 = left / right halves, 2 = top / bottom halves (2 passes of 32 lanes), 3 = quadrants
+  int split = 0;
   {
     const unsigned long long am = __ballot(alive);
     if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
       const int N[3] = {g.X, g.Y, g.Z};
       const float zref = readlane_f32(rc.dg.zlin(ke), 0);
-      float ext = 0.0f;
+      float full = 0.0f, halfx = 0.0f, halfy = 0.0f;  // lateral extent (voxels) of the tile / of its halves
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float s = g.scale[a] * 0.5f * (float)N[a];
         const float d0 = readlane_f32(rc.d[a], 0), dx = readlane_f32(rc.d[a], 1) - d0, dy = readlane_f32(rc.d[a], 8) - d0;
-        ext = fmaxf(ext, 7.0f * (fabsf(dx) + fabsf(dy)) * fabsf(s) * zref);
+        const float k = fabsf(s) * zref, ex = fabsf(dx) * k, ey = fabsf(dy) * k;
+        full = fmaxf(full, 7.0f * (ex + ey));
+        halfx = fmaxf(halfx, 3.0f * ex + 7.0f * ey);
+        halfy = fmaxf(halfy, 7.0f * ex + 3.0f * ey);
       }
-      if (ext > 5.5f) npass = 4;
+      if (full > 5.5f) split = (fminf(halfx, halfy) <= 5.5f) ? (halfx <= halfy ? 1 : 2) : 3;
     }
   }
   auto run_pass = [&](const bool alive_q, const int centre_lane) {
@@ -403,12 +412,23 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     }
 
   };
-  if (npass == 1) {
+  // lanes and reference lane of part q under the chosen split
+  auto in_part = [&](int q) {
+    const int hx = (lane >> 2) & 1, hy = (lane >> 5) & 1;
+    return split == 1 ? hx == q : (split == 2 ? hy == q : hx + 2 * hy == q);
+  };
+  auto centre_of = [&](int q) { return split == 1 ? 26 + 4 * q : (split == 2 ? 19 + 32 * q : 18 + 4 * (q & 1) + 32 * (q >> 1)); };
+  const int nparts = split == 0 ? 1 : (split == 3 ? 4 : 2);
+  if (qsplit == 4) {  // the parts of a tile run as sibling blocks; siblings without a part have nothing to do
+    if (quad < nparts) {
+      if (split == 0) run_pass(alive, 27);
+      else run_pass(alive && in_part(quad), centre_of(quad));
+    }
+  } else if (split == 0) {
     run_pass(alive, 27);
   } else {
-    for (int q = 0; q < 4; ++q) {
-      // quadrant q = pixels [4 (q & 1), +4) x [4 (q >> 1), +4); its centre-most lane is (lx0 + 2, ly0 + 2)
-      run_pass(alive && (((lane >> 2) & 1) + 2 * ((lane >> 5) & 1)) == q, 18 + 4 * (q & 1) + 32 * (q >> 1));
+    for (int q = 0; q < nparts; ++q) {
+      run_pass(alive && in_part(q), centre_of(q));
       __syncthreads();
     }
   }
@@ -418,11 +438,17 @@ bool tile_bwd_supported(const DevCfg& c, int deg) { return c.image_width > 0 && 
 
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
   const long long W = c.image_width, H = c.R / W;
-  const int nb = blocks_for_tiles(c.map_mode, ((W + 7) / 8) * num_segments(c.S), (H + 7) / 8);
+  // The parts (halves / quadrants) of a tile run as sibling blocks instead of consecutive passes while the launch is
+  // small enough for the extra blocks to find idle CUs (LDS bounds residency at 9 blocks per CU, 2304 on the chip);
+  // measured cross-over on MI355X: better up to 200x200 (5000 tile-segments), worse from 232x232 (6728)
+  static const int env_q = [] { const char* e = getenv("VOXE_TILE_QSPLIT"); return e ? atoi(e) : 0; }();
+  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S);
+  const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 5400 ? 4 : 1);
+  const int nb = blocks_for_tiles(c.map_mode, ((W + 7) / 8) * num_segments(c.S) * qsplit, (H + 7) / 8);
 #define VOXE_TBWD(COUT, WD, WF)                                                                   \
   render_bwd_tile_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                   \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.ray_state, a.gpacked)
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit)
   if (c.attn) {
     if (a.want_d && a.want_f) VOXE_TBWD(1, true, true);
     else if (a.want_d) VOXE_TBWD(1, true, false);
