@@ -472,7 +472,7 @@ hipError_t run_graphcut(const uint8_t* node_mask, const int8_t* terminal, int32_
     sscanf(e, "%d,%d,%d,%d,%d", &kRelabelBatch, &kRelabelInner, &push_sweeps, &push_inner, &push_max);
   long rounds = 0, relabel_launches = 0, push_launches = 0;
   for (;;) {
-    ++rounds;
+    if (++rounds > 100000) return hipErrorLaunchFailure;  // never observed; push-relabel terminates, this only bounds a bug
     // exact distances to the sink seeds over the residual graph
     relabel_init_kernel<<<nb, kThreads, 0, stream>>>(g, s);
     for (;;) {
