@@ -205,3 +205,34 @@ def test_datasets_on_disk_format_and_downsampling(tmp_path):
     half = ds.downsampled(2.0)
     assert half.images.shape == (3, 3, 6, 8) and half.camera_intrinsics == CameraIntrinsics(6, 8, 10.0)
     assert isinstance(half, InMemoryPosedImages)
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under vox-e_amd/ nor the entry scripts may import / load it, and
+    importing the whole product package must not pull it in"""
+    import ast
+    import glob
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "vox-e_amd", "**", "*.py"), recursive=True)
+    files += [os.path.join(root, n) for n in ("render_sh_based_voxel_grid.py", "edit_pretrained_relu_field.py",
+                                              "refine_edited_relu_field.py",
+                                              "train_sh_based_voxel_grid_with_posed_images.py")]
+    for path in files:
+        tree = ast.parse(open(path).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n.split(".")[0] == "oracle" or "voxe_oracle" in n for n in names), path
+        if not path.endswith(os.path.join("voxe_hip", "abi.py")):  # (its docstring names both libraries the ABI describes)
+            assert "libvoxe_oracle" not in open(path).read(), path
+    code = ("import sys; sys.path.insert(0, %r); import voxe_hip.ops, thre3d_atom.modules.sds_trainer, "
+            "thre3d_atom.modules.trainers, thre3d_atom.modules.attn_grid_trainer, thre3d_atom.modules.refinement_functions; "
+            "bad = [m for m in sys.modules if m.split('.')[0] == 'oracle' or 'voxe_oracle' in m]; "
+            "assert not bad, bad" % os.path.join(root, "vox-e_amd"))
+    subprocess.check_call([sys.executable, "-c", code])
