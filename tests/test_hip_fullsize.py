@@ -62,6 +62,19 @@ def test_100x100_backward_vs_oracle():
     assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
 
 
+@pytest.mark.parametrize("hw,cam", [(64, 5), (120, 9), (160, 5), (200, 2), (266, 9), (266, 40), (320, 7)])
+def test_mid_resolution_backward_vs_oracle(hw, cam):
+    """image sizes between 64 and 320 pixels walk through every tile decomposition of the LDS-window backward (whole
+    tile, 32-lane halves, 16-lane quadrants; as consecutive passes or as sibling blocks): gradients vs the oracle"""
+    grid = _grid("sphere" if cam % 2 else "random")
+    o, d = _rays(hw, i=cam)
+    cfg = make_render_cfg(S, NEAR, FAR, white_bkgd=True)
+    gc = np.random.default_rng(hw + cam).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, image_width=hw)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
+
+
 def test_400x400_backward_properties():
     grid = _grid("random")
     o, d = _rays(400, i=11)
