@@ -36,7 +36,22 @@ constexpr int kLayerSlots = kLat * kLat; // 64
 constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
 // channel planes are padded by a few doubles so the C channels of one voxel, read together by the
 // flush, sit in different bank groups; the plane offset folds into the ds instruction's immediate
-constexpr int kPlane = kWinSlots + 6;   // padding swept on hardware (0: 1.05 ms, 8: 0.98, 16: 1.05, 6: 0.953 per 400x400 backward)
+#ifndef VOXE_TILE_PAD
+#define VOXE_TILE_PAD 6
+#endif
+#ifndef VOXE_TILE_ROT
+#define VOXE_TILE_ROT 25
+#endif
+#ifndef VOXE_TILE_LANEROT
+#define VOXE_TILE_LANEROT(lane) (((lane) & 7) + 3 * ((lane) >> 3))
+#endif
+#ifndef VOXE_TILE_CROT
+#define VOXE_TILE_CROT(lane) (lane)
+#endif
+// LDS mapping constants, swept on hardware with tools/variants.py + tools/ab_variants.sh (three cameras): channel
+// rotation by lane & 3 instead of (lane >> 1) & 3: backward -6.5 %; layer rotation 9 / 17 / 25 ~ equal, 21 +0.4 %;
+// plane padding 6 ~ 10 < 2 < 4 << 8 (+35 %: bank aliasing)
+constexpr int kPlane = kWinSlots + VOXE_TILE_PAD;   // padding swept on hardware (0: 1.05 ms, 8: 0.98, 16: 1.05, 6: 0.953 per 400x400 backward)
 
 // wave-wide integer min / max, result wave-uniform (DPP inside rows of 16, readlane across rows).
 // Must be called with all 64 lanes active.
@@ -67,7 +82,7 @@ struct Window {
   __device__ __forceinline__ int off_v(int im) const { return (int)floorf(Av + Bv * (float)im) - 3; }
   // storage position of lateral cell (a, b) inside its layer: rotated per layer so that the same (a, b)
   // of neighbouring layers lands in different LDS banks
-  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + 21 * (key & (kRing - 1))) & 63; }
+  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + VOXE_TILE_ROT * (key & (kRing - 1))) & 63; }
 };
 template <int C>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
@@ -92,6 +107,7 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
 }
 
 template <int COUT, bool WANT_D, bool WANT_F>
+// launch bounds swept: (64, 3) best; 2 and 4..6 are 6-9 % slower (register budget vs the LDS-bound residency)
 __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
     w.base = wave_min_i32(first_key);
     __syncthreads();  // window zeroed
 
-    const int rot = ((lane & 7) + 3 * (lane >> 3)) & 7;  // per-lane corner permutation: neighbours in the tile differ
+    const int rot = VOXE_TILE_LANEROT(lane) & 7;  // per-lane corner permutation: neighbours in the tile differ
     for (int k = kmin; k <= kmax; ++k) {
       const bool on = has && (k >= k_lo) && (k <= k_hi);
       if (on) {
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
               fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
                      ((unsigned)b0 < (unsigned)(kLat - 1));
               lofs[s] = (key & (kRing - 1)) * kLayerSlots;
-              ab0[s] = a0 * kLat + b0 + 21 * (key & (kRing - 1));  // + the per-layer rotation of layer_pos()
+              ab0[s] = a0 * kLat + b0 + VOXE_TILE_ROT * (key & (kRing - 1));  // + the per-layer rotation of layer_pos()
             }
             if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
               // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
               float gr[C];
               int poff[C];
               if constexpr (kAllCh && C == 4) {
-                const int crot = lane >> 1 & 3;
+                const int crot = VOXE_TILE_CROT(lane) & 3;
                 const bool c1 = crot & 1, c2 = crot & 2;
                 // gr[j] = gch[(j + crot) & 3], poff[j] = plane offset of that channel
                 const float a0 = c1 ? gch[1] : gch[0], a1 = c1 ? gch[2] : gch[1], a2 = c1 ? gch[3] : gch[2], a3 = c1 ? gch[0] : gch[3];

@@ -8,7 +8,8 @@ import torch
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvoxe_hip.so")
+# VOXE_HIP_LIB: load another build of the same library (kernel-variant A/B runs, tools/variants.py)
+LIB_PATH = os.environ.get("VOXE_HIP_LIB") or os.path.join(_HERE, "libvoxe_hip.so")
 
 _lib = None
 _lock = threading.Lock()
