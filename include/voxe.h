@@ -98,7 +98,9 @@ typedef struct VoxeRenderCfg {
 } VoxeRenderCfg;
 
 /* depth-segment length of the image-ordered backward (samples per segment) */
+#ifndef VOXE_SEGMENT_SAMPLES
 #define VOXE_SEGMENT_SAMPLES 32
+#endif
 
 /* ------------------------------------------------------------------------------------------------
  * Library / device

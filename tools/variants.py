@@ -15,10 +15,16 @@ def main():
     b.build()
     out_dir = os.path.join(ROOT, "variants")
     os.makedirs(out_dir, exist_ok=True)
-    src = sys.argv[0] and os.path.join(b.CSRC, os.environ.get("VARIANT_SRC", "voxe_render_tile.hip"))
-    obj = os.path.join(out_dir, f"{os.path.basename(src)[:-4]}_{tag}.o")
-    subprocess.check_call([b.hipcc(), *b.FLAGS, *flags, "-I", b.INCLUDE, "-c", src, "-o", obj])
-    objs = [os.path.join(b.OBJ_DIR, s.replace(".hip", ".o")) for s in b.SOURCES if s != os.path.basename(src)] + [obj]
+    which = os.environ.get("VARIANT_SRC", "voxe_render_tile.hip")   # one source file, or "all"
+    rebuilt = b.SOURCES if which == "all" else [which]
+    objs = []
+    for name in b.SOURCES:
+        if name in rebuilt:
+            obj = os.path.join(out_dir, f"{name[:-4]}_{tag}.o")
+            subprocess.check_call([b.hipcc(), *b.FLAGS, *flags, "-I", b.INCLUDE, "-c", os.path.join(b.CSRC, name), "-o", obj])
+        else:
+            obj = os.path.join(b.OBJ_DIR, name.replace(".hip", ".o"))
+        objs.append(obj)
     lib = os.path.join(out_dir, f"libvoxe_hip_{tag}.so")
     subprocess.check_call([b.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
     print(lib)

@@ -190,12 +190,21 @@ __global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c
   const int nseg = num_segments(c.S);
   // one thread = `fseg` consecutive depth segments of one ray (fseg = 1: finest split, used for small images)
   const int ncoarse = (nseg + fseg - 1) / fseg;
-  // consecutive blocks = the coarse segments of one ray block, skewed by the ray-block index: hardware places
-  // block b on XCD b % 8, and an un-skewed map would give XCD j segment j of EVERY tile -- the first and last
-  // segments lie mostly outside the AABB, so those XCDs would idle while the middle ones do all the work.
-  const int cseg = (blockIdx.x + blockIdx.x / ncoarse) % ncoarse;
+  // Block order: hardware places block b on XCD b % 8 and, inside an XCD, round-robin on its 32 CUs.  The first and
+  // last depth segments lie mostly outside the AABB, so segment indices must not be periodic in b: each XCD walks its
+  // band of ray blocks SEGMENT-MAJOR (all its ray blocks at coarse segment 0, then 1, ...), see render_bwd_tile_kernel.
+  const int nrb = gridDim.x / ncoarse;  // ray blocks (a multiple of 8)
+  int cseg, rb;
+  if (c.map_mode == 0) {
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, per = nrb >> 3;
+    cseg = slot / per;
+    rb = ((slot - cseg * per) << 3) + x;
+  } else {
+    cseg = (blockIdx.x + blockIdx.x / ncoarse) % ncoarse;
+    rb = blockIdx.x / ncoarse;
+  }
   long long r;
-  if (!map_ray_block(c, blockIdx.x / ncoarse, gridDim.x / ncoarse, r)) return;
+  if (!map_ray_block(c, rb, nrb, r)) return;
   RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
   const int s_end = min(nseg, (cseg + 1) * fseg);
@@ -557,12 +566,13 @@ static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d
 template <int COUT, int NCM, int NCU>
 static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S);
-  // With few rays (a 100x100 image is 40 blocks) the chip is starved: split the march into depth segments.
-  // At 400x400 there are enough waves and the segmented variant is ~20 % slower (per-segment ray setup, extra
-  // partial-result traffic, more lock-step waste), so it is used below kSegFwdMaxRays only.
+  // The march of every ray block is split into depth segments handled by different blocks (a 100x100 image alone
+  // is 40 blocks; at 400x400 the finer split hides the gather latency better): with the segment-major block order
+  // one 32-sample segment per task is fastest at every image size (400x400, mean of three cameras: fseg 1 / 2 / 4 / 8
+  // = 0.273 / 0.286 / 0.291 / 0.326 ms).
   if (a.segbuf && nseg > 1 && !(c.term_eps > 0.0f)) {
     static const int env_fseg = [] { const char* e = getenv("VOXE_FSEG"); return e ? atoi(e) : 0; }();
-    int fseg = c.R <= 65536 ? 1 : 4;
+    int fseg = 1;
     if (env_fseg > 0) fseg = env_fseg;
     const int ncoarse = (nseg + fseg - 1) / fseg;
     render_fwd_seg_kernel<COUT, NCM, NCU><<<blocks_for(c) * ncoarse, 256, 0, st>>>(

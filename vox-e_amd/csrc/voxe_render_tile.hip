@@ -123,14 +123,31 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
   // ---- tile -> ray (XCD-banded like map_ray) ----------------------------------------------------
   const int W = c.image_width, H = (int)(c.R / W);
   const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
-  // a block = (pixel tile, depth segment): the segments of one tile are consecutive logical indices
+  // a block = (pixel tile, depth segment[, part]).  qsplit == 4 (small images that leave the chip under-filled): the
+  // parts of a tile run as sibling blocks instead of one after the other.
+  // Block order (default band mode): XCD x = blockIdx % 8 owns a contiguous band of tiles and walks it SEGMENT-MAJOR:
+  // all its tiles at depth segment 0, then segment 1, ...  The segments in front of / behind the volume are empty and
+  // retire at once; with the segments of a tile on consecutive blocks instead, "empty" and "full" blocks alternate
+  // with period nseg, which aliases with the round-robin placement on the 32 CUs of an XCD whenever nseg divides 32
+  // (measured: kSegLen 32 -> 0.87 ms, 24 -> 0.68 ms, 48 -> 0.76 ms for the same work before this ordering).
   const int nseg = num_segments(c.S);
-  // qsplit == 4 (small images that leave the chip under-filled): the four quadrant passes of a tile run as four
-  // blocks side by side instead of one after the other
-  const int logical = logical_tile(c, ntx * nseg * qsplit, nty);
-  if (logical < 0) return;  // launch padding (wave-uniform)
-  const int quad = logical % qsplit, rest = logical / qsplit;
-  const int seg = rest % nseg, tile = rest / nseg;
+  const int ntiles = ntx * nty;
+  int quad, seg, tile;
+  if (c.map_mode == 0) {
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tpb = (ntiles + 7) >> 3;  // tiles per XCD band
+    const int part = slot / tpb;        // (part, segment) major, tile minor: sibling parts that have nothing to do
+    quad = part / nseg;                 // (a tile that fits the window whole) are not periodic in the block index either
+    seg = part - quad * nseg;
+    tile = x * tpb + slot % tpb;
+    if (quad >= qsplit || tile >= ntiles) return;  // launch padding (wave-uniform)
+  } else {
+    const int logical = logical_tile(c, ntx * nseg * qsplit, nty);
+    if (logical < 0) return;
+    quad = logical % qsplit;
+    const int rest = logical / qsplit;
+    seg = rest % nseg, tile = rest / nseg;
+  }
   const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
   const int ty = tile / ntx, tx = tile - ty * ntx;
   const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
@@ -455,12 +472,15 @@ bool tile_bwd_supported(const DevCfg& c, int deg) { return c.image_width > 0 && 
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
   const long long W = c.image_width, H = c.R / W;
   // The parts (halves / quadrants) of a tile run as sibling blocks instead of consecutive passes while the launch is
-  // small enough for the extra blocks to find idle CUs (LDS bounds residency at 9 blocks per CU, 2304 on the chip);
-  // measured cross-over on MI355X: better up to 200x200 (5000 tile-segments), worse from 232x232 (6728)
+  // small enough for the extra blocks to pay off (LDS bounds residency at 9 blocks per CU, 2304 on the chip; siblings
+  // of a tile that fits the window whole retire at once); measured cross-over on MI355X with the segment-major block
+  // order: 15 % better at 266x266 (9248 tile-segments), equal at 320x320 (12800), 3 % worse at 400x400, 8 % at 800x800
   static const int env_q = [] { const char* e = getenv("VOXE_TILE_QSPLIT"); return e ? atoi(e) : 0; }();
   const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S);
-  const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 5400 ? 4 : 1);
-  const int nb = blocks_for_tiles(c.map_mode, ((W + 7) / 8) * num_segments(c.S) * qsplit, (H + 7) / 8);
+  const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
+  const long long ntiles = ((W + 7) / 8) * ((H + 7) / 8);
+  const int nb = c.map_mode == 0 ? (int)(8 * ((ntiles + 7) / 8) * num_segments(c.S) * qsplit)
+                                 : blocks_for_tiles(c.map_mode, ((W + 7) / 8) * num_segments(c.S) * qsplit, (H + 7) / 8);
 #define VOXE_TBWD(COUT, WD, WF)                                                                   \
   render_bwd_tile_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                   \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
