@@ -30,7 +30,12 @@
 
 namespace voxe {
 
-constexpr int kRing = 8;                 // live layers along the march axis
+#ifndef VOXE_TILE_RING
+#define VOXE_TILE_RING 8
+#endif
+// swept: 4 is 11 % faster for views along a grid axis but overflows the window for oblique ones (2.1x slower),
+// 16 halves the residency (1.9x slower)
+constexpr int kRing = VOXE_TILE_RING;    // live layers along the march axis (power of two)
 constexpr int kLat = 8;                  // lateral window edge (voxels)
 constexpr int kLayerSlots = kLat * kLat; // 64
 constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
