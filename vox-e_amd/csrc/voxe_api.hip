@@ -26,11 +26,11 @@ int bwd_mode_override() {
 bool force_scatter_bwd() { return bwd_mode_override() == 1; }
 bool force_no_tile_bwd() { return bwd_mode_override() != 0; }
 
-// VOXE_TILE_MAP = band (default) | linear | rows : block -> tile mapping (see logical_tile())
+// VOXE_TILE_MAP = interleave (default) | band | rows : block -> tile mapping (see logical_tile_of())
 int tile_map_mode() {
   static const int mode = [] {
     const char* e = getenv("VOXE_TILE_MAP");
-    if (e && strcmp(e, "linear") == 0) return 1;
+    if (e && strcmp(e, "band") == 0) return 1;
     if (e && strcmp(e, "rows") == 0) return 2;
     return 0;
   }();

@@ -190,19 +190,12 @@ __global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c
   const int nseg = num_segments(c.S);
   // one thread = `fseg` consecutive depth segments of one ray (fseg = 1: finest split, used for small images)
   const int ncoarse = (nseg + fseg - 1) / fseg;
-  // Block order: hardware places block b on XCD b % 8 and, inside an XCD, round-robin on its 32 CUs.  The first and
-  // last depth segments lie mostly outside the AABB, so segment indices must not be periodic in b: each XCD walks its
-  // band of ray blocks SEGMENT-MAJOR (all its ray blocks at coarse segment 0, then 1, ...), see render_bwd_tile_kernel.
+  // Block order: SEGMENT-MAJOR -- all ray blocks at coarse segment 0, then all at segment 1, ...  The first and last
+  // depth segments lie mostly outside the AABB and retire at once; if the segments of one ray block sat on consecutive
+  // blocks, "empty" and "full" blocks would alternate with period ncoarse, which aliases with the placement of block b
+  // on XCD b % 8 and round-robin on its 32 CUs (see render_bwd_tile_kernel).
   const int nrb = gridDim.x / ncoarse;  // ray blocks (a multiple of 8)
-  int cseg, rb;
-  if (c.map_mode == 0) {
-    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, per = nrb >> 3;
-    cseg = slot / per;
-    rb = ((slot - cseg * per) << 3) + x;
-  } else {
-    cseg = (blockIdx.x + blockIdx.x / ncoarse) % ncoarse;
-    rb = blockIdx.x / ncoarse;
-  }
+  const int cseg = blockIdx.x / nrb, rb = blockIdx.x - cseg * nrb;
   long long r;
   if (!map_ray_block(c, rb, nrb, r)) return;
   RayCtx<COUT, NCM, NCU> rc;

@@ -8,9 +8,11 @@ namespace voxe {
 
 // ------------------------------------------------------------------------------------------------
 // Thread -> ray mapping.
-//   * XCD-aware: hardware places block b on XCD b % 8 (observed, not contractual; only speed depends
-//     on it).  Logical work item = (b % 8) * ceil(nb/8) + b / 8, so each XCD walks a contiguous
-//     band of the image and its private 4 MiB L2 sees a compact part of the frustum.
+//   * XCD-aware: hardware places block b on XCD b % 8 and, inside an XCD, round-robin on its 32 CUs (observed,
+//     not contractual; only speed depends on it).  Default: tile = block index, i.e. neighbouring tiles on
+//     different XCDs.  The grid lives in the 256 MB Infinity Cache whatever the XCD, so balancing the eight XCDs
+//     (tiles near the image centre cross more of the volume) pays more than keeping each XCD's private 4 MiB L2 on
+//     a compact band of the frustum: the banded map is 5-11 % slower per kernel at 400x400 (measured, three cameras).
 //   * image_width > 0: a 256-thread block is a 16x16 pixel tile, each wave an 8x8 sub-tile, so the
 //     64 lanes of a wave touch a ~4x4x2 voxel neighbourhood per step (coalesced 16 B texel reads).
 // ------------------------------------------------------------------------------------------------
@@ -25,13 +27,13 @@ __device__ __forceinline__ long long ray_state_index(int boundary, int comp, int
 }
 
 // logical tile index of this block.  nt = number of tiles, ntx = tiles per image row (1 for linear ray order).
-//   mode 0: XCD bands  -- XCD x (blocks b % 8 == x) walks tiles [x*nt/8, (x+1)*nt/8): compulsory L2 traffic only
-//   mode 1: linear     -- tile = block index (neighbouring tiles on different XCDs)
+//   mode 0: interleaved -- tile = block index (neighbouring tiles on different XCDs; default)
+//   mode 1: XCD bands   -- XCD x (blocks b % 8 == x) walks tiles [x*nt/8, (x+1)*nt/8): compulsory L2 traffic only
 //   mode 2: row interleave -- XCD x walks tile rows x, x+8, x+16, ...: balances the XCDs when the work per
 //           row varies (image centre vs borders) at the price of every XCD touching the whole frustum
 // Tiles >= nt (padding of the launch) are reported as -1.
 __device__ __forceinline__ int logical_tile_of(const DevCfg& c, int b, int nblocks, int ntx, int nty) {
-  if (c.map_mode == 1) return b < ntx * nty ? b : -1;
+  if (c.map_mode == 0) return b < ntx * nty ? b : -1;
   const int x = b & 7, slot = b >> 3;
   if (c.map_mode == 2) {
     const int row = x + 8 * (slot / ntx), col = slot % ntx;
@@ -47,7 +49,7 @@ __device__ __forceinline__ int logical_tile(const DevCfg& c, int ntx, int nty) {
 
 // number of blocks to launch for nt = ntx * nty tiles under the mapping mode
 static inline int blocks_for_tiles(int map_mode, long long ntx, long long nty) {
-  if (map_mode == 1) return (int)(ntx * nty);
+  if (map_mode == 0) return (int)((ntx * nty + 7) / 8 * 8);
   if (map_mode == 2) return (int)(8 * ((nty + 7) / 8) * ntx);
   return (int)((ntx * nty + 7) / 8 * 8);
 }

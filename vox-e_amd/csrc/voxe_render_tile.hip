@@ -130,29 +130,17 @@ __global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
   const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
   // a block = (pixel tile, depth segment[, part]).  qsplit == 4 (small images that leave the chip under-filled): the
   // parts of a tile run as sibling blocks instead of one after the other.
-  // Block order (default band mode): XCD x = blockIdx % 8 owns a contiguous band of tiles and walks it SEGMENT-MAJOR:
-  // all its tiles at depth segment 0, then segment 1, ...  The segments in front of / behind the volume are empty and
-  // retire at once; with the segments of a tile on consecutive blocks instead, "empty" and "full" blocks alternate
-  // with period nseg, which aliases with the round-robin placement on the 32 CUs of an XCD whenever nseg divides 32
-  // (measured: kSegLen 32 -> 0.87 ms, 24 -> 0.68 ms, 48 -> 0.76 ms for the same work before this ordering).
+  // Block order: (part, SEGMENT)-major, tile minor -- all tiles at depth segment 0, then all at segment 1, ...  The
+  // segments in front of / behind the volume are empty and retire at once; with the segments of a tile on consecutive
+  // blocks instead, "empty" and "full" blocks alternate with period nseg, which aliases with the round-robin placement
+  // on the 32 CUs of an XCD whenever nseg divides 32 (measured: kSegLen 32 -> 0.87 ms, 24 -> 0.68 ms for the same
+  // work before this ordering).  Tiles are spread over the XCDs by logical_tile_of() (default: tile t on XCD t % 8).
   const int nseg = num_segments(c.S);
-  const int ntiles = ntx * nty;
-  int quad, seg, tile;
-  if (c.map_mode == 0) {
-    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int tpb = (ntiles + 7) >> 3;  // tiles per XCD band
-    const int part = slot / tpb;        // (part, segment) major, tile minor: sibling parts that have nothing to do
-    quad = part / nseg;                 // (a tile that fits the window whole) are not periodic in the block index either
-    seg = part - quad * nseg;
-    tile = x * tpb + slot % tpb;
-    if (quad >= qsplit || tile >= ntiles) return;  // launch padding (wave-uniform)
-  } else {
-    const int logical = logical_tile(c, ntx * nseg * qsplit, nty);
-    if (logical < 0) return;
-    quad = logical % qsplit;
-    const int rest = logical / qsplit;
-    seg = rest % nseg, tile = rest / nseg;
-  }
+  const int ntp = gridDim.x / (nseg * qsplit);  // tile slots (a multiple of 8 >= ntx * nty)
+  const int part = blockIdx.x / ntp;
+  const int quad = part / nseg, seg = part - quad * nseg;
+  const int tile = logical_tile_of(c, blockIdx.x - part * ntp, ntp, ntx, nty);
+  if (tile < 0) return;  // launch padding (wave-uniform)
   const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
   const int ty = tile / ntx, tx = tile - ty * ntx;
   const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
@@ -483,9 +471,7 @@ void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStr
   static const int env_q = [] { const char* e = getenv("VOXE_TILE_QSPLIT"); return e ? atoi(e) : 0; }();
   const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S);
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
-  const long long ntiles = ((W + 7) / 8) * ((H + 7) / 8);
-  const int nb = c.map_mode == 0 ? (int)(8 * ((ntiles + 7) / 8) * num_segments(c.S) * qsplit)
-                                 : blocks_for_tiles(c.map_mode, ((W + 7) / 8) * num_segments(c.S) * qsplit, (H + 7) / 8);
+  const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S) * qsplit;
 #define VOXE_TBWD(COUT, WD, WF)                                                                   \
   render_bwd_tile_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                   \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
