@@ -188,6 +188,10 @@ def main():
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kname, "alg_bytes_per_launch": int(kbytes), "launch_ms": round(kms, 4),
+        # `achieved` follows SURVEY.md 8(d)'s REQUESTED-bytes model (every trilinear corner fetch / scatter counted);
+        # neighbouring rays share corners and the kernels serve that reuse from L1 / L2 / the LDS gradient window, so
+        # it can exceed the HBM peak -- the HBM bytes actually moved are `traffic` (PMC), i.e. `hbm_measured_gbs`
+        "hbm_measured_gbs": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None),
         "phases_ms": {"pack": round(prof["ms_pack"] / max(prof["n_pack"], 1), 4), "fwd": round(ms_fwd, 4),
                       "memset": round(prof["ms_memset"] / max(prof["n_memset"], 1), 4), "bwd": round(ms_bwd, 4),
                       "unpack": round(prof["ms_unpack"] / max(prof["n_unpack"], 1), 4)},

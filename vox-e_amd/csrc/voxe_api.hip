@@ -26,15 +26,20 @@ int bwd_mode_override() {
 bool force_scatter_bwd() { return bwd_mode_override() == 1; }
 bool force_no_tile_bwd() { return bwd_mode_override() != 0; }
 
-// VOXE_TILE_MAP = interleave (default) | band | rows : block -> tile mapping (see logical_tile_of())
-int tile_map_mode() {
-  static const int mode = [] {
+// block -> tile mapping (see logical_tile_of()).  Default: image-ordered rays are interleaved over the XCDs (load
+// balance wins: neighbouring pixels share their voxels inside a wave anyway); rays in arbitrary order run in bands
+// (a batch kept in memory order then gives every XCD's L2 a compact part of the volume: forward -22 % at 32768
+// random rays).  VOXE_TILE_MAP = interleave | band | rows overrides both (A/B runs).
+int tile_map_mode(int image_width) {
+  static const int forced = [] {
     const char* e = getenv("VOXE_TILE_MAP");
+    if (e && strcmp(e, "interleave") == 0) return 0;
     if (e && strcmp(e, "band") == 0) return 1;
     if (e && strcmp(e, "rows") == 0) return 2;
-    return 0;
+    return -1;
   }();
-  return mode;
+  if (forced >= 0) return forced;
+  return image_width > 0 ? 0 : 1;
 }
 
 struct Variant {
@@ -88,7 +93,7 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->key0 = (uint32_t)c->seed ^ ((uint32_t)c->rng_offset * 0x9E3779B1u);
   dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32) ^ 0x7F4A7C15u;
   dc->image_width = c->image_width;
-  dc->map_mode = tile_map_mode();
+  dc->map_mode = tile_map_mode(c->image_width);
   dc->R = R;
 }
 

@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
 // segbuf layout: [segment][component][ray], components (Tseg, csum[COUT], asum, dsum).
 // ------------------------------------------------------------------------------------------------
 template <int COUT, int NCM, int NCU>
-__global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c, int fseg,
+// one-wave blocks (an 8x8 pixel tile each): 2-3 % faster than 256-thread blocks at 400x400, 33 % at 100x100 (finer
+// scheduling granularity; the kernel has no block-level cooperation)
+__global__ __launch_bounds__(64) void render_fwd_seg_kernel(DevGrid g, DevCfg c, int fseg,
                                                              const float* __restrict__ packed,
                                                              const float* __restrict__ rays_o,
                                                              const float* __restrict__ rays_d,
@@ -197,7 +199,25 @@ __global__ __launch_bounds__(256) void render_fwd_seg_kernel(DevGrid g, DevCfg c
   const int nrb = gridDim.x / ncoarse;  // ray blocks (a multiple of 8)
   const int cseg = blockIdx.x / nrb, rb = blockIdx.x - cseg * nrb;
   long long r;
-  if (!map_ray_block(c, rb, nrb, r)) return;
+  {  // one wave = one 8x8 pixel tile (image order) or 64 consecutive rays
+    const int lane = threadIdx.x;
+    if (c.image_width > 0) {
+      const int W = c.image_width, H = (int)(c.R / W);
+      const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
+      const int t = logical_tile_of(c, rb, nrb, ntx, nty);
+      if (t < 0) return;
+      const int ty = t / ntx, tx = t - ty * ntx;
+      const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
+      if (px >= W || py >= H) return;
+      r = (long long)py * W + px;
+    } else {
+      const int nt = (int)((c.R + 63) / 64);
+      const int t = logical_tile_of(c, rb, nrb, 1, nt);
+      if (t < 0) return;
+      r = (long long)t * 64 + lane;
+      if (r >= c.R) return;
+    }
+  }
   RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
   const int s_end = min(nseg, (cseg + 1) * fseg);
@@ -568,7 +588,10 @@ static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hi
     int fseg = 1;
     if (env_fseg > 0) fseg = env_fseg;
     const int ncoarse = (nseg + fseg - 1) / fseg;
-    render_fwd_seg_kernel<COUT, NCM, NCU><<<blocks_for(c) * ncoarse, 256, 0, st>>>(
+    const int nrb64 = c.image_width > 0
+                          ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, (c.R / c.image_width + 7) / 8)
+                          : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64);
+    render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
         g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
     render_fwd_combine_kernel<COUT><<<(int)((c.R + 255) / 256), 256, 0, st>>>(
         c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
