@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
 template <int COUT, int NCM, int NCU>
 // one-wave blocks (an 8x8 pixel tile each): 2-3 % faster than 256-thread blocks at 400x400, 33 % at 100x100 (finer
 // scheduling granularity; the kernel has no block-level cooperation)
-__global__ __launch_bounds__(64) void render_fwd_seg_kernel(DevGrid g, DevCfg c, int fseg,
+#ifndef VOXE_FWD_LB
+#define VOXE_FWD_LB 1
+#endif
+__global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid g, DevCfg c, int fseg,
                                                              const float* __restrict__ packed,
                                                              const float* __restrict__ rays_o,
                                                              const float* __restrict__ rays_d,

@@ -113,7 +113,10 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
 
 template <int COUT, bool WANT_D, bool WANT_F>
 // launch bounds swept: (64, 3) best; 2 and 4..6 are 6-9 % slower (register budget vs the LDS-bound residency)
-__global__ __launch_bounds__(64, 3) void render_bwd_tile_kernel(
+#ifndef VOXE_TILE_LB
+#define VOXE_TILE_LB 3
+#endif
+__global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
