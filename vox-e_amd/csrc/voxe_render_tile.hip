@@ -8,7 +8,7 @@
 //   * one WAVE (64 lanes) = one 8x8 pixel tile, one lane per ray, all lanes march in lock step over the
 //     sample index k (the per-ray math is identical to render_bwd_kernel);
 //   * the tile's gradient is accumulated in a per-wave LDS window that slides along the tile's dominant
-//     march axis m: a ring of 8 voxel layers x (8 x 8) lateral voxels x C channels, stored as DOUBLE
+//     march axis m: a ring of 6 voxel layers x (8 x 8) lateral voxels x C channels, stored as DOUBLE
 //     and updated with ds_add_f64 (~10 clk per wave instruction; ds_add_f32 is a 193-clk serial path);
 //     the lateral origin of every layer follows the tile's reference ray (a sheared, ray-aligned box),
 //     so 8x8 suffices for any view direction;
@@ -31,11 +31,18 @@
 namespace voxe {
 
 #ifndef VOXE_TILE_RING
-#define VOXE_TILE_RING 8
+#define VOXE_TILE_RING 6
 #endif
-// swept: 4 is 11 % faster for views along a grid axis but overflows the window for oblique ones (2.1x slower),
-// 16 halves the residency (1.9x slower)
-constexpr int kRing = VOXE_TILE_RING;    // live layers along the march axis (power of two)
+// swept over 15 cameras: 6 layers (12.4 KB: 12 one-wave blocks per CU, the same bound as the 168 VGPRs) is 8 % faster
+// than 8 (9 blocks per CU) for every camera; 5 is worse for oblique views, 4 overflows the window for them (2.1x
+// slower), 16 halves the residency (1.9x slower)
+constexpr int kRing = VOXE_TILE_RING;    // live layers along the march axis
+// ring position of a layer key (keys can be negative)
+__device__ __forceinline__ int ring_slot(int key) {
+  if constexpr ((VOXE_TILE_RING & (VOXE_TILE_RING - 1)) == 0) return key & (VOXE_TILE_RING - 1);
+  const int m = key % VOXE_TILE_RING;
+  return m < 0 ? m + VOXE_TILE_RING : m;
+}
 constexpr int kLat = 8;                  // lateral window edge (voxels)
 constexpr int kLayerSlots = kLat * kLat; // 64
 constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
@@ -87,14 +94,14 @@ struct Window {
   __device__ __forceinline__ int off_v(int im) const { return (int)floorf(Av + Bv * (float)im) - 3; }
   // storage position of lateral cell (a, b) inside its layer: rotated per layer so that the same (a, b)
   // of neighbouring layers lands in different LDS banks
-  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + VOXE_TILE_ROT * (key & (kRing - 1))) & 63; }
+  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + VOXE_TILE_ROT * ring_slot(key)) & 63; }
 };
 template <int C>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
                                             const Window& w, int key, int lane) {
   const int im = w.sgn * key;
   const int offu = w.off_u(im), offv = w.off_v(im);
-  const int lbase = (key & (kRing - 1)) * kLayerSlots;
+  const int lbase = ring_slot(key) * kLayerSlots;
   constexpr int kPerInstr = 64 / C;  // voxels per wave instruction (C == 4 -> 16, C == 2 -> 32)
 #pragma unroll
   for (int j = 0; j < kLayerSlots / kPerInstr; ++j) {
@@ -340,8 +347,8 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
               const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
               fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
                      ((unsigned)b0 < (unsigned)(kLat - 1));
-              lofs[s] = (key & (kRing - 1)) * kLayerSlots;
-              ab0[s] = a0 * kLat + b0 + VOXE_TILE_ROT * (key & (kRing - 1));  // + the per-layer rotation of layer_pos()
+              lofs[s] = ring_slot(key) * kLayerSlots;
+              ab0[s] = a0 * kLat + b0 + VOXE_TILE_ROT * ring_slot(key);  // + the per-layer rotation of layer_pos()
             }
             if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
               // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
                   const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
                                      ((unsigned)b < (unsigned)kLat);
                   if (inwin) {
-                    const int idx = (key & (kRing - 1)) * kLayerSlots + w.layer_pos(key, a * kLat + b);
+                    const int idx = ring_slot(key) * kLayerSlots + w.layer_pos(key, a * kLat + b);
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
                       if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
