@@ -25,3 +25,10 @@ for kind in ("random", "sphere"):
     td, tf = gh.hip_backward(grid, cfg, o, d, gc, image_width=hw)
     sd, sf = gh.hip_backward(grid, cfg, o, d, gc)
     print(kind, "tile vs oracle", rel_l2(td, rd), rel_l2(tf, rf), "| scatter vs oracle", rel_l2(sd, rd), rel_l2(sf, rf), "| tile vs scatter", rel_l2(td, sd), rel_l2(tf, sf))
+    # per-voxel view: relative error of the tile kernel where the oracle's gradient is small but non-zero
+    for name, t, r in (("density", td, rd), ("feature", tf, rf)):
+        ref = np.abs(r).ravel(); err = np.abs(t - r).ravel(); big = ref.max()
+        for lo, hi in ((1e-3, 1.0), (1e-6, 1e-3), (1e-9, 1e-6), (1e-12, 1e-9)):
+            m = (ref > lo * big) & (ref <= hi * big)
+            if m.any():
+                print(f"   {name:8s} |g| in ({lo:g}, {hi:g}] x max: {int(m.sum()):8d} voxels, median rel err {np.median(err[m] / ref[m]):.2e}, p99 {np.quantile(err[m] / ref[m], 0.99):.2e}")
