@@ -119,6 +119,16 @@ def main():
     del inside
 
     step_no = [0]
+    # N > 1: ONE all-reduce of the flat gradient, then the replicated Adam.  VOXE_BENCH_SHARDED_OPT=1 selects the
+    # ZeRO-1 style alternative (reduce-scatter, Adam on 1/world of the buffer, all-gather of the parameters: the same
+    # wire bytes, the optimiser pass divided by `world`, one more collective launch) -- not measured on > 1 GPU yet,
+    # so it is not the default.
+    sharded_opt = dist is not None and flat_p.numel() % world == 0 and os.environ.get("VOXE_BENCH_SHARDED_OPT") == "1"
+    if sharded_opt:
+        per = flat_p.numel() // world
+        lo, hi = rank * per, (rank + 1) * per
+        g_shard = torch.empty(per, dtype=torch.float32, device=dev)
+        p_shard = torch.empty(per, dtype=torch.float32, device=dev)
 
     def step():
         step_no[0] += 1
@@ -126,6 +136,14 @@ def main():
         ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
         ops.render_bwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, g_colour, None,
                             None, d_dens, d_feat, ws, rng)
+        if dist is not None and sharded_opt and not args.no_adam:
+            # gradient sum as reduce-scatter, Adam on this rank's 1/world slice of the flat buffer, all-gather of the
+            # updated parameters: the wire bytes of one all-reduce, the optimiser pass divided by `world`
+            dist.reduce_scatter_tensor(g_shard, flat_g)
+            ops.adam_step_(flat_p[lo:hi], g_shard, exp_avg[lo:hi], exp_avg_sq[lo:hi], step_no[0], lr=1e-4)
+            p_shard.copy_(flat_p[lo:hi])
+            dist.all_gather_into_tensor(flat_p, p_shard)
+            return
         if dist is not None:
             dist.all_reduce(flat_g)  # sum over ranks (RCCL, xGMI)
         if not args.no_adam:
@@ -244,7 +262,7 @@ def main():
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
                             f"{'' if args.no_adam else ' + Adam'}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
-                "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
+                "grad_exchange": ("reduce-scatter + sharded Adam + all-gather" if sharded_opt else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
                 "term_eps": args.term_eps,
             },
             "roofline": roofline,
