@@ -1,0 +1,123 @@
+"""Randomised parity sweep (fixed seeds): grid shapes, world boxes, activations, channel kinds, sample counts, sampling
+modes, cameras (inside / outside / grazing the box), image-ordered and unordered rays -- HIP vs the oracle:
+sample indices and masks bit for bit, renders to 5e-6, gradients to 1e-4 rel-L2 (or absolute when they vanish)."""
+import numpy as np
+import pytest
+import torch
+
+from voxe_hip import abi
+from voxe_hip.desc import make_render_cfg
+
+from oracle import voxe_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import gpu_helpers as gh
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    dims = tuple(int(v) for v in rng.integers(1, 40, 3))
+    if seed % 7 == 0:
+        dims = (int(rng.integers(24, 64)),) * 3
+    attn = seed % 5 == 3
+    F = 1 if attn else 3
+    dens = rng.uniform(-1, 1, dims + (1,)).astype(np.float32)
+    feat = rng.uniform(-2, 2, dims + (F,)).astype(np.float32)
+    ext = rng.uniform(0.5, 3.0, 3)
+    centre = rng.uniform(-0.3, 0.3, 3)
+    aabb = [(float(c - e / 2), float(c + e / 2)) for c, e in zip(centre, ext)]
+    pre, post, scale = [(abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, 100.0 / 3.0), (abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, 3.0),
+                        (abi.ACT_IDENTITY, abi.ACT_RELU, 20.0), (abi.ACT_ABS, abi.ACT_IDENTITY, 1.5),
+                        (abi.ACT_IDENTITY, abi.ACT_IDENTITY, 0.7)][seed % 5 if not attn else 1]
+    if post == abi.ACT_IDENTITY and pre == abi.ACT_IDENTITY:
+        dens = np.abs(dens)  # a raw field must stay non-negative to be a density
+    grid = vo.Grid(dens, feat, aabb, scale, pre, post, abi.FEAT_ATTN if attn else abi.FEAT_SH)
+    # camera: on a sphere around the box, sometimes inside it, looking roughly at the centre
+    h, w = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    radius = rng.uniform(0.2, 4.5)
+    eye = centre + radius * _unit(rng.standard_normal(3))
+    fwd = _unit(centre + 0.2 * rng.standard_normal(3) - eye)
+    up = _unit(np.cross(np.cross(fwd, rng.standard_normal(3)), fwd))
+    right = np.cross(fwd, up)
+    rot = np.stack([right, up, -fwd], axis=1).astype(np.float32)   # camera looks down -z
+    focal = float(rng.uniform(0.4, 2.5) * w)
+    o, d = vo.cast_rays(h, w, focal, rot, eye.astype(np.float32))
+    S = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 97, 160, 257]))
+    near = float(rng.uniform(0.01, 0.5))
+    far = float(near + rng.uniform(0.5, 7.0))
+    mode = seed % 4
+    kw = dict(white_bkgd=bool(rng.integers(0, 2)), linear_disparity=(mode == 1 and not attn), aabb_clip=(mode == 2))
+    jitter = rng.uniform(0, 1, (h * w, S)).astype(np.float32) if mode == 3 else None
+    if jitter is not None:
+        kw["perturb"] = True
+    cfg = make_render_cfg(S, near, far, **kw)
+    return grid, cfg, o, d, jitter, (h, w), rng
+
+
+def _close(name, got, ref):
+    """1e-4 relative in L2, plus an absolute floor: the density gradient is a difference of O(upstream) terms
+    (T dL/dw - suffix / (1 - alpha)) evaluated in float32, so when it nearly cancels (a couple of samples, ReLU field)
+    only the absolute error is meaningful"""
+    err = float(np.linalg.norm(np.asarray(got, np.float64) - np.asarray(ref, np.float64)))
+    assert err <= 1e-4 * float(np.linalg.norm(ref)) + 2e-5, (name, err, float(np.linalg.norm(ref)))
+
+
+def _unit(v):
+    return v / max(np.linalg.norm(v), 1e-12)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration(seed):
+    grid, cfg, o, d, jitter, (h, w), rng = _case(seed)
+    ordered = seed % 3 != 2
+    width = w if ordered else 0
+    if not ordered:                                        # unordered rays: the scatter backward paths
+        perm = rng.permutation(h * w)
+        o, d = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm])
+        jitter = None if jitter is None else np.ascontiguousarray(jitter[perm])
+    # --- index math: bit for bit
+    ref_p = vo.sample_probe(grid, cfg, o, d, jitter)
+    got_p = gh.hip_probe(grid, cfg, o, d, jitter, image_width=width)
+    assert np.array_equal(got_p["inside"].astype(bool), ref_p["inside"])
+    assert np.array_equal(got_p["z"], ref_p["z"])
+    m = ref_p["inside"]
+    assert np.array_equal(got_p["idx"][m], ref_p["idx"][m])
+    # --- forward
+    ref = vo.render_fwd(grid, cfg, o, d, jitter)
+    got = gh.hip_forward(grid, cfg, o, d, jitter, image_width=width)
+    for k in ("colour", "depth", "acc"):
+        scale = max(1.0, float(np.abs(ref[k]).max()))
+        np.testing.assert_allclose(got[k], ref[k].reshape(got[k].shape), rtol=0, atol=5e-6 * scale, err_msg=k)
+    # --- backward (colour + depth + accumulated weight upstream gradients)
+    cout = grid.cout
+    gc = rng.standard_normal((h * w, cout)).astype(np.float32)
+    gdep = (0.2 * rng.standard_normal(h * w)).astype(np.float32)
+    gacc = (0.2 * rng.standard_normal(h * w)).astype(np.float32)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, d_acc=gacc, jitter=jitter)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, g_acc=gacc, jitter=jitter, image_width=width)
+    for name, got_g, ref_g in (("densities", gd, rd), ("features", gf, rf)):
+        _close(name, got_g, ref_g)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration_sh_degrees(seed):
+    """same sweep with view-dependent colour (SH degree 1..3, 3 * (deg + 1)^2 feature channels), full and diffuse"""
+    grid, cfg, o, d, jitter, (h, w), rng = _case(100 + seed)
+    if grid.feature_kind == abi.FEAT_ATTN:
+        grid.feature_kind = abi.FEAT_SH
+    deg = 1 + seed % 3
+    dims = grid.densities.shape[:3]
+    grid.features = rng.uniform(-1, 1, dims + (3 * (deg + 1) ** 2,)).astype(np.float32)
+    cfg.sh_degree = deg
+    cfg.render_diffuse = int(seed % 4 == 0)
+    width = w if seed % 2 else 0
+    ref = vo.render_fwd(grid, cfg, o, d, jitter)
+    got = gh.hip_forward(grid, cfg, o, d, jitter, image_width=width)
+    np.testing.assert_allclose(got["colour"], ref["colour"], rtol=0, atol=5e-6)
+    gc = rng.standard_normal((h * w, 3)).astype(np.float32)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, jitter=jitter)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, jitter=jitter, image_width=width)
+    for name, got_g, ref_g in (("densities", gd, rd), ("features", gf, rf)):
+        _close(name, got_g, ref_g)
