@@ -121,3 +121,63 @@ def test_random_configuration_sh_degrees(seed):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, jitter=jitter, image_width=width)
     for name, got_g, ref_g in (("densities", gd, rd), ("features", gf, rf)):
         _close(name, got_g, ref_g)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_grid_passes(seed):
+    """whole-grid passes (density correlation, total variation, Adam, trilinear up-sampling) and the point query on
+    random shapes, vs the oracle"""
+    from helpers import rel_l2
+    from voxe_hip import ops
+
+    rng = np.random.default_rng(500 + seed)
+    dims = tuple(int(v) for v in rng.integers(1, 30, 3))
+    C = int(rng.integers(1, 5))
+    # density-correlation loss (needs non-degenerate variance) and TV (needs every axis to have a difference)
+    a = rng.uniform(-1, 1, dims + (1,)).astype(np.float32)
+    b = (a + 0.3 * rng.standard_normal(a.shape)).astype(np.float32)
+    if a.size > 2:
+        ta = gh.t(a, True)
+        loss = ops.density_correlation_loss(ta, gh.t(b))
+        loss.backward()
+        ref_loss, ref_grad = vo.dcl_fwd_bwd(a, b)
+        assert abs(float(loss.detach()) - ref_loss) < 5e-6
+        assert rel_l2(gh.n(ta.grad), ref_grad) < 2e-5
+    if min(dims) >= 2:
+        grid = rng.uniform(-1, 1, dims + (C,)).astype(np.float32)
+        tg = gh.t(grid, True)
+        tv = ops.tv_loss_on_grid(tg)
+        tv.backward()
+        ref_tv, ref_tvg = vo.tv_fwd_bwd(grid)
+        assert abs(float(tv.detach()) - ref_tv) < 5e-6 and rel_l2(gh.n(tg.grad), ref_tvg) < 1e-6
+    # Adam, odd lengths and steps
+    n = int(rng.integers(1, 5000))
+    p = rng.standard_normal(n).astype(np.float32)
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    tp, tm, tvv = gh.t(p.copy()), gh.t(m.copy()), gh.t(v.copy())
+    for step in range(1, 4):
+        grad = (rng.standard_normal(n) * 10.0 ** float(rng.integers(-6, 3))).astype(np.float32)
+        lr = float(rng.uniform(1e-4, 0.1))
+        ops.adam_step_(tp, gh.t(grad), tm, tvv, step, lr=lr)
+        vo.adam_step(p, grad, m, v, lr, 0.9, 0.999, 1e-8, step)
+        np.testing.assert_allclose(gh.n(tp), p, rtol=2e-6, atol=1e-7)
+    # trilinear up-sampling to an arbitrary size
+    src = rng.uniform(-1, 1, dims + (C,)).astype(np.float32)
+    out_size = tuple(int(v) for v in rng.integers(1, 45, 3))
+    np.testing.assert_allclose(gh.n(ops.upsample_trilinear(gh.t(src), out_size)), vo.upsample_trilinear(src, out_size),
+                               rtol=0, atol=1e-6)
+    # point query, points inside / on the faces / outside the box
+    grid, _, _, _, _, _, _ = _case(300 + seed)
+    lo = np.array([r[0] for r in grid.aabb]); hi = np.array([r[1] for r in grid.aabb])
+    pts = (lo + (hi - lo) * rng.uniform(-0.2, 1.2, (777, 3))).astype(np.float32)
+    pts[:8] = np.array([[lo[0], lo[1], lo[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], lo[2]], (lo + hi) / 2,
+                        [lo[0], (lo[1] + hi[1]) / 2, hi[2]], lo - 1, hi + 1, [hi[0], lo[1], lo[2]]], np.float32)
+    d, f = gh.t(grid.densities, True), gh.t(grid.features, True)
+    out = ops.query_points(gh.spec_of(grid), d, f, gh.t(pts))
+    ref = vo.query_fwd(grid, pts)
+    np.testing.assert_allclose(gh.n(out), ref, rtol=3e-6, atol=3e-6)
+    g_out = rng.standard_normal(ref.shape).astype(np.float32)
+    (out * gh.t(g_out)).sum().backward()
+    rd, rf = vo.query_bwd(grid, pts, g_out)
+    _close("query densities", gh.n(d.grad), rd)
+    _close("query features", gh.n(f.grad), rf)
