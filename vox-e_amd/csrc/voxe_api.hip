@@ -251,8 +251,9 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   make_dev(grid, cfg, R, v, &dg, &dc);
   // depth-segment states for the segmented backward, when that backward applies and the workspace holds them
   float* state = nullptr;
-  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd() && workspace_bytes >= l.total)
-    state = (float*)((char*)workspace + l.state_off);
+  const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
+  const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
+  if ((tiled || packed_bwd) && workspace_bytes >= l.total) state = (float*)((char*)workspace + l.state_off);
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
   { PhaseTimer t(PH_FWD, s); launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s); }
@@ -284,10 +285,11 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   if (R > 0) {
     DevGrid dg; DevCfg dc;
     make_dev(grid, cfg, R, v, &dg, &dc);
-    BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
-              d_densities != nullptr, d_features != nullptr, state};
     const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
-    if (tiled && !cfg->ray_state_valid) {
+    const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
+    BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
+              d_densities != nullptr, d_features != nullptr, (tiled || packed_bwd) ? state : nullptr};
+    if ((tiled || packed_bwd) && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
@@ -297,7 +299,7 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     PhaseTimer t(PH_BWD, s);
     if (tiled)
       launch_bwd_tile(dg, dc, a, s);
-    else if (packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd())
+    else if (packed_bwd)
       launch_bwd_packed_scatter(dg, dc, a, s);
     else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
     const float* __restrict__ colour, const float* __restrict__ depth,
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
-    float* __restrict__ gpacked) {
+    const float* __restrict__ ray_state, float* __restrict__ gpacked) {
   constexpr int C = COUT + 1;
   constexpr int kLanesPerSample = 2 * C;                 // (z corner, channel)
   constexpr int kSamplesPerInstr = 64 / kLanesPerSample;  // 8 (C = 4) or 16 (C = 2)
@@ -33,8 +33,14 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
   __shared__ float s_g[C][64];
   const int lane = threadIdx.x;
 
+  // With the forward's depth-segment states (ray_state != nullptr) a block is (64 rays, 32-sample depth segment),
+  // segment-major like the other render kernels: a 32768-ray batch is 512 waves if every wave marches whole rays --
+  // half a wave per SIMD, latency bound far below the atomic-request ceiling -- and 4096 with segments.
   const int nt = (int)((c.R + 63) / 64);
-  const int logical = logical_tile(c, 1, nt);
+  const int nseg = ray_state ? num_segments(c.S) : 1;
+  const int nrb = gridDim.x / nseg;
+  const int seg = blockIdx.x / nrb;
+  const int logical = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, 1, nt);
   if (logical < 0) return;
   const long long r0 = (long long)logical * 64 + lane;
   const bool alive = r0 < c.R;
@@ -42,9 +48,23 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
 
   RayCtx<COUT, 1, 1> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
-  const int k_lo = rc.k_lo;
-  int k_hi = alive ? rc.k_hi : k_lo - 1;
-  const bool has = k_lo <= k_hi;
+  const int ks = ray_state ? seg * kSegLen : 0, ke = ray_state ? min(c.S, ks + kSegLen) - 1 : c.S - 1;
+  const int k_lo = max(rc.k_lo, ks);
+  int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
+  bool has = k_lo <= k_hi;
+  // state at the segment start (transmittance + partial sums of the forward), as in render_bwd_tile_kernel
+  float T = 1.0f, pre_c[COUT], pre_a = 0.0f, pre_d = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = 0.0f;
+  if (has && seg > 0) {
+    constexpr int NC = COUT + 3;
+    T = ray_state[ray_state_index(seg, 0, NC, c.R, r)];
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
+    pre_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
+    pre_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
+    if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
+  }
 
   float gc[COUT], gsum = 0.0f;
 #pragma unroll
@@ -67,7 +87,11 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
   for (int off = 32; off > 0; off >>= 1) trips = max(trips, __shfl_xor(trips, off, 64));
 
   const int sx = g.X > 1 ? g.Y * g.Z : 0, sy = g.Y > 1 ? g.Z : 0, sz = g.Z > 1 ? 1 : 0;
-  float prefix = 0.0f, T = 1.0f;
+  // prefix = sum_{j < segment start} dL/dw_j w_j from the saved partial sums
+  float prefix = gdep * pre_d + gacc * pre_a;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
+  if (white) prefix -= gsum * pre_a;
   float z_next = has ? rc.dg.z(k_lo) : 0.0f;
   for (int i = 0; i < trips; ++i) {
     const int k = k_lo + i;
@@ -155,11 +179,11 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
 bool packed_scatter_supported(int deg) { return deg == 0; }
 
 void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
-  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64);
+  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * (a.ray_state ? num_segments(c.S) : 1);
 #define VOXE_PBWD(COUT, WD, WF)                                                                     \
   render_bwd_packed_scatter_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, \
-      a.d_acc, a.gpacked)
+      a.d_acc, a.ray_state, a.gpacked)
   if (c.attn) {
     if (a.want_d && a.want_f) VOXE_PBWD(1, true, true);
     else if (a.want_d) VOXE_PBWD(1, true, false);

@@ -46,6 +46,18 @@ class Workspace:
         self.buf: Optional[torch.Tensor] = None
         self.key = None        # which grid values are packed in the buffer
         self.state_key = None  # which forward call's per-ray depth-segment states it holds
+        # A differentiable forward leaves its per-ray states here for its backward.  When a second differentiable
+        # forward arrives before that backward (two renders in one loss: specular + diffuse), it runs in `sibling`
+        # (own buffers) instead of overwriting the states -- otherwise the first backward must re-march its rays.
+        self.pending = False
+        self.sibling: Optional["Workspace"] = None
+
+    def for_differentiable_forward(self) -> "Workspace":
+        if not self.pending:
+            return self
+        if self.sibling is None:
+            self.sibling = Workspace()
+        return self.sibling if not self.sibling.pending else self
 
     def ensure(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
@@ -155,6 +167,9 @@ class _RenderFn(torch.autograd.Function):
         depth = torch.empty((R, 1), dtype=torch.float32, device=device)
         acc = torch.empty((R, 1), dtype=torch.float32, device=device)
         disp = torch.empty((R, 1), dtype=torch.float32, device=device)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # (grad mode itself is off inside Function.forward)
+            workspace = workspace.for_differentiable_forward()
+            workspace.pending = True
         render_fwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, disp, workspace, rng)
         ctx.spec, ctx.params, ctx.workspace, ctx.rng = spec, params, workspace, rng
         ctx.save_for_backward(densities, features, ro, rd, jit, colour, depth, acc)
@@ -190,6 +205,7 @@ class _RenderFn(torch.autograd.Function):
         d_feat = torch.empty_like(feat) if need_f else None
         render_bwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, g_colour, g_depth, g_acc,
                         d_dens, d_feat, workspace, ctx.rng)
+        workspace.pending = False
         return d_dens, d_feat, None, None, None, None, None, None, None
 
 
