@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--scene", choices=["random", "sphere"], default="random")
     ap.add_argument("--term-eps", type=float, default=0.0, help="early ray termination (NOT in the reference); 0 = off")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra 100x100 measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="side of the image the CPU oracle is timed on (0: the full image if a probe says it fits ~30 s)")
@@ -187,7 +188,7 @@ def main():
         bwd_name = "render_bwd_tile_kernel<3,true,true>" if args.ray_order == "image" else "render_bwd_packed_scatter_kernel<3,true,true>"
         kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
-        kname, kbytes, kms = "render_fwd_kernel<3,1,1>", bytes_fwd, ms_fwd
+        kname, kbytes, kms = "render_fwd_seg_kernel<3,1,1>", bytes_fwd, ms_fwd
     achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     # HBM traffic of that kernel: PMC counters cannot be read from inside this process; they are collected by
     # tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS script) and committed
@@ -197,7 +198,7 @@ def main():
     default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, args.ray_order) == (160, 400, 256, "random", 0.0, False, 3, "image")
     if default_cfg and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))["kernels"]
-        key = "voxe::render_bwd_tile_kernel<3, true, true>" if ms_bwd >= ms_fwd else "voxe::render_fwd_kernel<3, 1, 1>"
+        key = "voxe::render_bwd_tile_kernel<3, true, true>" if ms_bwd >= ms_fwd else "voxe::render_fwd_seg_kernel<3, 1, 1>"
         if key in pmc and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
             # KiB -> bytes; FETCH_SIZE counts 64 B per 128 B request on gfx950 (MI355X_MICROARCH.md, HBM section)
             traffic = int((2.0 * pmc[key]["FETCH_SIZE"] + pmc[key]["WRITE_SIZE"]) * 1024)
@@ -217,6 +218,47 @@ def main():
         # whole-step figure in BASELINE.md's convention: rays/s x (S_in*384 + 72) B, per GPU
         "step_alg_gbs_per_gpu": round(rays_per_s / world * (s_in_total / R * 384 + 72) / 1e9, 2),
     }
+
+    # ---- secondary line: the same step at 100x100 (BASELINE.json asks for both image sizes), N = 1 default run only ----
+    secondary = None
+    if world == 1 and default_cfg and not args.no_secondary:
+        hw2 = 100
+        ro2, rd2 = ops.cast_rays(hw2, hw2, focal_for(hw2), pose.rotation, pose.translation, dev)
+        R2 = ro2.shape[0]
+        p2 = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw2)
+        g2 = torch.randn((R2, 3), generator=torch.Generator().manual_seed(44)).to(dev)
+        out2 = [torch.empty((R2, n), dtype=torch.float32, device=dev) for n in (3, 1, 1, 1)]
+        ws2 = ops.Workspace()
+        inside2 = ops.sample_probe(spec, ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=hw2),
+                                   dens, feat, ro2, rd2, outputs=("inside",))["inside"]
+        s_in2 = int(inside2.sum().item())
+
+        def step2():
+            step_no[0] += 1
+            rng = (42, step_no[0])
+            ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
+            ops.render_bwd_into(spec, p2, dens, feat, ro2, rd2, None, out2[0], out2[1], out2[2], g2, None, None,
+                                d_dens, d_feat, ws2, rng)
+            ops.adam_step_(flat_p, flat_g, exp_avg, exp_avg_sq, step_no[0], lr=1e-4)
+
+        for _ in range(args.warmup):
+            step2()
+        torch.cuda.synchronize()
+        ops.profile_enable(True)
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t2
+        pr2 = ops.profile_read()
+        ops.profile_enable(False)
+        b2 = pr2["ms_bwd"] / max(pr2["n_bwd"], 1)
+        secondary = {
+            "workload": f"same grid and step, one {hw2}x{hw2} camera", "value": round(R2 * args.steps / e2, 1), "unit": "rays/s",
+            "ms_per_step": round(1e3 * e2 / args.steps, 4), "in_aabb_samples_per_ray": round(s_in2 / R2, 2),
+            "bwd_ms": round(b2, 4), "fwd_ms": round(pr2["ms_fwd"] / max(pr2["n_fwd"], 1), 4),
+            "roofline_frac_bwd": round((s_in2 * 256 + R2 * 56) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b2 > 0 else None,
+        }
 
     # ---- CPU baseline: the oracle (a C port of the reference path) on the host cores, bounded sample ----
     cpu_baseline = None
@@ -265,7 +307,7 @@ def main():
                 "grad_exchange": ("reduce-scatter + sharded Adam + all-gather" if sharded_opt else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
                 "term_eps": args.term_eps,
             },
-            "roofline": roofline,
+            "roofline": roofline, "secondary": secondary,
             "cpu_baseline": cpu_baseline,
         }
     if dist is not None:
