@@ -16,6 +16,11 @@ for p in (os.path.join(ROOT, "vox-e_amd"), ROOT):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Image-ordered renders below 8192 rays take the scatter backward by default (faster on an empty chip); the parity
+# tests use small images, so they lower the threshold to keep exercising the LDS-window backward.  The scatter
+# backward is covered by the unordered-ray cases (tests/test_hip_fuzz.py, bench --ray-order random).
+os.environ.setdefault("VOXE_TILE_MIN_RAYS", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
