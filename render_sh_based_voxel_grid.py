@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Render a camera path of a trained SH voxel grid (entry point kept from the reference's
 render_sh_based_voxel_grid.py:74-170; same option names).  Every frame is one fused HIP forward launch.
-Frames are written as PNGs (and as rendered_video.mp4 when `imageio` is installed)."""
+Frames are written as PNGs, plus rendered_video.mp4 when `imageio` is installed (an animated PNG otherwise)."""
 import os
 import sys
 from pathlib import Path
@@ -74,7 +74,12 @@ def main(**kwargs) -> None:
 
         imageio.mimwrite(out / "rendered_video.mp4", frames, fps=cfg.fps)
     except ImportError:
-        print(f"imageio not installed: wrote {len(frames)} PNG frames to {out} instead of an mp4")
+        # no video encoder available: an animated PNG of the same frames (plays in browsers) next to the stills
+        from PIL import Image
+
+        stills = [Image.fromarray(f) for f in frames]
+        stills[0].save(out / "rendered_video.png", save_all=True, append_images=stills[1:], duration=int(1000 / cfg.fps), loop=0)
+        print(f"imageio not installed: wrote {len(frames)} PNG frames and rendered_video.png (APNG) to {out} instead of an mp4")
 
 
 if __name__ == "__main__":
