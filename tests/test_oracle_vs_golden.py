@@ -118,6 +118,8 @@ def test_render_forward_and_grads(tag):
             kw["perturb"] = True
         elif rest.startswith("lindisp"):
             kw["linear_disparity"] = True
+        elif rest.startswith("clipjit"):
+            kw["aabb_clip"] = kw["perturb"] = True
         elif rest.startswith("clip"):
             kw["aabb_clip"] = True
     cfg = cfg_from_bounds(g["bounds"], S, **kw)

@@ -283,6 +283,9 @@ def g5_g6_render():
         out.update({f"{kind}_lindisp_" + k: v for k, v in res.items()})
         res = render_case(vg, rays, 64, True, optimized_sampling=True, grads=(kind == "softplus_soft"))
         out.update({f"{kind}_clip_" + k: v for k, v in res.items()})
+        # the tester's combination: AABB-clipped AND jittered (modules/testers.py:35 with the default perturbation)
+        res = render_case(vg, rays, 64, True, jitter_seed=78, optimized_sampling=True, grads=(kind == "softplus_soft"))
+        out.update({f"{kind}_clipjit_" + k: v for k, v in res.items()})
     save("render_sh0.npz", **out)
 
 
