@@ -77,3 +77,19 @@ def test_direction_words():
     # the two variants differ only in where "side" starts (45 vs 60 degrees of yaw)
     for a, b in zip(loose, strict):
         assert a == b or (a, b) == ("side", "front")
+
+
+def test_token_attention_maps_match_reference():
+    """layer / head averaging, token slicing, the reference's Gaussian filter (kernel pinned), reflect padding and
+    bilinear up-sampling of the cross-attention maps (tests/golden/attention_maps.npz)"""
+    from thre3d_atom.thre3d_reprs.cross_attn import average_attention, gaussian_kernel_2d, token_attention_maps
+
+    z = load_golden("attention_maps.npz")
+    layers = [torch.from_numpy(z[f"layer{n}"]) for n in range(5)]
+    np.testing.assert_allclose(gaussian_kernel_2d(3, 0.5).numpy(), z["kernel"], rtol=1e-6, atol=1e-9)
+    avg = average_attention(layers, res=16)
+    np.testing.assert_allclose(avg.numpy(), z["average"], rtol=1e-6, atol=1e-9)
+    h, w = (int(v) for v in z["hw"])
+    maps = token_attention_maps(avg, [int(i) for i in z["indices"]], h, w)
+    assert len(maps) == 3 and maps[0].shape == (h, w)
+    np.testing.assert_allclose(torch.stack(maps).numpy(), z["maps"], rtol=1e-5, atol=1e-8)

@@ -545,6 +545,42 @@ def g14_edit_trajectory():
     save("edit_trajectory.npz", **out)
 
 
+def g15_attention_maps():
+    """Token attention maps (thre3d_atom/thre3d_reprs/cross_attn.py:425-467).  That module imports diffusers / cv2 and
+    calls `.cuda()`, so it cannot be imported here; its Gaussian filter (thre3d_atom/thre3d_reprs/gaussian_smoothing.py,
+    torch only) IS imported and applied, and the ~15 lines around it (layer / head average, token slice, reflect pad,
+    bilinear up-sampling) are restated below exactly as written there."""
+    from thre3d_atom.thre3d_reprs.gaussian_smoothing import GaussianSmoothing  # noqa: E402
+
+    g = torch.Generator().manual_seed(15)
+    layers = [torch.softmax(torch.randn(4, pix, 12, generator=g), dim=-1) for pix in (256, 1024, 256, 64, 256)]  # 12 tokens keep the fixture small
+    res, prompts = 16, ["a prompt"]
+    out_maps = []
+    for item in layers:                      # aggregate_attention(..., select=0)
+        if item.shape[1] == res ** 2:
+            out_maps.append(item.reshape(len(prompts), -1, res, res, item.shape[-1])[0])
+    agg = torch.cat(out_maps, dim=0)
+    agg = agg.sum(0) / agg.shape[0]
+    text = agg[:, :, 1:-1]                   # compute_max_attention_per_index
+    indices = [2, 5, 9]
+    h, w = 37, 52
+    maps = []
+    for i in [j - 1 for j in indices]:
+        image = text[:, :, i]
+        smoothing = GaussianSmoothing(channels=1, kernel_size=3, sigma=0.5, dim=2)
+        inp = torch.nn.functional.pad(image.unsqueeze(0).unsqueeze(0), (1, 1, 1, 1), mode="reflect")
+        image = smoothing(inp).squeeze(0).squeeze(0)
+        up = torch.nn.Upsample(size=(h, w), mode="bilinear")(image.view(1, 1, res, res))[0][0]
+        u_inp = torch.nn.functional.pad(up.unsqueeze(0).unsqueeze(0), (1, 1, 1, 1), mode="reflect")
+        maps.append(smoothing(u_inp).squeeze(0).squeeze(0))
+    out = {f"layer{n}": np_(a) for n, a in enumerate(layers)}
+    out["indices"], out["hw"] = np.array(indices), np.array([h, w])
+    out["average"] = np_(agg)
+    out["maps"] = np.stack([np_(m) for m in maps])
+    out["kernel"] = np_(GaussianSmoothing(1, 3, 0.5, 2).weight[0, 0])
+    save("attention_maps.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -560,3 +596,4 @@ if __name__ == "__main__":
     g12_frames()
     g13_refinement()
     g14_edit_trajectory()
+    g15_attention_maps()

@@ -78,6 +78,40 @@ class StableDiffusion(nn.Module):
     def get_max_step_ratio(self) -> float:
         return self.max_step_ratio
 
+    def get_num_tokens(self, prompt: str) -> int:
+        """tokens of the padded prompt that are not the end / padding token 49407 (begin token included; sd.py:104-114)"""
+        ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                             return_tensors="pt")["input_ids"][0]
+        return int((ids != 49407).sum())
+
+    @torch.no_grad()
+    def get_attn_map(self, prompt: str, pred_rgb: torch.Tensor, timestamp: int = 0, indices_to_fetch=(7,),
+                     guidance_scale: float = 100, logvar=None):
+        """Cross-attention maps of `prompt`'s tokens for the rendered image (one noisy UNet evaluation at `timestamp`,
+        or at a random step when it is 0): list of [H, W] maps for the 1-based `indices_to_fetch`, and the step
+        (sd.py:138-172).  Uses an explicit attention processor while it runs and restores the UNet's own afterwards."""
+        from thre3d_atom.thre3d_reprs.cross_attn import (
+            CrossAttentionRecorder, average_attention, install_recorder, token_attention_maps)
+
+        height, width = pred_rgb.shape[-2:]
+        text_embeddings = self.get_text_embeds(prompt, "")
+        pred_rgb_512 = F.interpolate(pred_rgb, (512, 512), mode="bilinear", align_corners=False)
+        t = torch.randint(self.min_step, self.max_step + 1, [1], dtype=torch.long, device=self.device)
+        if timestamp > 0:
+            t = torch.as_tensor(timestamp, dtype=torch.long, device=self.device)
+        latents = self.encode_imgs(pred_rgb_512)
+        noisy = self.scheduler.add_noise(latents, torch.randn_like(latents), t)
+        recorder = CrossAttentionRecorder()
+        previous = install_recorder(self.unet, recorder)
+        try:
+            self.unet(torch.cat([noisy] * 2), t, encoder_hidden_states=text_embeddings)
+        finally:
+            self.unet.set_attn_processor(previous)
+        maps = None
+        if indices_to_fetch is not None:
+            maps = token_attention_maps(average_attention(recorder.records, res=16), indices_to_fetch, height, width)
+        return maps, int(t.item())
+
     @torch.no_grad()
     def get_text_embeds(self, prompt: str, negative_prompt: str) -> torch.Tensor:
         def embed(text):
