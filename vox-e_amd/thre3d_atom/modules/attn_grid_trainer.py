@@ -154,10 +154,8 @@ def refine_edited_relu_field(
 
         attn_guidance = StableDiffusion(vol_mod_edit.device, "1.4", auth_token=hf_auth_token)
     if not (hasattr(attn_guidance, "get_attn_map") and hasattr(attn_guidance, "get_num_tokens")):
-        raise NotImplementedError(
-            "cross-attention extraction from the diffusion UNet is outside this build (SURVEY.md 8a19): pass "
-            "`attn_guidance` with get_num_tokens(prompt) and get_attn_map(prompt=, pred_rgb=, timestamp=, "
-            "indices_to_fetch=) -> (list of [H, W] maps, aux)")
+        raise TypeError("`attn_guidance` needs get_num_tokens(prompt) and get_attn_map(prompt=, pred_rgb=, timestamp=, "
+                        "indices_to_fetch=) -> (list of [H, W] maps, aux)")
     device = vol_mod_edit.device
     im_h, im_w = (int(v) for v in (image_dims if image_dims is not None else camera_intrinsics[:2]))
 
