@@ -8,7 +8,7 @@ Both expose what the trainers use: `camera_intrinsics`, `camera_bounds`,
 Image decoding is host I/O, outside the render hot path."""
 import json
 from pathlib import Path
-from typing import Optional, Tuple
+from typing import Tuple
 
 import numpy as np
 import torch

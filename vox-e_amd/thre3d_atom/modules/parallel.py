@@ -7,7 +7,7 @@ gradient is summed with ONE all-reduce per step over a flat buffer that both par
 (65.5 MB at 160^3), followed by the identical optimiser step on every rank.
 Everything here is plumbing on torch tensors (works on CPU tensors with gloo, which is how it is tested).
 """
-from typing import List, Sequence, Tuple
+from typing import List, Tuple
 
 import torch
 import torch.distributed as dist

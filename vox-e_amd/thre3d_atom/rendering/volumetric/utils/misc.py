@@ -3,7 +3,7 @@
 API of the reference's thre3d_atom/rendering/volumetric/utils/misc.py; `cast_rays` runs the HIP
 ray-generation kernel (voxe_cast_rays), everything else is tensor bookkeeping.
 """
-from typing import Any, List, Sequence, Tuple
+from typing import Any, Sequence, Tuple
 
 import numpy as np
 import torch
