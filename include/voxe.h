@@ -140,6 +140,13 @@ int voxe_cast_rays(int32_t H, int32_t W, float focal, const float* rot, const fl
 int voxe_cast_rays_indexed(int32_t H, int32_t W, float focal, const float* poses, int32_t K,
                            const int64_t* flat_index, int64_t B, float* rays_o, float* rays_d, void* stream);
 
+/* A uniformly random SUBSET of `count` distinct indices of [0, n), in random order: what `torch.randperm(n)[:count]`
+ * is used for in the ray-batch samplers (rendering/volumetric/utils/misc.py:126-138) without permuting all n
+ * (n = 1.28 M pixels for a 32768-ray batch).  out[i] = P(i), P a keyed 4-round Feistel permutation of [0, 2^b)
+ * (b = even number of bits >= log2 n) restricted to [0, n) by cycle walking: distinct by construction, reproducible
+ * from (seed, rng_offset); integer work, bit-exact between device and oracle.  n <= 2^31, count <= n.       */
+int voxe_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_offset, int64_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Volumetric render, forward -- replaces the whole chain
  *   render_sh_voxel_grid(_attn)            thre3d_reprs/renderers.py:50-163
@@ -294,6 +301,7 @@ int voxe_cpu_cast_rays(int32_t H, int32_t W, float focal, const float* rot, cons
                        float* rays_o, float* rays_d);
 int voxe_cpu_cast_rays_indexed(int32_t H, int32_t W, float focal, const float* poses, int32_t K,
                                const int64_t* flat_index, int64_t B, float* rays_o, float* rays_d);
+int voxe_cpu_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_offset, int64_t* out);
 int voxe_cpu_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                         const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
                         float* colour, float* depth, float* acc, float* disparity);

@@ -139,6 +139,12 @@ def cast_rays_indexed(H: int, W: int, focal: float, poses, flat_index):
     return o, d
 
 
+def random_subset(n: int, count: int, seed: int, rng_offset: int) -> np.ndarray:
+    out = np.empty((count,), np.int64)
+    _check(lib().voxe_cpu_random_subset(int(n), int(count), int(seed), int(rng_offset), out.ctypes.data), "random_subset")
+    return out
+
+
 def render_fwd(grid: Grid, cfg: abi.VoxeRenderCfg, rays_o, rays_d, jitter=None):
     rays_o, rays_d = _f32(rays_o), _f32(rays_d)
     R = rays_o.shape[0]

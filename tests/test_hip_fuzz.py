@@ -181,3 +181,12 @@ def test_random_grid_passes(seed):
     rd, rf = vo.query_bwd(grid, pts, g_out)
     _close("query densities", gh.n(d.grad), rd)
     _close("query features", gh.n(f.grad), rf)
+
+
+@pytest.mark.parametrize("n,count", [(1, 1), (5, 5), (1000, 999), (8 * 400 * 400, 32768), ((1 << 21) + 3, 100000)])
+def test_random_subset_bit_exact(n, count):
+    from voxe_hip import ops
+
+    got = ops.random_subset(n, count, gh.DEV, rng=(77, 5)).cpu().numpy()
+    assert np.array_equal(got, vo.random_subset(n, count, 77, 5))
+    assert len(np.unique(got)) == count and got.min() >= 0 and got.max() < n

@@ -206,3 +206,26 @@ def test_cc_largest_k_vs_scipy(seed, dims, p):
 def test_cc_no_foreground():
     labels, n = vo.cc_largest_k(np.zeros((3, 4, 5), bool), 10)
     assert n == 0 and not labels.any()
+
+
+@pytest.mark.parametrize("n,count", [(1, 1), (2, 2), (7, 5), (1000, 1000), (8 * 400 * 400, 32768), (1 << 20, 4096),
+                                     ((1 << 20) + 1, 50000)])
+def test_random_subset_is_a_uniform_looking_set_of_distinct_indices(n, count):
+    """the Feistel sampler that stands in for torch.randperm(n)[:count]: distinct, in range, different per (seed,
+    offset), a full permutation when count == n, and evenly spread (chi-square over 64 buckets)"""
+    a = vo.random_subset(n, count, 1234, 1)
+    assert a.shape == (count,) and a.min() >= 0 and a.max() < n
+    assert len(np.unique(a)) == count
+    if count == n:
+        assert np.array_equal(np.sort(a), np.arange(n))
+    if n > 1000:
+        b = vo.random_subset(n, count, 1234, 2)
+        assert len(np.intersect1d(a, b)) < count * (count / n) * 3 + 50          # ~ count^2 / n by chance
+        assert not np.array_equal(a, vo.random_subset(n, count, 1235, 1))
+        assert np.array_equal(a, vo.random_subset(n, count, 1234, 1))             # reproducible
+        if count >= 4096:
+            hist = np.bincount((a * 64 // n).astype(np.int64), minlength=64).astype(np.float64)
+            chi2 = float(((hist - count / 64) ** 2 / (count / 64)).sum())
+            assert chi2 < 120.0, chi2                                             # 63 d.o.f.: mean 63, p(>120) ~ 2e-5
+            # order is random too: successive picks are not monotone
+            assert 0.4 < float((np.diff(a) > 0).mean()) < 0.6

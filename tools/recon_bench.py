@@ -55,7 +55,8 @@ def main():
         if not os.environ.get("RECON_OLD_BATCH") and not os.environ.get("RECON_SORT"):
             picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
             rays_b, pix_b = sample_random_rays_and_pixels_from_cameras(intr, poses[picks], images, B, image_ids=picks,
-                                                                       memory_order=not os.environ.get("RECON_DRAW_ORDER"))
+                                                                       memory_order=not os.environ.get("RECON_DRAW_ORDER"),
+                                                                       fast_subset=not os.environ.get("RECON_RANDPERM"))
             rays = pixels = None
         else:
             picks = torch.randint(0, NV, (8,), generator=gen).tolist()

@@ -228,6 +228,14 @@ int voxe_cast_rays_indexed(int32_t H, int32_t W, float focal, const float* poses
   return finish();
 }
 
+int voxe_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_offset, int64_t* out, void* stream) {
+  if (!out) return VOXE_ERR_NULL_POINTER;
+  if (n <= 0 || n > (1ll << 31) || count < 0 || count > n) return VOXE_ERR_BAD_SHAPE;
+  if (count == 0) return VOXE_OK;
+  launch_random_subset(n, count, seed, rng_offset, (long long*)out, (hipStream_t)stream);
+  return finish();
+}
+
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
   return ws_layout(grid, cfg, R).total;

@@ -50,6 +50,25 @@ __host__ __device__ inline uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
+
+// Keyed pseudo-random permutation of [0, n): 4-round Feistel network on b = 2 * half bits (2^b >= n) with mix32 round
+// functions, restricted to [0, n) by cycle walking (a bijection of [0, 2^b) stays a bijection of [0, n) when out-of-range
+// values are fed through again).  Same definition in oracle/voxe_cpu.c.
+__host__ __device__ inline uint32_t feistel_permute(uint32_t x, uint32_t n, int half, uint32_t key0, uint32_t key1) {
+  const uint32_t mask = (1u << half) - 1u;
+  do {
+    uint32_t l = x >> half, r = x & mask;
+    for (int round = 0; round < 4; ++round) {
+      const uint32_t f = mix32(r ^ (round & 1 ? key1 : key0) ^ ((uint32_t)round * 0x9E3779B9u)) & mask;
+      const uint32_t t = l ^ f;
+      l = r;
+      r = t;
+    }
+    x = (l << half) | r;
+  } while (x >= n);
+  return x;
+}
+
 __host__ __device__ inline uint32_t jitter_base(uint32_t key0, uint32_t key1, long long ray) {
   const uint32_t lo = (uint32_t)ray, hi = (uint32_t)((unsigned long long)ray >> 32);
   return mix32(mix32(lo ^ key0) + (hi ^ key1));

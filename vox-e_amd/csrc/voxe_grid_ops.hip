@@ -70,6 +70,21 @@ void launch_cast_rays_indexed(int H, int W, float focal, const float* poses, int
                                                                     rays_d);
 }
 
+__global__ __launch_bounds__(256) void random_subset_kernel(uint32_t n, long long count, int half, uint32_t key0,
+                                                           uint32_t key1, long long* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (long long)feistel_permute((uint32_t)i, n, half, key0, key1);
+}
+
+void launch_random_subset(long long n, long long count, unsigned long long seed, unsigned long long rng_offset,
+                          long long* out, hipStream_t st) {
+  int bits = 2;
+  while ((1ull << bits) < (unsigned long long)n) bits += 2;
+  const uint32_t key0 = mix32((uint32_t)seed ^ ((uint32_t)rng_offset * 0x9E3779B1u));
+  const uint32_t key1 = mix32((uint32_t)(seed >> 32) ^ (uint32_t)(rng_offset >> 32) ^ 0x7F4A7C15u);
+  random_subset_kernel<<<(int)((count + 255) / 256), 256, 0, st>>>((uint32_t)n, count, bits / 2, key0, key1, out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // block reduction helper (double): wave shuffle -> LDS -> lane 0
 // ------------------------------------------------------------------------------------------------

@@ -55,6 +55,8 @@ void launch_cast_rays(int H, int W, float focal, const float* rot, const float* 
                       float* rays_d, hipStream_t st);
 void launch_cast_rays_indexed(int H, int W, float focal, const float* poses, int K, const long long* flat_index,
                               long long B, float* rays_o, float* rays_d, hipStream_t st);
+void launch_random_subset(long long n, long long count, unsigned long long seed, unsigned long long rng_offset,
+                          long long* out, hipStream_t st);
 size_t dcl_scratch_bytes(long long n);
 void launch_dcl(const float* a, const float* b, long long n, float grad_scale, float* loss_out,
                 float* d_a, int accumulate, void* scratch, hipStream_t st);

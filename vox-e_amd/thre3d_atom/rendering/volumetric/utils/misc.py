@@ -68,7 +68,7 @@ def sample_random_rays_and_pixels_synchronously(rays: Rays, pixels: Tensor, samp
 
 def sample_random_rays_and_pixels_from_cameras(camera_intrinsics: CameraIntrinsics, poses: Tensor, images: Tensor,
                                                sample_size: int, image_ids: Any = None,
-                                               memory_order: bool = False) -> Tuple[Rays, Tensor]:
+                                               memory_order: bool = False, fast_subset: bool = False) -> Tuple[Rays, Tensor]:
     """What the reconstruction loop keeps of `cast_rays` per camera -> `collate_rays` -> pixel concat ->
     `sample_random_rays_and_pixels_synchronously` (modules/trainers.py:290-313), computed for the selected pixels
     only: the same `randperm` draw picks flat (camera, y, x) indices, the HIP kernel casts just those rays and the
@@ -76,11 +76,16 @@ def sample_random_rays_and_pixels_from_cameras(camera_intrinsics: CameraIntrinsi
     host synchronisation.   poses [K,3,4] and images [N,C,H,W] on the GPU; `image_ids` [K] maps the K cameras to
     rows of `images` (default: the first K).  `memory_order=True` returns the same random subset sorted by (camera,
     row, column) instead of in draw order: the batch (a set; the loss is a mean over it) is unchanged, but rays that
-    are neighbours in the batch then walk neighbouring voxels, which the forward gather rewards (-25 % at 32768 rays)."""
+    are neighbours in the batch then walk neighbouring voxels, which the forward gather rewards (-25 % at 32768 rays).
+    `fast_subset=True` draws the subset with voxe_random_subset (same distribution: a uniformly random set of distinct
+    pixels; 0.02 ms instead of 0.20 ms for `randperm` over 1.28 M pixels) -- a different random stream than torch's."""
     height, width, focal = camera_intrinsics
     K = int(poses.shape[0])
     per = int(height) * int(width)
-    subset = torch.randperm(K * per, dtype=torch.long, device=images.device)[:sample_size]
+    if fast_subset:  # a keyed Feistel permutation evaluated at sample_size points instead of a permutation of all pixels
+        subset = _ops.random_subset(K * per, min(int(sample_size), K * per), images.device)
+    else:
+        subset = torch.randperm(K * per, dtype=torch.long, device=images.device)[:sample_size]
     if memory_order:
         subset = torch.sort(subset).values
     origins, directions = _ops.cast_rays_indexed(height, width, focal, poses, subset)

@@ -87,6 +87,7 @@ _RC = C.POINTER(VoxeRenderCfg)
 _COMMON = {
     "cast_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P], False, True),
     "cast_rays_indexed": (C.c_int, [C.c_int32, C.c_int32, C.c_float, _P, C.c_int32, _P, C.c_int64, _P, _P], False, True),
+    "random_subset": (C.c_int, [C.c_int64, C.c_int64, C.c_uint64, C.c_uint64, _P], False, True),
     "render_fwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P], True, True),
     "render_bwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32], True, True),
     "sample_probe": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P], True, True),

@@ -343,6 +343,21 @@ def cast_rays_indexed(height: int, width: int, focal: float, poses: torch.Tensor
     return ro, rd
 
 
+def random_subset(n: int, count: int, device, rng: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """`count` distinct pseudo-random indices of [0, n) (int64, random order) -- the role of torch.randperm(n)[:count]
+    without permuting all n.  Reproducible: (seed, counter) come from torch's CPU generator state like the jitter."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise VoxeError("random_subset runs on the GPU only (no CPU fallback in the product path)")
+    ensure_gfx950(device)
+    seed, offset = rng if rng is not None else _next_rng()
+    with torch.cuda.device(device):
+        out = torch.empty((int(count),), dtype=torch.int64, device=device)
+        check(lib().voxe_random_subset(int(n), int(count), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(out),
+                                       stream_ptr(device)), "voxe_random_subset")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # whole-grid passes
 # ------------------------------------------------------------------------------------------------
