@@ -451,22 +451,19 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
   // lanes and reference lane of part q under the chosen split
   auto in_part = [&](int q) {
     const int hx = (lane >> 2) & 1, hy = (lane >> 5) & 1;
-    return split == 1 ? hx == q : (split == 2 ? hy == q : hx + 2 * hy == q);
+    return split == 0 ? true : (split == 1 ? hx == q : (split == 2 ? hy == q : hx + 2 * hy == q));
   };
-  auto centre_of = [&](int q) { return split == 1 ? 26 + 4 * q : (split == 2 ? 19 + 32 * q : 18 + 4 * (q & 1) + 32 * (q >> 1)); };
+  auto centre_of = [&](int q) {
+    return split == 0 ? 27 : (split == 1 ? 26 + 4 * q : (split == 2 ? 19 + 32 * q : 18 + 4 * (q & 1) + 32 * (q >> 1)));
+  };
   const int nparts = split == 0 ? 1 : (split == 3 ? 4 : 2);
-  if (qsplit == 4) {  // the parts of a tile run as sibling blocks; siblings without a part have nothing to do
-    if (quad < nparts) {
-      if (split == 0) run_pass(alive, 27);
-      else run_pass(alive && in_part(quad), centre_of(quad));
-    }
-  } else if (split == 0) {
-    run_pass(alive, 27);
-  } else {
-    for (int q = 0; q < nparts; ++q) {
-      run_pass(alive && in_part(q), centre_of(q));
-      __syncthreads();
-    }
+  // qsplit == 4: the parts of a tile run as sibling blocks (siblings without a part have nothing to do); otherwise one
+  // block walks its parts.  ONE call site: the pass is ~3.5 k instructions and would otherwise be inlined four times.
+  const int q_begin = qsplit == 4 ? quad : 0;
+  const int q_end = qsplit == 4 ? min(quad + 1, nparts) : nparts;
+  for (int q = q_begin; q < q_end; ++q) {
+    run_pass(alive && in_part(q), centre_of(q));
+    __syncthreads();
   }
 }
 
