@@ -109,15 +109,18 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const int cout = g->feature_kind == VOXE_FEAT_ATTN ? 1 : 3;
   const int nseg = c ? num_segments(c->num_samples) : 1;
   const size_t state = align_up((size_t)(nseg - 1) * (size_t)(cout + 3) * (size_t)(R > 0 ? R : 0) * sizeof(float), 256);
+  // the gradient region also fits the 2x2x2-bricked layout of the scatter backward (dims rounded up to even)
+  const size_t bvox = (size_t)((g->X + 1) / 2) * ((g->Y + 1) / 2) * ((g->Z + 1) / 2) * 8;
+  const size_t gbytes = align_up(bvox * (size_t)(g->F + 1) * sizeof(float), 256);
   WsLayout l;
   l.packed_off = 0;
   l.grad_off = bytes;
-  l.state_off = 2 * bytes;
+  l.state_off = bytes + gbytes;
   // partial results of the depth-segmented forward: nseg x (cout + 3) floats per ray
   const size_t seg = align_up((size_t)nseg * (size_t)(cout + 3) * (size_t)(R > 0 ? R : 0) * sizeof(float), 256);
-  l.seg_off = 2 * bytes + state;
+  l.seg_off = bytes + gbytes + state;
   l.fwd_total = bytes;  // the forward alone needs only the packed grid (states / segments are used when they fit)
-  l.total = 2 * bytes + state + seg;
+  l.total = bytes + gbytes + state + seg;
   return l;
 }
 
@@ -290,6 +293,7 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     PhaseTimer t(PH_MEMSET, s);
     if (hipMemsetAsync(gpacked, 0, l.state_off - l.grad_off, s) != hipSuccess) return VOXE_ERR_LAUNCH;
   }
+  bool bricked_grad = false;
   if (R > 0) {
     DevGrid dg; DevCfg dc;
     make_dev(grid, cfg, R, v, &dg, &dc);
@@ -307,14 +311,16 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
     PhaseTimer t(PH_BWD, s);
     if (tiled)
       launch_bwd_tile(dg, dc, a, s);
-    else if (packed_bwd)
+    else if (packed_bwd) {
       launch_bwd_packed_scatter(dg, dc, a, s);
+      bricked_grad = true;  // that kernel accumulates into the bricked layout
+    }
     else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
   }
   {
     PhaseTimer t(PH_UNPACK, s);
-    launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, s);
+    launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, bricked_grad ? 1 : 0, s);
   }
   return finish();
 }
@@ -404,7 +410,7 @@ int voxe_query_bwd(const VoxeGridDesc* grid, const float* points, int64_t N, con
     launch_query(dg, grid->F + 1, packed, points, N, nullptr, d_out, gpacked, d_densities != nullptr,
                  d_features != nullptr, s);
   }
-  launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, s);
+  launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, 0, s);
   return finish();
 }
 

@@ -51,6 +51,14 @@ __host__ __device__ inline uint32_t mix32(uint32_t x) {
   return x;
 }
 
+// Slot of voxel (x, y, z) in a 2x2x2-BRICKED buffer: the 8 voxels of a brick are contiguous (8 x 16 B = one 128 B line
+// with 4 channels), so the 2x2x2 footprint of a sample touches (1.5)^3 = 3.4 lines on average instead of 4.5 in the
+// linear [X,Y,Z] order.  Used for the gradient buffer of the scatter backward (requests, not bytes, bound it).
+__host__ __device__ inline long long brick_slot(int x, int y, int z, int Y, int Z) {
+  const long long by = (Y + 1) >> 1, bz = (Z + 1) >> 1;
+  return ((((long long)(x >> 1) * by + (y >> 1)) * bz + (z >> 1)) << 3) | (long long)(((x & 1) << 2) | ((y & 1) << 1) | (z & 1));
+}
+
 // Keyed pseudo-random permutation of [0, n): 4-round Feistel network on b = 2 * half bits (2^b >= n) with mix32 round
 // functions, restricted to [0, n) by cycle walking (a bijection of [0, 2^b) stays a bijection of [0, n) when out-of-range
 // values are fed through again).  Same definition in oracle/voxe_cpu.c.

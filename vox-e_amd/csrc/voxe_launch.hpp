@@ -30,7 +30,7 @@ struct ProbeArgs {
 // voxe_render.hip
 void launch_pack_any(const VoxeGridDesc* gd, float* packed, hipStream_t st);
 void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
-                       int accumulate, hipStream_t st);
+                       int accumulate, int bricked, hipStream_t st);
 void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
                 hipStream_t st);
 void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a,

@@ -50,20 +50,27 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restric
                                                           const float* __restrict__ dens,
                                                           float* __restrict__ d_dens,
                                                           float* __restrict__ d_feat, long long nvox,
-                                                          float scale, int pre_act, int accumulate) {
+                                                          float scale, int pre_act, int accumulate,
+                                                          int bricked, int Y, int Z) {
   constexpr int F = C - 1;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += stride) {
+    // source position: the voxel itself, or its slot in the 2x2x2-bricked gradient buffer of the scatter backward
+    long long si = i;
+    if (bricked) {
+      const int z = (int)(i % Z), y = (int)((i / Z) % Y), x = (int)(i / ((long long)Y * Z));
+      si = brick_slot(x, y, z, Y, Z);
+    }
     float v[C];
     if constexpr (C == 4) {
-      const float4 t = reinterpret_cast<const float4*>(gpacked)[i];
+      const float4 t = reinterpret_cast<const float4*>(gpacked)[si];
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     } else if constexpr (C == 2) {
-      const float2 t = reinterpret_cast<const float2*>(gpacked)[i];
+      const float2 t = reinterpret_cast<const float2*>(gpacked)[si];
       v[0] = t.x; v[1] = t.y;
     } else {
 #pragma unroll
-      for (int f = 0; f < C; ++f) v[f] = gpacked[i * C + f];
+      for (int f = 0; f < C; ++f) v[f] = gpacked[si * C + f];
     }
     if (d_feat) {
 #pragma unroll
@@ -572,11 +579,11 @@ static void launch_pack(const VoxeGridDesc* gd, float* packed, hipStream_t st) {
 
 template <int C>
 static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
-                          int accumulate, hipStream_t st) {
+                          int accumulate, int bricked, hipStream_t st) {
   const long long nvox = (long long)gd->X * gd->Y * gd->Z;
   const int nb = (int)((nvox + 255) / 256 < 4096 ? (nvox + 255) / 256 : 4096);
   unpack_grad_kernel<C><<<nb, 256, 0, st>>>(gpacked, gd->densities, d_dens, d_feat, nvox,
-                                            gd->density_scale, gd->density_pre_act, accumulate);
+                                            gd->density_scale, gd->density_pre_act, accumulate, bricked, gd->Y, gd->Z);
 }
 
 template <int COUT, int NCM, int NCU>
@@ -643,13 +650,13 @@ void launch_pack_any(const VoxeGridDesc* gd, float* packed, hipStream_t st) {
   }
 }
 void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
-                       int accumulate, hipStream_t st) {
+                       int accumulate, int bricked, hipStream_t st) {
   switch (gd->F + 1) {
-    case 2: launch_unpack<2>(gd, gpacked, d_dens, d_feat, accumulate, st); break;
-    case 4: launch_unpack<4>(gd, gpacked, d_dens, d_feat, accumulate, st); break;
-    case 13: launch_unpack<13>(gd, gpacked, d_dens, d_feat, accumulate, st); break;
-    case 28: launch_unpack<28>(gd, gpacked, d_dens, d_feat, accumulate, st); break;
-    case 49: launch_unpack<49>(gd, gpacked, d_dens, d_feat, accumulate, st); break;
+    case 2: launch_unpack<2>(gd, gpacked, d_dens, d_feat, accumulate, bricked, st); break;
+    case 4: launch_unpack<4>(gd, gpacked, d_dens, d_feat, accumulate, bricked, st); break;
+    case 13: launch_unpack<13>(gd, gpacked, d_dens, d_feat, accumulate, bricked, st); break;
+    case 28: launch_unpack<28>(gd, gpacked, d_dens, d_feat, accumulate, bricked, st); break;
+    case 49: launch_unpack<49>(gd, gpacked, d_dens, d_feat, accumulate, bricked, st); break;
   }
 }
 void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
