@@ -21,7 +21,9 @@ timeout 300 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench.t
 for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_refine -o ${TAG}_refine -- python $GRAFT_REPO_ROOT/tools/refine_bench.py 160 > /dev/null 2>&1
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_recon -o ${TAG}_recon -- python $GRAFT_REPO_ROOT/tools/recon_bench.py 20 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
+head -6 $O/prof_recon/${TAG}_recon_kernel_stats.csv | cut -c1-160
 head -12 $O/prof_refine/${TAG}_refine_kernel_stats.csv | cut -c1-160
 head -8 $O/prof/${TAG}_kernel_stats.csv | cut -c1-200
 bash tools/gpu_pmc.sh > $O/pmc.txt 2>&1; tail -3 $O/pmc.txt | cut -c1-300
