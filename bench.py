@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="side of the image the CPU oracle is timed on (0: the full image if a probe says it fits ~30 s)")
     ap.add_argument("--no-adam", action="store_true")
+    ap.add_argument("--optimizer", choices=["fused", "split"], default="fused",
+                    help="fused: voxe_render_bwd_acc + voxe_grid_adam_step (gradient un-pack, Adam, re-pack and gradient "
+                         "clear in one pass over the grid); split: voxe_render_bwd + voxe_adam_step (same arithmetic, bit for bit)")
     ap.add_argument("--no-jitter", action="store_true")
     ap.add_argument("--ray-order", choices=["image", "linear", "random"], default="image",
                     help="image: row-major image rays with the width hint (LDS-window backward); linear: same rays without the "
@@ -131,7 +134,28 @@ def main():
         g_shard = torch.empty(per, dtype=torch.float32, device=dev)
         p_shard = torch.empty(per, dtype=torch.float32, device=dev)
 
+    fused = args.optimizer == "fused" and not args.no_adam and not sharded_opt
+    m_feat, m_dens = exp_avg[: nvox * 3], exp_avg[nvox * 3:]
+    v_feat, v_dens = exp_avg_sq[: nvox * 3], exp_avg_sq[nvox * 3:]
+    first = [True]
+
+    def fused_step():
+        # the gradient stays in the workspace in the backward kernel's layout; N > 1 sums THAT region over the ranks;
+        # one pass then applies the chain rule of the density pre-activation, Adam on both tensors, writes the packed
+        # grid of the next forward and clears the gradient for the next backward
+        step_no[0] += 1
+        rng = (42, step_no[0])
+        ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
+        layout = ops.render_bwd_acc(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, g_colour, None,
+                                    None, ws, rng, zero_first=first[0])
+        first[0] = False
+        if dist is not None:
+            dist.all_reduce(ops.workspace_grad_view(spec, dens, feat, ws))
+        ops.grid_adam_step_(spec, dens, feat, layout, ws, step_no[0], 1e-4, (m_dens, v_dens), (m_feat, v_feat))
+
     def step():
+        if fused:
+            return fused_step()
         step_no[0] += 1
         rng = (42, step_no[0])
         ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
@@ -233,7 +257,18 @@ def main():
                                    dens, feat, ro2, rd2, outputs=("inside",))["inside"]
         s_in2 = int(inside2.sum().item())
 
+        zero2 = [True]
+
         def step2():
+            if fused:
+                step_no[0] += 1
+                rng = (42, step_no[0])
+                ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
+                layout = ops.render_bwd_acc(spec, p2, dens, feat, ro2, rd2, None, out2[0], out2[1], out2[2], g2, None, None,
+                                            ws2, rng, zero_first=zero2[0])
+                zero2[0] = False
+                ops.grid_adam_step_(spec, dens, feat, layout, ws2, step_no[0], 1e-4, (m_dens, v_dens), (m_feat, v_feat))
+                return
             step_no[0] += 1
             rng = (42, step_no[0])
             ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
@@ -302,10 +337,10 @@ def main():
                 "workload": f"{G}^3 SH-0 softplus ReLU-field grid ({args.scene}), one {HW}x{HW} camera per GPU, "
                             f"S={S}, jitter {'off' if args.no_jitter else 'on'}, white bkgd, ray order {args.ray_order}; step = render fwd + bwd"
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
-                            f"{'' if args.no_adam else ' + Adam'}",
+                            f"{'' if args.no_adam else (' + Adam (fused grid step)' if fused else ' + Adam')}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
                 "grad_exchange": ("reduce-scatter + sharded Adam + all-gather" if sharded_opt else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
-                "term_eps": args.term_eps,
+                "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
             },
             "roofline": roofline, "secondary": secondary,
             "cpu_baseline": cpu_baseline,

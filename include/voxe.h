@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 3
+#define VOXE_ABI_VERSION 4
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -230,6 +230,37 @@ size_t voxe_tv_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t C);
 int voxe_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t C, float grad_scale,
                     float* loss_out, float* d_grid, int32_t accumulate,
                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused optimiser step of a voxel grid: gradient un-pack + torch.optim.Adam + re-pack in ONE streaming pass
+ *   (modules/sds_trainer.py:200-203,332-333; modules/trainers.py:247-255,350-351).
+ *
+ * voxe_render_bwd_acc  == voxe_render_bwd that LEAVES the gradient in the workspace (kernel layout) instead of
+ *   splitting it into the two API tensors.  zero_first != 0 clears the gradient region first, 0 accumulates on top
+ *   (several renders per optimiser step).  *grad_layout (HOST int) receives VOXE_GRAD_LINEAR / VOXE_GRAD_BRICKED
+ *   (which backward kernel ran; VOXE_GRAD_ANY for R == 0); every render accumulated into one step must report the
+ *   same layout.
+ * voxe_grid_adam_step  grid->densities / grid->features are the PARAMETERS and are updated in place (the const
+ *   of the descriptor is cast away); gradient = the workspace's packed gradient (chain rule of the density
+ *   pre-activation applied like voxe_render_bwd does) + optional extra gradients in API layout (regularisers);
+ *   exp_avg / exp_avg_sq: Adam state per tensor, NULL pair = that tensor is frozen.  Afterwards the workspace holds the
+ *   NEW grid packed (pass reuse_packed_grid = 1 to the next render) and a ZEROED gradient region (pass zero_first = 0).
+ *   Arithmetic identical to voxe_render_bwd + voxe_adam_step, bit for bit.                                        */
+enum { VOXE_GRAD_ANY = -1, VOXE_GRAD_LINEAR = 0, VOXE_GRAD_BRICKED = 1 };
+int voxe_render_bwd_acc(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                        const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                        const float* colour, const float* depth, const float* acc,
+                        const float* d_colour, const float* d_depth, const float* d_acc,
+                        int32_t want_densities, int32_t want_features, int32_t zero_first, int32_t* grad_layout,
+                        void* workspace, size_t workspace_bytes, void* stream);
+size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid);  /* byte offset / size of the gradient region, e.g. */
+size_t voxe_workspace_grad_bytes(const VoxeGridDesc* grid);   /* for the multi-GPU all-reduce between the two calls */
+int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout,
+                        const float* extra_d_densities, const float* extra_d_features,
+                        float* exp_avg_densities, float* exp_avg_sq_densities,
+                        float* exp_avg_features, float* exp_avg_sq_features,
+                        float lr, float beta1, float beta2, float eps, int64_t step,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* torch.optim.Adam(betas, eps, weight_decay=0, amsgrad=False) single-tensor step
  *   modules/sds_trainer.py:200-203, modules/trainers.py:247-255; `step` is the 1-based step count. */

@@ -1,0 +1,231 @@
+"""Fused grid optimiser step (voxe_render_bwd_acc + voxe_grid_adam_step) against the split path it replaces
+(voxe_render_bwd + voxe_adam_step on each tensor): parameters, Adam moments and the next render must be identical
+BIT FOR BIT over several steps when both consume the same gradient bits (the backward itself sums float atomics in
+a launch-dependent order, so two backward LAUNCHES agree only to rounding) -- for both gradient layouts (LDS-window backward: linear; scatter backward: 2x2x2
+bricks), odd grid sizes, extra (regulariser) gradients, accumulation of two renders and a frozen tensor."""
+import pytest
+import torch
+
+from synth import FAR, NEAR, RADIUS, focal_for, random_grid, synth_pose_angles
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+    from voxe_hip import abi, ops
+
+AABB = ((-1.5, 1.5),) * 3
+LR = 3e-3
+
+
+def _scene(side, nfeat, hw, ordered, dims=None, cam=3):
+    dev = torch.device("cuda", 0)
+    dens, feat = random_grid(side, nfeat)
+    if dims is not None:
+        dens, feat = dens[: dims[0], : dims[1], : dims[2]].contiguous(), feat[: dims[0], : dims[1], : dims[2]].contiguous()
+    yaw, pitch = synth_pose_angles(cam, 100)
+    pose = pose_spherical(yaw, pitch, RADIUS)
+    ro, rd = ops.cast_rays(hw, hw, focal_for(hw), pose.rotation, pose.translation, dev)
+    if not ordered:
+        perm = torch.randperm(ro.shape[0], generator=torch.Generator().manual_seed(3)).to(dev)
+        ro, rd = ro[perm].contiguous(), rd[perm].contiguous()
+    return dens.to(dev), feat.to(dev), ro, rd
+
+
+def _region_to_gradients(region, layout, dens, spec, C):
+    """the workspace gradient region -> (d_densities, d_features) exactly like unpack_grad_kernel: de-brick, split the
+    channels, chain rule of the density pre-activation (sign(raw * scale) * scale for abs, scale otherwise)"""
+    X, Y, Z = dens.shape[:3]
+    dev = dens.device
+    if layout == abi.GRAD_BRICKED:
+        bx, by, bz = (X + 1) // 2, (Y + 1) // 2, (Z + 1) // 2
+        x, y, z = torch.meshgrid(torch.arange(X, device=dev), torch.arange(Y, device=dev), torch.arange(Z, device=dev), indexing="ij")
+        slot = ((((x // 2) * by + (y // 2)) * bz + (z // 2)) * 8) + (x % 2) * 4 + (y % 2) * 2 + (z % 2)
+        g = region[: bx * by * bz * 8 * C].view(-1, C)[slot.reshape(-1)].view(X, Y, Z, C)
+    else:
+        g = region[: X * Y * Z * C].view(X, Y, Z, C)
+    scale = torch.tensor(spec.density_scale, dtype=torch.float32, device=dev)
+    chain = torch.sign(dens * scale) * scale if spec.density_pre_act == abi.ACT_ABS else scale
+    return (g[..., C - 1:] * chain).contiguous(), g[..., : C - 1].contiguous()
+
+
+class _Run:
+    """one optimisation run.  mode "fused": voxe_render_bwd_acc + voxe_grid_adam_step.  mode "split": voxe_render_bwd +
+    voxe_adam_step per tensor (its own backward launches: float atomics make it equal only to rounding).  mode "shadow":
+    the split optimiser fed with the gradient decoded from a fused run's workspace (bit-exact comparison)."""
+
+    def __init__(self, mode, dens, feat, spec, params, ro, rd, cout, freeze_density=False, extras=False, renders=1):
+        self.mode, self.spec, self.params, self.ro, self.rd = mode, spec, params, ro, rd
+        self.dens, self.feat = dens.clone(), feat.clone()
+        self.freeze_density, self.extras, self.renders = freeze_density, extras, renders
+        dev, R = dens.device, ro.shape[0]
+        self.out = [torch.empty((R, n), dtype=torch.float32, device=dev) for n in (cout, 1, 1, 1)]
+        gen = torch.Generator().manual_seed(11)
+        self.g_colour = torch.randn((R, cout), generator=gen).to(dev)
+        self.g_depth = torch.randn((R, 1), generator=gen).to(dev) * 0.1
+        self.g_acc = torch.randn((R, 1), generator=gen).to(dev) * 0.1
+        self.m = [torch.zeros_like(self.dens), torch.zeros_like(self.feat)]
+        self.v = [torch.zeros_like(self.dens), torch.zeros_like(self.feat)]
+        self.ws = ops.Workspace()
+        self.n = 0
+        self.layouts = set()
+        self.egen = torch.Generator().manual_seed(5)
+        self.decoded = None   # fused mode: (d_densities, d_features) decoded from the workspace before the step
+
+    def _extras(self):
+        if not self.extras:
+            return None, None
+        return ((torch.randn(self.dens.shape, generator=self.egen) * 1e-3).to(self.dens.device),
+                (torch.randn(self.feat.shape, generator=self.egen) * 1e-3).to(self.dens.device))
+
+    def _split_update(self, d_dens, d_feat, ex_d, ex_f):
+        if self.extras:   # autograd would add the regulariser gradient onto the render gradient
+            d_dens, d_feat = d_dens + ex_d, d_feat + ex_f
+        if not self.freeze_density:
+            ops.adam_step_(self.dens, d_dens, self.m[0], self.v[0], self.n, LR)
+        ops.adam_step_(self.feat, d_feat, self.m[1], self.v[1], self.n, LR)
+
+    def shadow_step(self, decoded):
+        self.n += 1
+        self._split_update(*decoded, *self._extras())
+
+    def step(self):
+        self.n += 1
+        ex_d, ex_f = self._extras()
+        d_dens, d_feat = torch.zeros_like(self.dens), torch.zeros_like(self.feat)
+        layout = abi.GRAD_ANY
+        for r in range(self.renders):
+            rng = (9, 100 * self.n + r)
+            ops.render_fwd_into(self.spec, self.params, self.dens, self.feat, self.ro, self.rd, None, *self.out, self.ws, rng)
+            args = (self.spec, self.params, self.dens, self.feat, self.ro, self.rd, None, self.out[0], self.out[1],
+                    self.out[2], self.g_colour, self.g_depth, self.g_acc)
+            if self.mode == "fused":
+                layout = ops.render_bwd_acc(*args, self.ws, rng, zero_first=(self.n == 1 and r == 0))
+                self.layouts.add(layout)
+            else:
+                ops.render_bwd_into(*args, d_dens, d_feat, self.ws, rng, accumulate=(r > 0))
+        if self.mode == "fused":
+            region = ops.workspace_grad_view(self.spec, self.dens, self.feat, self.ws)
+            self.decoded = _region_to_gradients(region.clone(), layout, self.dens, self.spec, self.feat.shape[-1] + 1)
+            sd = None if self.freeze_density else (self.m[0], self.v[0])
+            ops.grid_adam_step_(self.spec, self.dens, self.feat, layout, self.ws, self.n, LR, sd, (self.m[1], self.v[1]),
+                                ex_d, ex_f)
+            assert float(region.abs().max()) == 0.0      # the step leaves the gradient region cleared
+        else:
+            self._split_update(d_dens, d_feat, ex_d, ex_f)
+
+    def render(self, ws=None):
+        ws = ws if ws is not None else self.ws
+        ops.render_fwd_into(self.spec, self.params, self.dens, self.feat, self.ro, self.rd, None, *self.out, ws, (9, 7))
+        return [t.clone() for t in self.out]
+
+
+def _state(r: _Run):
+    return (("densities", r.dens), ("features", r.feat), ("exp_avg d", r.m[0]), ("exp_avg f", r.m[1]),
+            ("exp_avg_sq d", r.v[0]), ("exp_avg_sq f", r.v[1]))
+
+
+def _compare(a: _Run, b: _Run):
+    for (name, x), (_, y) in zip(_state(a), _state(b)):
+        assert torch.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} differ, max {float((x - y).abs().max()):.3e}"
+
+
+def _rel(x, y):
+    return float((x - y).norm() / y.norm().clamp_min(1e-30))
+
+
+CASES = {
+    # name: side, F, hw, ordered rays, dims, kind, pre_act, post_act, kwargs
+    "sh0_tile_linear": (48, 3, 96, True, None, "sh", "identity", "softplus", {}),
+    "sh0_scatter_bricked": (40, 3, 64, False, None, "sh", "identity", "softplus", {}),
+    "sh0_odd_dims_bricked": (40, 3, 64, False, (37, 40, 33), "sh", "identity", "softplus", {}),
+    "sh0_odd_dims_tile": (40, 3, 96, True, (37, 40, 33), "sh", "identity", "softplus", {}),
+    "sh0_preact_abs_relu": (40, 3, 96, True, None, "sh", "abs", "relu", {}),
+    "sh0_extras_two_renders": (40, 3, 96, True, None, "sh", "identity", "softplus", {"extras": True, "renders": 2}),
+    "sh0_extras_scatter": (40, 3, 64, False, None, "sh", "identity", "softplus", {"extras": True, "renders": 2}),
+    "attn_frozen_density": (40, 1, 96, True, None, "attn", "identity", "relu", {"freeze_density": True}),
+    "sh1_linear": (24, 12, 48, True, None, "sh1", "identity", "softplus", {}),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_fused_step_equals_split_step(case):
+    side, nfeat, hw, ordered, dims, kind, pre, post, kw = CASES[case]
+    dens, feat, ro, rd = _scene(side, nfeat, hw, ordered, dims)
+    acts = {"identity": abi.ACT_IDENTITY, "abs": abi.ACT_ABS, "relu": abi.ACT_RELU, "softplus": abi.ACT_SOFTPLUS}
+    spec = ops.GridSpec(aabb=AABB, density_scale=100.0 / 3.0 if post == "softplus" else 1.0, density_pre_act=acts[pre],
+                        density_post_act=acts[post], feature_kind=abi.FEAT_ATTN if kind == "attn" else abi.FEAT_SH)
+    params = ops.RenderParams(num_samples=96, near=NEAR, far=FAR, perturb=True, white_bkgd=kind != "attn",
+                              sh_degree=1 if kind == "sh1" else 0, image_width=hw if ordered else 0)
+    cout = 1 if kind == "attn" else 3
+    shadow = _Run("shadow", dens, feat, spec, params, ro, rd, cout, **kw)
+    split = _Run("split", dens, feat, spec, params, ro, rd, cout, **kw)
+    fused = _Run("fused", dens, feat, spec, params, ro, rd, cout, **kw)
+    for _ in range(4):
+        fused.step()
+        shadow.shadow_step(fused.decoded)      # same gradient bits through voxe_adam_step: must match exactly
+        _compare(shadow, fused)
+        split.step()                           # own backward launches: equal up to the order of the float atomics
+    for (name, x), (_, y) in zip(_state(fused), _state(split)):
+        if name.startswith("exp_avg_sq") or not float(y.abs().max()):
+            continue
+        assert _rel(x, y) < 5e-4, f"{name}: rel-L2 {_rel(x, y):.3e}"
+    expect = abi.GRAD_LINEAR if (ordered or kind == "sh1") else abi.GRAD_BRICKED   # scatter: unordered SH-0 rays only
+    assert fused.layouts == {expect}
+    assert not torch.equal(fused.feat, feat)             # the run really moved the parameters
+    if kw.get("freeze_density"):
+        assert torch.equal(fused.dens, dens) and float(fused.m[0].abs().max()) == 0.0
+    # the packed grid the fused step left in the workspace == a fresh pack of the updated tensors
+    reused = fused.render()
+    fresh = fused.render(ops.Workspace())
+    for x, y in zip(reused, fresh):
+        assert torch.equal(x, y)
+
+
+def test_gradient_region_view_matches_split_gradient():
+    """what a data-parallel job all-reduces: the workspace gradient region, linear layout = [X,Y,Z,(features, density)]"""
+    dens, feat, ro, rd = _scene(40, 3, 96, True)
+    spec = ops.GridSpec(aabb=AABB, density_scale=100.0 / 3.0)
+    params = ops.RenderParams(num_samples=96, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=96)
+    run = _Run("fused", dens, feat, spec, params, ro, rd, 3)
+    rng = (9, 1)
+    ops.render_fwd_into(spec, params, run.dens, run.feat, ro, rd, None, *run.out, run.ws, rng)
+    args = (spec, params, run.dens, run.feat, ro, rd, None, run.out[0], run.out[1], run.out[2], run.g_colour, run.g_depth, run.g_acc)
+    layout = ops.render_bwd_acc(*args, run.ws, rng)
+    assert layout == abi.GRAD_LINEAR
+    region = ops.workspace_grad_view(spec, run.dens, run.feat, run.ws)
+    assert region.numel() * 4 == 40 ** 3 * 4 * 4       # even dims: the bricked layout needs no padding
+    d_dens, d_feat = _region_to_gradients(region.clone(), layout, run.dens, spec, 4)
+    s_dens, s_feat = torch.zeros_like(dens), torch.zeros_like(feat)
+    ops.render_bwd_into(*args, s_dens, s_feat, run.ws, rng)       # (re-runs the backward: equal up to atomics order)
+    assert _rel(d_feat, s_feat) < 1e-5 and _rel(d_dens, s_dens) < 1e-5
+    # doubling the region (what an all-reduce over two identical ranks does) doubles the step's gradient
+    ops.render_bwd_acc(*args, run.ws, rng)
+    region = ops.workspace_grad_view(spec, run.dens, run.feat, run.ws)
+    d_dens, d_feat = _region_to_gradients(region.clone(), layout, run.dens, spec, 4)
+    region.mul_(2.0)
+    ref = _Run("shadow", dens, feat, spec, params, ro, rd, 3)
+    ops.adam_step_(ref.dens, d_dens * 2.0, ref.m[0], ref.v[0], 1, LR)
+    ops.adam_step_(ref.feat, d_feat * 2.0, ref.m[1], ref.v[1], 1, LR)
+    ops.grid_adam_step_(spec, run.dens, run.feat, layout, run.ws, 1, LR, (run.m[0], run.v[0]), (run.m[1], run.v[1]))
+    _compare(ref, run)
+    assert float(ops.workspace_grad_view(spec, run.dens, run.feat, run.ws).abs().max()) == 0.0
+
+
+def test_fused_step_argument_errors():
+    dens, feat, ro, rd = _scene(16, 3, 16, True)
+    spec = ops.GridSpec(aabb=AABB)
+    with pytest.raises(ops.VoxeError):
+        ops.grid_adam_step_(spec, dens, feat, abi.GRAD_LINEAR, ops.Workspace(), 1, LR)   # no gradient in the workspace
+    ws = ops.Workspace()
+    params = ops.RenderParams(num_samples=16, near=NEAR, far=FAR, image_width=16)
+    out = [torch.empty((ro.shape[0], n), device=dens.device) for n in (3, 1, 1, 1)]
+    ops.render_fwd_into(spec, params, dens, feat, ro, rd, None, *out, ws)
+    ops.render_bwd_acc(spec, params, dens, feat, ro, rd, None, out[0], out[1], out[2], torch.ones_like(out[0]), None, None, ws)
+    m = torch.zeros_like(dens)
+    with pytest.raises(ops.VoxeError):   # moments of the wrong size
+        ops.grid_adam_step_(spec, dens, feat, abi.GRAD_LINEAR, ws, 1, LR, (m, m), (m, m))
+    with pytest.raises(ops.VoxeError):   # unknown layout
+        ops.grid_adam_step_(spec, dens, feat, 7, ws, 1, LR, (m, m.clone()))
+    with pytest.raises(ops.VoxeError):   # step < 1
+        ops.grid_adam_step_(spec, dens, feat, abi.GRAD_LINEAR, ws, 0, LR, (m, m.clone()))

@@ -271,36 +271,33 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   return finish();
 }
 
-int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
-                    const float* rays_d, int64_t R, const float* jitter, const float* colour,
-                    const float* depth, const float* acc, const float* d_colour, const float* d_depth,
-                    const float* d_acc, float* d_densities, float* d_features, int32_t accumulate,
-                    void* workspace, size_t workspace_bytes, void* stream) {
-  Variant v;
-  const int st = validate(grid, cfg, R, &v);
-  if (st) return st;
-  if (R > 0 && (!rays_o || !rays_d || !colour || !depth || !acc || !d_colour))
-    return VOXE_ERR_NULL_POINTER;
-  if (!d_densities && !d_features) return VOXE_OK;
+}  // extern "C" (reopened below)
+
+namespace {
+// memset (optional) + backward kernel into the workspace's packed gradient region; *bricked = layout of that region
+int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Variant& v, const float* rays_o,
+                      const float* rays_d, int64_t R, const float* jitter, const float* colour, const float* depth,
+                      const float* acc, const float* d_colour, const float* d_depth, const float* d_acc, bool want_d,
+                      bool want_f, bool zero_first, bool* bricked, void* workspace, size_t workspace_bytes,
+                      hipStream_t s) {
   const WsLayout l = ws_layout(grid, cfg, R);
   if (!workspace || workspace_bytes < l.total) return VOXE_ERR_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
   float* packed = (float*)((char*)workspace + l.packed_off);
   float* gpacked = (float*)((char*)workspace + l.grad_off);
   float* state = (float*)((char*)workspace + l.state_off);
   if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
-  {
+  if (zero_first) {
     PhaseTimer t(PH_MEMSET, s);
     if (hipMemsetAsync(gpacked, 0, l.state_off - l.grad_off, s) != hipSuccess) return VOXE_ERR_LAUNCH;
   }
-  bool bricked_grad = false;
+  *bricked = false;
   if (R > 0) {
     DevGrid dg; DevCfg dc;
     make_dev(grid, cfg, R, v, &dg, &dc);
     const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
     const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
-              d_densities != nullptr, d_features != nullptr, (tiled || packed_bwd) ? state : nullptr};
+              want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
     if ((tiled || packed_bwd) && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
@@ -313,15 +310,87 @@ int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
       launch_bwd_tile(dg, dc, a, s);
     else if (packed_bwd) {
       launch_bwd_packed_scatter(dg, dc, a, s);
-      bricked_grad = true;  // that kernel accumulates into the bricked layout
-    }
-    else
+      *bricked = true;  // that kernel accumulates into the bricked layout
+    } else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
   }
+  return VOXE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int voxe_render_bwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
+                    const float* rays_d, int64_t R, const float* jitter, const float* colour,
+                    const float* depth, const float* acc, const float* d_colour, const float* d_depth,
+                    const float* d_acc, float* d_densities, float* d_features, int32_t accumulate,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  if (R > 0 && (!rays_o || !rays_d || !colour || !depth || !acc || !d_colour))
+    return VOXE_ERR_NULL_POINTER;
+  if (!d_densities && !d_features) return VOXE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bool bricked = false;
+  const int rc = render_bwd_common(grid, cfg, v, rays_o, rays_d, R, jitter, colour, depth, acc, d_colour, d_depth, d_acc,
+                                   d_densities != nullptr, d_features != nullptr, true, &bricked, workspace,
+                                   workspace_bytes, s);
+  if (rc) return rc;
   {
+    const WsLayout l = ws_layout(grid, cfg, R);
     PhaseTimer t(PH_UNPACK, s);
-    launch_unpack_any(grid, gpacked, d_densities, d_features, accumulate, bricked_grad ? 1 : 0, s);
+    launch_unpack_any(grid, (const float*)((char*)workspace + l.grad_off), d_densities, d_features, accumulate,
+                      bricked ? 1 : 0, s);
   }
+  return finish();
+}
+
+int voxe_render_bwd_acc(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o, const float* rays_d,
+                        int64_t R, const float* jitter, const float* colour, const float* depth, const float* acc,
+                        const float* d_colour, const float* d_depth, const float* d_acc, int32_t want_densities,
+                        int32_t want_features, int32_t zero_first, int32_t* grad_layout, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  if (!grad_layout || (R > 0 && (!rays_o || !rays_d || !colour || !depth || !acc || !d_colour)))
+    return VOXE_ERR_NULL_POINTER;
+  bool bricked = false;
+  const int rc = render_bwd_common(grid, cfg, v, rays_o, rays_d, R, jitter, colour, depth, acc, d_colour, d_depth, d_acc,
+                                   want_densities != 0, want_features != 0, zero_first != 0, &bricked, workspace,
+                                   workspace_bytes, (hipStream_t)stream);
+  if (rc) return rc;
+  *grad_layout = R > 0 ? (bricked ? VOXE_GRAD_BRICKED : VOXE_GRAD_LINEAR) : VOXE_GRAD_ANY;
+  return finish();
+}
+
+size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid) {
+  if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
+  return ws_layout(grid, nullptr, 0).grad_off;
+}
+size_t voxe_workspace_grad_bytes(const VoxeGridDesc* grid) {
+  if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
+  const WsLayout l = ws_layout(grid, nullptr, 0);
+  return l.state_off - l.grad_off;
+}
+
+int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, const float* extra_d_densities,
+                        const float* extra_d_features, float* exp_avg_d, float* exp_avg_sq_d, float* exp_avg_f,
+                        float* exp_avg_sq_f, float lr, float beta1, float beta2, float eps, int64_t step,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  if (!grid || !grid->densities || !grid->features) return VOXE_ERR_NULL_POINTER;
+  if (grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0 || step < 1) return VOXE_ERR_BAD_SHAPE;
+  if ((exp_avg_d == nullptr) != (exp_avg_sq_d == nullptr) || (exp_avg_f == nullptr) != (exp_avg_sq_f == nullptr))
+    return VOXE_ERR_NULL_POINTER;
+  if (grad_layout != VOXE_GRAD_LINEAR && grad_layout != VOXE_GRAD_BRICKED && grad_layout != VOXE_GRAD_ANY)
+    return VOXE_ERR_UNSUPPORTED;
+  const WsLayout l = ws_layout(grid, nullptr, 0);
+  if (!workspace || workspace_bytes < l.state_off) return VOXE_ERR_WORKSPACE;
+  if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, (float*)((char*)workspace + l.grad_off),
+                        extra_d_densities, extra_d_features, exp_avg_d, exp_avg_sq_d, exp_avg_f, exp_avg_sq_f, lr, beta1,
+                        beta2, eps, step, (float*)((char*)workspace + l.packed_off), (hipStream_t)stream))
+    return VOXE_ERR_UNSUPPORTED;
   return finish();
 }
 

@@ -31,6 +31,10 @@ struct ProbeArgs {
 void launch_pack_any(const VoxeGridDesc* gd, float* packed, hipStream_t st);
 void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
                        int accumulate, int bricked, hipStream_t st);
+// fused un-pack + Adam + re-pack (false: channel count without a kernel)
+bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, float* gpacked, const float* extra_d, const float* extra_f,
+                      float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
+                      long long step, float* packed_out, hipStream_t st);
 void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
                 hipStream_t st);
 void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a,

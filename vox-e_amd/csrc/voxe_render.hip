@@ -10,7 +10,10 @@
 // corner is ONE aligned 16-byte load for SH-0 (float4) / 8-byte load for the attention grid, and
 // the two z-neighbours of a corner pair are contiguous (32 B).  Gradients are accumulated in the
 // same packed layout and split back (with the pre-activation chain rule) by unpack_grad_kernel.
+#include <stdint.h>
 #include <stdlib.h>
+
+#include <math.h>
 
 #include "voxe_device.hpp"
 #include "voxe_launch.hpp"
@@ -84,6 +87,116 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restric
       d_dens[i] = accumulate ? d_dens[i] + gval : gval;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused optimiser step: un-pack the gradient (+ chain rule of the density pre-activation), Adam on both parameter
+// tensors, re-pack the updated grid, clear the gradient -- one streaming pass instead of four
+// (unpack 131 MB + Adam 459 MB + pack 131 MB + memset 65 MB -> 590 MB at 160^3).  Arithmetic of unpack_grad_kernel and
+// adam_kernel (voxe_grid_ops.hip), operation for operation.
+// ------------------------------------------------------------------------------------------------
+struct AdamHyper {
+  float step_size, bc2_sqrt, beta1, beta2, eps;
+};
+#ifndef VOXE_GA_BLOCKS
+#define VOXE_GA_BLOCKS 16384
+#endif
+__device__ __forceinline__ float adam_update(float p, float gi, float& m, float& v, const AdamHyper& h) {
+  const float mi = m + (gi - m) * (1.0f - h.beta1);
+  const float vi = v * h.beta2 + ((1.0f - h.beta2) * gi) * gi;
+  const float denom = sqrtf(vi) / h.bc2_sqrt + h.eps;
+  m = mi;
+  v = vi;
+  return p - h.step_size * (mi / denom);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpacked, float* __restrict__ dens,
+                                                        float* __restrict__ feat, const float* __restrict__ extra_d,
+                                                        const float* __restrict__ extra_f, float* __restrict__ m_d,
+                                                        float* __restrict__ v_d, float* __restrict__ m_f,
+                                                        float* __restrict__ v_f, float* __restrict__ packed,
+                                                        long long nvox, float scale, int pre_act, int bricked, int Y,
+                                                        int Z, AdamHyper h) {
+  constexpr int F = C - 1;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += stride) {
+    long long si = i;
+    if (bricked) {
+      const int z = (int)(i % Z), y = (int)((i / Z) % Y), x = (int)(i / ((long long)Y * Z));
+      si = brick_slot(x, y, z, Y, Z);
+    }
+    float g[C];
+    if constexpr (C == 4) {
+      const float4 t = reinterpret_cast<const float4*>(gpacked)[si];
+      g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+      reinterpret_cast<float4*>(gpacked)[si] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else if constexpr (C == 2) {
+      const float2 t = reinterpret_cast<const float2*>(gpacked)[si];
+      g[0] = t.x; g[1] = t.y;
+      reinterpret_cast<float2*>(gpacked)[si] = make_float2(0.0f, 0.0f);
+    } else {
+#pragma unroll
+      for (int f = 0; f < C; ++f) { g[f] = gpacked[si * C + f]; gpacked[si * C + f] = 0.0f; }
+    }
+    float out[C];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const long long j = i * F + f;
+      float p = feat[j];
+      if (m_f) {
+        const float gi = extra_f ? g[f] + extra_f[j] : g[f];
+        float m = m_f[j], v = v_f[j];
+        p = adam_update(p, gi, m, v, h);
+        feat[j] = p; m_f[j] = m; v_f[j] = v;
+      }
+      out[f] = p;
+    }
+    float d = dens[i];
+    if (m_d) {
+      const float gd = g[F] * pre_activate_grad(pre_act, d, scale);
+      const float gi = extra_d ? gd + extra_d[i] : gd;
+      float m = m_d[i], v = v_d[i];
+      d = adam_update(d, gi, m, v, h);
+      dens[i] = d; m_d[i] = m; v_d[i] = v;
+    }
+    out[F] = pre_activate(pre_act, d, scale);
+    if constexpr (C == 4) {
+      reinterpret_cast<float4*>(packed)[i] = make_float4(out[0], out[1], out[2], out[3]);
+    } else if constexpr (C == 2) {
+      reinterpret_cast<float2*>(packed)[i] = make_float2(out[0], out[1]);
+    } else {
+#pragma unroll
+      for (int f = 0; f < C; ++f) packed[i * C + f] = out[f];
+    }
+  }
+}
+
+template <int C>
+static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, float* gpacked, const float* extra_d,
+                               const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h,
+                               float* packed_out, hipStream_t st) {
+  const long long nvox = (long long)gd->X * gd->Y * gd->Z;
+  const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
+  grid_adam_kernel<C><<<nb, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
+                                          extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, nvox, gd->density_scale,
+                                          gd->density_pre_act, bricked ? 1 : 0, gd->Y, gd->Z, h);
+}
+
+bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, float* gpacked, const float* extra_d, const float* extra_f,
+                      float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
+                      long long step, float* packed_out, hipStream_t st) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);   // same host arithmetic as launch_adam()
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const AdamHyper h{(float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps};
+  switch (gd->F + 1) {
+    case 2: launch_grid_adam_t<2>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 4: launch_grid_adam_t<4>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 13: launch_grid_adam_t<13>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 28: launch_grid_adam_t<28>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 49: launch_grid_adam_t<49>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+  }
+  return false;
 }
 
 // ------------------------------------------------------------------------------------------------

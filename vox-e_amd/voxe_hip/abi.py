@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # VoxeStatus
 OK = 0
@@ -101,6 +101,7 @@ _COMMON = {
     "cc_largest_k": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P], True, True),
 }
 
+GRAD_ANY, GRAD_LINEAR, GRAD_BRICKED = -1, 0, 1
 GRAPH_CAP_ONE = 1 << 28
 DIR_XP, DIR_XM, DIR_YP, DIR_YM, DIR_ZP, DIR_ZM = range(6)
 
@@ -118,6 +119,13 @@ HIP_ONLY = {
     "strerror": (C.c_char_p, [C.c_int]),
     "device_check": (C.c_int, [C.c_char_p, C.c_size_t]),
     "workspace_bytes": (C.c_size_t, [_GD, _RC, C.c_int64]),
+    # fused optimiser step of a grid (gradient stays in the workspace between the two calls)
+    "render_bwd_acc": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                 C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
+    "workspace_grad_offset": (C.c_size_t, [_GD]),
+    "workspace_grad_bytes": (C.c_size_t, [_GD]),
+    "grid_adam_step": (C.c_int, [_GD, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int64, _P, C.c_size_t, _P]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "graphcut_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

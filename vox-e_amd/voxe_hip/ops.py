@@ -458,6 +458,78 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
         torch.autograd.graph.increment_version(t)
 
 
+def render_bwd_acc(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
+                   colour, depth, acc, g_colour, g_depth, g_acc, workspace: Workspace, rng=(0, 0),
+                   zero_first: bool = True, want_densities: bool = True, want_features: bool = True) -> int:
+    """voxe_render_bwd_acc: the backward of one render, its gradient LEFT in the workspace (kernel layout) for
+    `grid_adam_step_`.  Returns the layout (abi.GRAD_*); renders accumulated into one step must agree on it."""
+    device = densities.device
+    L = lib()
+    R = rays_o.shape[0]
+    key = _pack_key(spec, densities, features)
+    g, c = _descs(spec, params, densities, features, rng[0], rng[1], workspace.key == key)
+    layout = C.c_int32(abi.GRAD_ANY)
+    with torch.cuda.device(device):
+        ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
+        c.reuse_packed_grid = int(workspace.key == key)
+        c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng))
+        check(L.voxe_render_bwd_acc(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
+                                    ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
+                                    int(want_densities), int(want_features), int(zero_first), C.byref(layout),
+                                    ptr(ws), ws.numel(), stream_ptr(device)), "voxe_render_bwd_acc")
+    workspace.key = key
+    return int(layout.value)
+
+
+def workspace_grad_view(spec: GridSpec, densities, features, workspace: Workspace) -> torch.Tensor:
+    """float32 view of the workspace's gradient region (what a data-parallel job all-reduces between
+    `render_bwd_acc` and `grid_adam_step_`)."""
+    g, _ = _descs(spec, RenderParams(num_samples=1, near=0.0, far=1.0), densities, features, 0, 0, False)
+    L = lib()
+    off, nbytes = L.voxe_workspace_grad_offset(C.byref(g)), L.voxe_workspace_grad_bytes(C.byref(g))
+    if workspace.buf is None or workspace.buf.numel() < off + nbytes:
+        raise VoxeError("workspace_grad_view: the workspace holds no gradient region yet")
+    return workspace.buf[off:off + nbytes].view(torch.float32)
+
+
+@torch.no_grad()
+def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, workspace: Workspace, step: int, lr: float,
+                    state_densities=None, state_features=None, extra_d_densities=None, extra_d_features=None,
+                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+    """voxe_grid_adam_step: consume the workspace gradient (+ optional extra gradients in tensor layout), update
+    densities / features in place with torch.optim.Adam arithmetic, leave the NEW grid packed and a zeroed gradient
+    region in the workspace.  state_* = (exp_avg, exp_avg_sq) or None to freeze that tensor."""
+    device = densities.device
+    ensure_gfx950(device)
+    tensors = [("densities", densities, densities), ("features", features, features)]
+    for nm, st, ref in (("state_densities", state_densities, densities), ("state_features", state_features, features)):
+        if st is not None:
+            tensors += [(nm, st[0], ref), (nm, st[1], ref)]
+    for nm, t, ref in (("extra_d_densities", extra_d_densities, densities), ("extra_d_features", extra_d_features, features)):
+        if t is not None:
+            tensors.append((nm, t, ref))
+    for nm, t, ref in tensors:
+        require_device(t, f"grid_adam_step_ ({nm})")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != ref.numel():
+            raise VoxeError(f"grid_adam_step_: {nm} must be contiguous float32 of its parameter's size")
+    if workspace.buf is None:
+        raise VoxeError("grid_adam_step_: the workspace holds no gradient (call render_bwd_acc first)")
+    g, _ = _descs(spec, RenderParams(num_samples=1, near=0.0, far=1.0), densities, features, 0, 0, False)
+    m_d, v_d = state_densities if state_densities is not None else (None, None)
+    m_f, v_f = state_features if state_features is not None else (None, None)
+    with torch.cuda.device(device):
+        ws = workspace.buf
+        check(lib().voxe_grid_adam_step(C.byref(g), int(grad_layout), ptr(extra_d_densities), ptr(extra_d_features),
+                                        ptr(m_d), ptr(v_d), ptr(m_f), ptr(v_f), float(lr), float(beta1), float(beta2),
+                                        float(eps), int(step), ptr(ws), ws.numel(), stream_ptr(device)),
+              "voxe_grid_adam_step")
+    for t in (densities, features, m_d, v_d, m_f, v_f):
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+    workspace.key = _pack_key(spec, densities, features)   # the workspace holds the updated grid packed
+    workspace.state_key = None
+
+
 @torch.no_grad()
 def upsample_trilinear(src: torch.Tensor, out_size: Sequence[int]) -> torch.Tensor:
     """[X,Y,Z,C] -> [X2,Y2,Z2,C], F.interpolate(trilinear, align_corners=False) semantics
