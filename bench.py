@@ -135,27 +135,30 @@ def main():
         p_shard = torch.empty(per, dtype=torch.float32, device=dev)
 
     fused = args.optimizer == "fused" and not args.no_adam and not sharded_opt
-    m_feat, m_dens = exp_avg[: nvox * 3], exp_avg[nvox * 3:]
-    v_feat, v_dens = exp_avg_sq[: nvox * 3], exp_avg_sq[nvox * 3:]
     first = [True]
+    if fused:
+        from thre3d_atom.modules.parallel import ShardedGridAdam
 
-    def fused_step():
-        # the gradient stays in the workspace in the backward kernel's layout; N > 1 sums THAT region over the ranks;
-        # one pass then applies the chain rule of the density pre-activation, Adam on both tensors, writes the packed
-        # grid of the next forward and clears the gradient for the next backward
+        # N = 1: the fused step.  N > 1: reduce-scatter of the gradient region over x-slabs, the fused step on this
+        # rank's slab, all-gather of the packed grid (thre3d_atom/modules/parallel.py)
+        opt = ShardedGridAdam(spec, dens, feat, lr=1e-4, exercise_collectives=os.environ.get("VOXE_BENCH_FORCE_DIST") == "1")
+        exp_avg = exp_avg_sq = None   # (the split path's moments; the fused optimiser owns its own)
+
+    def fused_step(prm, ro, rd, outs, gcol, wsx):
+        # the gradient stays in the workspace in the backward kernel's layout; one pass then applies the chain rule of
+        # the density pre-activation and Adam to both tensors, writes the packed grid of the next forward and clears
+        # the gradient for the next backward
         step_no[0] += 1
         rng = (42, step_no[0])
-        ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
-        layout = ops.render_bwd_acc(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, g_colour, None,
-                                    None, ws, rng, zero_first=first[0])
+        ops.render_fwd_into(spec, prm, dens, feat, ro, rd, None, *outs, wsx, rng)
+        layout = ops.render_bwd_acc(spec, prm, dens, feat, ro, rd, None, outs[0], outs[1], outs[2], gcol, None, None,
+                                    wsx, rng, zero_first=first[0])
         first[0] = False
-        if dist is not None:
-            dist.all_reduce(ops.workspace_grad_view(spec, dens, feat, ws))
-        ops.grid_adam_step_(spec, dens, feat, layout, ws, step_no[0], 1e-4, (m_dens, v_dens), (m_feat, v_feat))
+        opt.step(wsx, layout)
 
     def step():
         if fused:
-            return fused_step()
+            return fused_step(params, rays_o, rays_d, (colour, depth, acc, disp), g_colour, ws)
         step_no[0] += 1
         rng = (42, step_no[0])
         ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
@@ -197,6 +200,19 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # outside the timed region: every rank must hold the same packed grid (what the next render samples); the sharded
+    # optimiser then makes the raw parameter tensors whole again
+    replicas_consistent = None
+    if dist is not None and fused:
+        packed = ops.workspace_packed_view(spec, dens, feat, ws).double()
+        chk = torch.stack([packed.sum(), packed.abs().sum(), (packed * packed).sum()])
+        lo_chk, hi_chk = chk.clone(), chk.clone()
+        dist.all_reduce(lo_chk, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_chk, op=dist.ReduceOp.MAX)
+        replicas_consistent = bool(torch.equal(lo_chk, hi_chk))
+        opt.gather_parameters()
+        del packed
 
     rays_per_s = world * R * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -257,18 +273,9 @@ def main():
                                    dens, feat, ro2, rd2, outputs=("inside",))["inside"]
         s_in2 = int(inside2.sum().item())
 
-        zero2 = [True]
-
         def step2():
             if fused:
-                step_no[0] += 1
-                rng = (42, step_no[0])
-                ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
-                layout = ops.render_bwd_acc(spec, p2, dens, feat, ro2, rd2, None, out2[0], out2[1], out2[2], g2, None, None,
-                                            ws2, rng, zero_first=zero2[0])
-                zero2[0] = False
-                ops.grid_adam_step_(spec, dens, feat, layout, ws2, step_no[0], 1e-4, (m_dens, v_dens), (m_feat, v_feat))
-                return
+                return fused_step(p2, ro2, rd2, out2, g2, ws2)
             step_no[0] += 1
             rng = (42, step_no[0])
             ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
@@ -276,6 +283,7 @@ def main():
                                 d_dens, d_feat, ws2, rng)
             ops.adam_step_(flat_p, flat_g, exp_avg, exp_avg_sq, step_no[0], lr=1e-4)
 
+        first[0] = True   # (another workspace: its gradient region starts uncleared)
         for _ in range(args.warmup):
             step2()
         torch.cuda.synchronize()
@@ -339,7 +347,8 @@ def main():
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
                             f"{'' if args.no_adam else (' + Adam (fused grid step)' if fused else ' + Adam')}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
-                "grad_exchange": ("reduce-scatter + sharded Adam + all-gather" if sharded_opt else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
+                "grad_exchange": (opt.mode if fused else ("reduce-scatter + sharded Adam + all-gather" if sharded_opt else ("all-reduce" if dist is not None else "none"))), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
+                "replicas_consistent": replicas_consistent,
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
             },
             "roofline": roofline, "secondary": secondary,

@@ -245,6 +245,10 @@ int voxe_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t 
  *   pre-activation applied like voxe_render_bwd does) + optional extra gradients in API layout (regularisers);
  *   exp_avg / exp_avg_sq: Adam state per tensor, NULL pair = that tensor is frozen.  Afterwards the workspace holds the
  *   NEW grid packed (pass reuse_packed_grid = 1 to the next render) and a ZEROED gradient region (pass zero_first = 0).
+ *   [x_begin, x_end) restricts the step to the voxels of those x-planes (0, X = the whole grid; x_begin must be even
+ *   for VOXE_GRAD_BRICKED unless it is 0 ... X): an optimiser sharded over GPUs updates only its slab -- a slab is one
+ *   contiguous byte range of every tensor involved, the workspace's packed grid and gradient regions included
+ *   (voxe_workspace_grad_offset + x_begin * Y * Z * (F + 1) * 4 in the linear layout).
  *   Arithmetic identical to voxe_render_bwd + voxe_adam_step, bit for bit.                                        */
 enum { VOXE_GRAD_ANY = -1, VOXE_GRAD_LINEAR = 0, VOXE_GRAD_BRICKED = 1 };
 int voxe_render_bwd_acc(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
@@ -255,7 +259,7 @@ int voxe_render_bwd_acc(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                         void* workspace, size_t workspace_bytes, void* stream);
 size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid);  /* byte offset / size of the gradient region, e.g. */
 size_t voxe_workspace_grad_bytes(const VoxeGridDesc* grid);   /* for the multi-GPU all-reduce between the two calls */
-int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout,
+int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x_begin, int32_t x_end,
                         const float* extra_d_densities, const float* extra_d_features,
                         float* exp_avg_densities, float* exp_avg_sq_densities,
                         float* exp_avg_features, float* exp_avg_sq_features,

@@ -91,3 +91,134 @@ def test_shard_rows_partition():
             bands = [shard_rows(H, r, world) for r in range(world)]
             assert bands[0][0] == 0 and bands[-1][1] == H
             assert all(bands[i][1] == bands[i + 1][0] for i in range(world - 1))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ShardedGridAdam (reduce-scatter of the gradient region, fused step on this rank's x-slab, all-gather of the packed
+# grid) with a CPU stand-in for the four voxe_hip.ops functions it calls: same layouts (linear / 2x2x2 bricks), same
+# contract (the step consumes + clears the gradient slab and writes the packed slab).
+# ------------------------------------------------------------------------------------------------------------------
+class _CpuWorkspace:
+    def __init__(self, X, Y, Z, C):
+        self.packed = torch.zeros(X * Y * Z * C)
+        nb = ((X + 1) // 2) * ((Y + 1) // 2) * ((Z + 1) // 2) * 8
+        self.grad = torch.zeros(nb * C + 16)          # + tail padding like the 256-byte aligned region
+
+
+def _brick_slots(X, Y, Z):
+    x, y, z = torch.meshgrid(torch.arange(X), torch.arange(Y), torch.arange(Z), indexing="ij")
+    by, bz = (Y + 1) // 2, (Z + 1) // 2
+    return (((x // 2) * by + y // 2) * bz + z // 2) * 8 + (x % 2) * 4 + (y % 2) * 2 + z % 2
+
+
+class _CpuOps:
+    """stand-in backend: packed texel = (features, density), Adam in float32 like torch.optim.Adam"""
+
+    @staticmethod
+    def workspace_grad_view(spec, dens, feat, ws):
+        return ws.grad
+
+    @staticmethod
+    def workspace_packed_view(spec, dens, feat, ws):
+        return ws.packed
+
+    @staticmethod
+    def store_gradient(ws, g_full, layout):       # g_full [X,Y,Z,C] -> the region in `layout`
+        X, Y, Z, C = g_full.shape
+        ws.grad.zero_()
+        if layout == 1:
+            ws.grad[: ws.grad.numel() - 16].view(-1, C)[_brick_slots(X, Y, Z).reshape(-1)] = g_full.reshape(-1, C)
+        else:
+            ws.grad[: g_full.numel()] = g_full.reshape(-1)
+
+    @staticmethod
+    def grid_adam_step_(spec, dens, feat, layout, ws, step, lr, state_densities=None, state_features=None, beta1=0.9,
+                        beta2=0.999, eps=1e-8, x_range=None):
+        X, Y, Z, F = feat.shape
+        C = F + 1
+        x0, x1 = x_range if x_range is not None else (0, X)
+        if layout == 1:
+            slots = _brick_slots(X, Y, Z)[x0:x1].reshape(-1)
+            rows = ws.grad[: ws.grad.numel() - 16].view(-1, C)
+            g = rows[slots].view(x1 - x0, Y, Z, C).clone()
+            rows[slots] = 0.0
+        else:
+            flat = ws.grad[x0 * Y * Z * C: x1 * Y * Z * C]
+            g = flat.view(x1 - x0, Y, Z, C).clone()
+            flat.zero_()
+        for p, st, gi in ((feat, state_features, g[..., :F]), (dens, state_densities, g[..., F:])):
+            if st is None:
+                continue
+            m, v = st[0][x0:x1], st[1][x0:x1]
+            m.lerp_(gi, 1 - beta1)
+            v.mul_(beta2).addcmul_(gi, gi, value=1 - beta2)
+            denom = (v.sqrt() / (1 - beta2 ** step) ** 0.5).add_(eps)
+            p[x0:x1].addcdiv_(m, denom, value=-lr / (1 - beta1 ** step))
+        ws.packed.view(X, Y, Z, C)[x0:x1] = torch.cat((feat[x0:x1], dens[x0:x1]), dim=-1)
+
+
+def _sharded_worker(rank, world, port, results):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "vox-e_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from thre3d_atom.modules import parallel
+
+    assert parallel.slab_of(8, 1, 2) == (4, 8) and parallel.slab_of(8, 0, 2, 2) == (0, 4)
+    assert parallel.slab_of(6, 0, 2, 2) is None and parallel.slab_of(5, 0, 2) is None
+    modes = {}
+    for name, (X, Y, Z, F, layout) in {"linear": (6, 5, 3, 3, 0), "bricked": (8, 5, 3, 3, 1), "bricked_odd_x": (6, 4, 4, 1, 1),
+                                       "indivisible": (5, 4, 3, 3, 0)}.items():
+        C = F + 1
+        gen = torch.Generator().manual_seed(3)
+        dens0, feat0 = torch.randn(X, Y, Z, 1, generator=gen), torch.randn(X, Y, Z, F, generator=gen)
+        grads = [[torch.randn(X, Y, Z, C, generator=gen) for _ in range(world)] for _ in range(3)]   # [step][rank]
+        # reference: one process, summed gradient
+        rd, rf, rws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
+        rm = ((torch.zeros_like(rd), torch.zeros_like(rd)), (torch.zeros_like(rf), torch.zeros_like(rf)))
+        for k, per_rank in enumerate(grads):
+            _CpuOps.store_gradient(rws, sum(per_rank[1:], per_rank[0]), layout)
+            _CpuOps.grid_adam_step_(None, rd, rf, layout, rws, k + 1, 0.05, rm[0], rm[1])
+        # this rank of the sharded job
+        d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
+        opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps)
+        for per_rank in grads:
+            _CpuOps.store_gradient(ws, per_rank[rank], layout)
+            opt.step(ws, layout)
+            # every rank holds the same, complete packed grid for the next render ...
+            assert torch.equal(ws.packed, rws.packed) or per_rank is not grads[-1]
+            # ... and a cleared gradient region for the next backward
+            assert float(ws.grad.abs().max()) == 0.0
+        modes[name] = opt.mode
+        assert torch.equal(ws.packed, rws.packed), name
+        x0, x1 = parallel.slab_of(X, rank, world, 2 if layout == 1 else 1) or (0, X)
+        assert torch.equal(d[x0:x1], rd[x0:x1]) and torch.equal(f[x0:x1], rf[x0:x1]), name
+        if opt.mode.startswith("reduce-scatter") and world > 1:
+            other = slice(0, x0) if x0 > 0 else slice(x1, X)
+            assert torch.equal(d[other], dens0[other]), "a rank must not touch the raw parameters outside its slab"
+        opt.gather_parameters()
+        assert torch.equal(d, rd) and torch.equal(f, rf), name
+    assert modes["linear"].startswith("reduce-scatter") and modes["bricked"].startswith("reduce-scatter")
+    assert modes["bricked_odd_x"].startswith("all-reduce")       # 6 x-planes = 3 brick pairs: not divisible by 2 ranks
+    assert modes["indivisible"].startswith("all-reduce")
+    results[rank] = True
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_sharded_grid_adam():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as manager:
+        results = manager.dict()
+        procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, results)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(100)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert len(results) == world

@@ -229,3 +229,40 @@ def test_fused_step_argument_errors():
         ops.grid_adam_step_(spec, dens, feat, 7, ws, 1, LR, (m, m.clone()))
     with pytest.raises(ops.VoxeError):   # step < 1
         ops.grid_adam_step_(spec, dens, feat, abi.GRAD_LINEAR, ws, 0, LR, (m, m.clone()))
+
+
+@pytest.mark.parametrize("ordered,dims,slabs", [(True, (40, 40, 40), [(0, 20), (20, 40)]),
+                                                (True, (37, 40, 33), [(0, 11), (11, 12), (12, 37)]),
+                                                (False, (40, 36, 33), [(0, 10), (10, 20), (20, 30), (30, 40)]),
+                                                (False, (37, 40, 33), [(0, 36), (36, 37)])])
+def test_slab_steps_equal_full_step(ordered, dims, slabs):
+    """x_range: the step applied slab by slab (what the ranks of a sharded optimiser do, each on its own slab) leaves
+    exactly the parameters, moments, packed grid and cleared gradient of one full step"""
+    hw = 96 if ordered else 64
+    dens, feat, ro, rd = _scene(40, 3, hw, ordered, dims)
+    spec = ops.GridSpec(aabb=AABB, density_scale=100.0 / 3.0)
+    params = ops.RenderParams(num_samples=96, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw if ordered else 0)
+    part = _Run("fused", dens, feat, spec, params, ro, rd, 3)
+    rng = (9, 100)
+    ops.render_fwd_into(spec, params, part.dens, part.feat, ro, rd, None, *part.out, part.ws, rng)
+    args = (spec, params, part.dens, part.feat, ro, rd, None, part.out[0], part.out[1], part.out[2], part.g_colour,
+            part.g_depth, part.g_acc)
+    layout = ops.render_bwd_acc(*args, part.ws, rng)
+    region = ops.workspace_grad_view(spec, part.dens, part.feat, part.ws)
+    d_dens, d_feat = _region_to_gradients(region.clone(), layout, part.dens, spec, 4)
+    ref = _Run("shadow", dens, feat, spec, params, ro, rd, 3)     # the full step through voxe_adam_step, same gradient bits
+    ref.shadow_step((d_dens, d_feat))
+    for x0, x1 in slabs:
+        ops.grid_adam_step_(spec, part.dens, part.feat, layout, part.ws, 1, LR, (part.m[0], part.v[0]), (part.m[1], part.v[1]),
+                            x_range=(x0, x1))
+    _compare(ref, part)
+    assert float(region.abs().max()) == 0.0
+    got = ops.workspace_packed_view(spec, part.dens, part.feat, part.ws).view(*dims, 4)
+    assert torch.equal(got[..., :3], part.feat) and torch.equal(got[..., 3:], part.dens * spec.density_scale)
+    if layout == abi.GRAD_BRICKED:
+        with pytest.raises(ops.VoxeError):      # bricks pair x-planes: a slab cannot start on an odd plane
+            ops.grid_adam_step_(spec, part.dens, part.feat, layout, part.ws, 2, LR, (part.m[0], part.v[0]),
+                                (part.m[1], part.v[1]), x_range=(1, 3))
+    with pytest.raises(ops.VoxeError):
+        ops.grid_adam_step_(spec, part.dens, part.feat, layout, part.ws, 2, LR, (part.m[0], part.v[0]),
+                            (part.m[1], part.v[1]), x_range=(0, dims[0] + 1))

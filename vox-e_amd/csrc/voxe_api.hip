@@ -375,19 +375,23 @@ size_t voxe_workspace_grad_bytes(const VoxeGridDesc* grid) {
   return l.state_off - l.grad_off;
 }
 
-int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, const float* extra_d_densities,
+int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x_begin, int32_t x_end,
+                        const float* extra_d_densities,
                         const float* extra_d_features, float* exp_avg_d, float* exp_avg_sq_d, float* exp_avg_f,
                         float* exp_avg_sq_f, float lr, float beta1, float beta2, float eps, int64_t step,
                         void* workspace, size_t workspace_bytes, void* stream) {
   if (!grid || !grid->densities || !grid->features) return VOXE_ERR_NULL_POINTER;
   if (grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0 || step < 1) return VOXE_ERR_BAD_SHAPE;
+  if (x_begin < 0 || x_end > grid->X || x_begin > x_end) return VOXE_ERR_BAD_SHAPE;
+  if (grad_layout == VOXE_GRAD_BRICKED && (x_begin & 1) && x_begin != x_end) return VOXE_ERR_BAD_SHAPE;
   if ((exp_avg_d == nullptr) != (exp_avg_sq_d == nullptr) || (exp_avg_f == nullptr) != (exp_avg_sq_f == nullptr))
     return VOXE_ERR_NULL_POINTER;
   if (grad_layout != VOXE_GRAD_LINEAR && grad_layout != VOXE_GRAD_BRICKED && grad_layout != VOXE_GRAD_ANY)
     return VOXE_ERR_UNSUPPORTED;
   const WsLayout l = ws_layout(grid, nullptr, 0);
   if (!workspace || workspace_bytes < l.state_off) return VOXE_ERR_WORKSPACE;
-  if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, (float*)((char*)workspace + l.grad_off),
+  if (x_begin == x_end) return VOXE_OK;
+  if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, x_begin, x_end, (float*)((char*)workspace + l.grad_off),
                         extra_d_densities, extra_d_features, exp_avg_d, exp_avg_sq_d, exp_avg_f, exp_avg_sq_f, lr, beta1,
                         beta2, eps, step, (float*)((char*)workspace + l.packed_off), (hipStream_t)stream))
     return VOXE_ERR_UNSUPPORTED;

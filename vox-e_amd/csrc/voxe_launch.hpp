@@ -32,7 +32,7 @@ void launch_pack_any(const VoxeGridDesc* gd, float* packed, hipStream_t st);
 void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
                        int accumulate, int bricked, hipStream_t st);
 // fused un-pack + Adam + re-pack (false: channel count without a kernel)
-bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, float* gpacked, const float* extra_d, const float* extra_f,
+bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
                       long long step, float* packed_out, hipStream_t st);
 void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,

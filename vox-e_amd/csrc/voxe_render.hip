@@ -116,11 +116,11 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
                                                         const float* __restrict__ extra_f, float* __restrict__ m_d,
                                                         float* __restrict__ v_d, float* __restrict__ m_f,
                                                         float* __restrict__ v_f, float* __restrict__ packed,
-                                                        long long nvox, float scale, int pre_act, int bricked, int Y,
-                                                        int Z, AdamHyper h) {
+                                                        long long vox_begin, long long vox_end, float scale,
+                                                        int pre_act, int bricked, int Y, int Z, AdamHyper h) {
   constexpr int F = C - 1;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvox; i += stride) {
+  for (long long i = vox_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox_end; i += stride) {
     long long si = i;
     if (bricked) {
       const int z = (int)(i % Z), y = (int)((i / Z) % Y), x = (int)(i / ((long long)Y * Z));
@@ -173,28 +173,28 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
 }
 
 template <int C>
-static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, float* gpacked, const float* extra_d,
+static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d,
                                const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h,
                                float* packed_out, hipStream_t st) {
-  const long long nvox = (long long)gd->X * gd->Y * gd->Z;
+  const long long plane = (long long)gd->Y * gd->Z, nvox = (x_end - x_begin) * plane;
   const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
   grid_adam_kernel<C><<<nb, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
-                                          extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, nvox, gd->density_scale,
+                                          extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane, x_end * plane, gd->density_scale,
                                           gd->density_pre_act, bricked ? 1 : 0, gd->Y, gd->Z, h);
 }
 
-bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, float* gpacked, const float* extra_d, const float* extra_f,
+bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
                       long long step, float* packed_out, hipStream_t st) {
   const double bc1 = 1.0 - pow((double)beta1, (double)step);   // same host arithmetic as launch_adam()
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const AdamHyper h{(float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps};
   switch (gd->F + 1) {
-    case 2: launch_grid_adam_t<2>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 4: launch_grid_adam_t<4>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 13: launch_grid_adam_t<13>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 28: launch_grid_adam_t<28>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 49: launch_grid_adam_t<49>(gd, bricked, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
   }
   return false;
 }

@@ -4,7 +4,9 @@ single-process / single-GPU: no torch.distributed call anywhere in it).
 One process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI on ROCm).  The grid is
 replicated, rays / cameras are split by rank with no collective inside the render, and the voxel-grid
 gradient is summed with ONE all-reduce per step over a flat buffer that both parameter tensors view
-(65.5 MB at 160^3), followed by the identical optimiser step on every rank.
+(65.5 MB at 160^3), followed by the identical optimiser step on every rank (FlatGrid) -- or, with the fused grid
+optimiser step, summed by a reduce-scatter over x-slabs, stepped on 1/world of the grid per rank and the PACKED grid
+all-gathered for the next render (ShardedGridAdam: the wire bytes of the all-reduce, the optimiser pass / world).
 Everything here is plumbing on torch tensors (works on CPU tensors with gloo, which is how it is tested).
 """
 from typing import List, Tuple
@@ -113,3 +115,96 @@ def all_gather_rows(local: torch.Tensor, height: int, align: int = 8) -> torch.T
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded)
     return torch.cat([part[: hi - lo] for part, (lo, hi) in zip(parts, bands)], dim=0)
+
+
+def slab_of(extent: int, rank: int, world: int, align: int = 1):
+    """[begin, end) of rank's equal share of `extent` x-planes in multiples of `align`, or None when it does not
+    divide (collectives over slabs need equal sizes; the caller then falls back to the replicated step)."""
+    if world < 1 or extent % (world * align) != 0:
+        return None
+    per = extent // world
+    return rank * per, (rank + 1) * per
+
+
+class ShardedGridAdam:
+    """Optimiser step of ONE voxel grid in a data-parallel job, on top of the fused grid step
+    (voxe_render_bwd_acc leaves every rank's gradient in its workspace; voxe_grid_adam_step consumes it).
+
+    world == 1                 : the plain fused step.
+    X divisible by the world   : ZeRO-1 over x-slabs -- reduce-scatter of the gradient region (each rank receives the
+        sum of ITS slab), fused Adam on that slab only (raw parameters + moments of the other slabs are never touched
+        on this rank), all-gather of the packed grid's slabs, in place, so every rank renders the same updated grid.
+        Same wire bytes as one all-reduce; the optimiser's HBM pass shrinks by `world`.
+    otherwise                  : all-reduce of the gradient region + the replicated full step.
+    `gather_parameters()` makes the raw tensors whole again on every rank (checkpoints, upsampling between stages).
+
+    `backend` is voxe_hip.ops; tests substitute a CPU stand-in with the same four functions."""
+
+    def __init__(self, spec, densities: torch.Tensor, features: torch.Tensor, lr: float, betas=(0.9, 0.999),
+                 eps: float = 1e-8, train_densities: bool = True, train_features: bool = True, backend=None,
+                 exercise_collectives: bool = False):
+        if backend is None:
+            from voxe_hip import ops as backend
+        self.ops, self.spec, self.densities, self.features = backend, spec, densities, features
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.state_densities = (torch.zeros_like(densities), torch.zeros_like(densities)) if train_densities else None
+        self.state_features = (torch.zeros_like(features), torch.zeros_like(features)) if train_features else None
+        self.steps = 0
+        self.exercise_collectives = exercise_collectives   # run the collectives even in a 1-rank group (bring-up)
+        self._shard = None
+        self.mode = "single"
+
+    def _slab(self, grad_layout: int):
+        """(x_begin, x_end, floats per slab in the gradient region, floats per slab in the packed grid) or None"""
+        rank, world = world_info()
+        X, Y, Z = (int(v) for v in self.densities.shape[:3])
+        C = int(self.features.shape[-1]) + 1
+        bricked = grad_layout == 1   # VOXE_GRAD_BRICKED
+        xr = slab_of(X, rank, world, 2 if bricked else 1)
+        if xr is None:
+            return None
+        planes = xr[1] - xr[0]
+        g_per = (planes // 2) * ((Y + 1) // 2) * ((Z + 1) // 2) * 8 * C if bricked else planes * Y * Z * C
+        return xr[0], xr[1], g_per, planes * Y * Z * C
+
+    @torch.no_grad()
+    def step(self, workspace, grad_layout: int) -> None:
+        rank, world = world_info()
+        self.steps += 1
+        kw = dict(state_densities=self.state_densities, state_features=self.state_features, beta1=self.betas[0],
+                  beta2=self.betas[1], eps=self.eps)
+        args = (self.spec, self.densities, self.features, grad_layout, workspace, self.steps, self.lr)
+        if world == 1 and not (self.exercise_collectives and dist.is_initialized()):
+            self.mode = "single"
+            return self.ops.grid_adam_step_(*args, **kw)
+        region = self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace)
+        slab = self._slab(grad_layout)
+        if slab is None:
+            self.mode = "all-reduce + replicated step"
+            dist.all_reduce(region)
+            return self.ops.grid_adam_step_(*args, **kw)
+        self.mode = "reduce-scatter + sharded step + all-gather of the packed grid"
+        x0, x1, g_per, p_per = slab
+        if self._shard is None or self._shard.numel() != g_per:
+            self._shard = torch.empty(g_per, dtype=region.dtype, device=region.device)
+        dist.reduce_scatter_tensor(self._shard, region[: world * g_per])
+        # the step reads (and clears) the gradient in place: put the summed slab where the kernel expects it and clear
+        # what this rank's own backward left in the other slabs
+        region[: rank * g_per].zero_()
+        region[(rank + 1) * g_per:].zero_()
+        region[rank * g_per: (rank + 1) * g_per].copy_(self._shard)
+        self.ops.grid_adam_step_(*args, x_range=(x0, x1), **kw)
+        packed = self.ops.workspace_packed_view(self.spec, self.densities, self.features, workspace)
+        dist.all_gather_into_tensor(packed, packed[rank * p_per: (rank + 1) * p_per])
+
+    @torch.no_grad()
+    def gather_parameters(self) -> None:
+        """all ranks -> the full raw tensors (a no-op unless the sharded mode ran)"""
+        rank, world = world_info()
+        if not self.mode.startswith("reduce-scatter"):
+            return
+        for t in (self.densities, self.features):
+            flat = t.view(-1)
+            per = flat.numel() // world
+            dist.all_gather_into_tensor(flat, flat[rank * per: (rank + 1) * per].clone())
+            torch.autograd.graph.increment_version(t)

@@ -124,7 +124,7 @@ HIP_ONLY = {
                                  C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
     "workspace_grad_offset": (C.c_size_t, [_GD]),
     "workspace_grad_bytes": (C.c_size_t, [_GD]),
-    "grid_adam_step": (C.c_int, [_GD, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+    "grid_adam_step": (C.c_int, [_GD, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int64, _P, C.c_size_t, _P]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

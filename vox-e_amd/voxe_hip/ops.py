@@ -492,13 +492,25 @@ def workspace_grad_view(spec: GridSpec, densities, features, workspace: Workspac
     return workspace.buf[off:off + nbytes].view(torch.float32)
 
 
+def workspace_packed_view(spec: GridSpec, densities, features, workspace: Workspace) -> torch.Tensor:
+    """float32 view [X*Y*Z*(F+1)] of the workspace's packed grid (what the next render samples): a sharded optimiser
+    all-gathers the x-slabs of THIS instead of the raw parameters."""
+    n = densities.numel() + features.numel()
+    if workspace.buf is None or workspace.buf.numel() < 4 * n:
+        raise VoxeError("workspace_packed_view: the workspace holds no packed grid yet")
+    return workspace.buf[: 4 * n].view(torch.float32)
+
+
 @torch.no_grad()
 def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, workspace: Workspace, step: int, lr: float,
                     state_densities=None, state_features=None, extra_d_densities=None, extra_d_features=None,
-                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8) -> None:
+                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                    x_range: Optional[Tuple[int, int]] = None) -> None:
     """voxe_grid_adam_step: consume the workspace gradient (+ optional extra gradients in tensor layout), update
     densities / features in place with torch.optim.Adam arithmetic, leave the NEW grid packed and a zeroed gradient
-    region in the workspace.  state_* = (exp_avg, exp_avg_sq) or None to freeze that tensor."""
+    region in the workspace.  state_* = (exp_avg, exp_avg_sq) or None to freeze that tensor.  x_range = (x_begin, x_end)
+    restricts the step to a slab of x-planes (sharded optimiser: the caller exchanges the other slabs of the packed grid
+    before the next render)."""
     device = densities.device
     ensure_gfx950(device)
     tensors = [("densities", densities, densities), ("features", features, features)]
@@ -519,7 +531,8 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
     m_f, v_f = state_features if state_features is not None else (None, None)
     with torch.cuda.device(device):
         ws = workspace.buf
-        check(lib().voxe_grid_adam_step(C.byref(g), int(grad_layout), ptr(extra_d_densities), ptr(extra_d_features),
+        x0, x1 = (0, int(densities.shape[0])) if x_range is None else (int(x_range[0]), int(x_range[1]))
+        check(lib().voxe_grid_adam_step(C.byref(g), int(grad_layout), x0, x1, ptr(extra_d_densities), ptr(extra_d_features),
                                         ptr(m_d), ptr(v_d), ptr(m_f), ptr(v_f), float(lr), float(beta1), float(beta2),
                                         float(eps), int(step), ptr(ws), ws.numel(), stream_ptr(device)),
               "voxe_grid_adam_step")
