@@ -16,6 +16,9 @@ timeout 300 python bench.py --grid 256 --image 800 --no-cpu-baseline --steps 10 
 timeout 300 env VOXE_BWD_MODE=scatter python bench.py --no-cpu-baseline --steps 5 2>/dev/null | tail -1 > $O/bench_400_scatter_bwd.json
 timeout 300 python bench.py --term-eps 1e-4 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_400_term1e-4.json
 timeout 300 python bench.py --image 200 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_200.json
+timeout 300 python bench.py --image 266 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_266.json
+timeout 300 python bench.py --optimizer split --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_400_split_optimizer.json
+timeout 300 env VOXE_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/bench_400_rccl_1rank.json
 timeout 300 python tools/refine_bench.py 160 2>/dev/null | tail -4 > $O/refine_bench.txt; cat $O/refine_bench.txt
 timeout 300 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench.txt; cat $O/recon_bench.txt
 for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
