@@ -424,3 +424,43 @@ def test_sample_counts_across_segment_boundaries(S):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(3, 9), image_width=w)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["full", "diffuse"])
+def test_sh_degrees_image_ordered_backward(deg, mode):
+    """view-dependent grids with image-ordered rays: the LDS-window backward runs the 3 * (deg + 1)^2 + 1 gradient
+    channels as groups of 4 (sibling blocks); gradients vs the oracle, vs the ray-order-agnostic kernel, and with one of
+    the two tensors frozen (density only: just the group that holds the density channel is launched)"""
+    g = load_golden("frames32.npz")
+    base = grid_from_golden(g, "", "softplus")
+    rng = np.random.default_rng(deg)
+    feats = rng.uniform(-1, 1, base.densities.shape[:3] + (3 * (deg + 1) ** 2,)).astype(np.float32)
+    grid = vo.Grid(base.densities, feats, base.aabb, base.density_scale, base.density_pre_act, base.density_post_act)
+    h, w = 40, 56
+    o, d = vo.cast_rays(h, w, 0.5 * w / np.tan(0.5 * 0.6911112), g["rot"][3], g["trans"][3])
+    cfg = cfg_from_bounds(g["bounds"], 80, white_bkgd=True, sh_degree=deg, render_diffuse=(mode == "diffuse"))
+    gc = rng.standard_normal((h * w, 3)).astype(np.float32)
+    gdep = rng.standard_normal(h * w).astype(np.float32) * 0.1
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, image_width=w)
+    assert rel_l2(gd, rd) < GRAD_REL_L2 and rel_l2(gf, rf) < GRAD_REL_L2
+    if mode == "diffuse":   # only the degree-0 coefficient of every colour receives a gradient
+        per_colour = gf.reshape(gf.shape[:3] + (3, (deg + 1) ** 2))
+        assert not per_colour[..., 1:].any() and per_colour[..., 0].any()
+    gd0, gf0 = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep)          # linear mapping: generic scatter kernel
+    assert rel_l2(gd, gd0) < 1e-4 and rel_l2(gf, gf0) < 1e-5
+    # one tensor frozen
+    import torch
+    from voxe_hip import ops
+
+    for freeze in ("features", "densities"):
+        dt = gh.t(grid.densities, freeze != "densities")
+        ft = gh.t(grid.features, freeze != "features")
+        c, dep, _, _ = ops.render(gh.spec_of(grid), gh.params_of(cfg, image_width=w), dt, ft, gh.t(o), gh.t(d), None)
+        ((c * gh.t(gc)).sum() + (dep[:, 0] * gh.t(gdep)).sum()).backward()
+        torch.cuda.synchronize()
+        if freeze == "features":
+            assert ft.grad is None and rel_l2(gh.n(dt.grad), rd) < GRAD_REL_L2
+        else:
+            assert dt.grad is None and rel_l2(gh.n(ft.grad), rf) < GRAD_REL_L2

@@ -48,7 +48,7 @@ void launch_query(const DevGrid& g, int C, const float* packed, const float* poi
 
 // voxe_render_tile.hip: LDS-window backward for image-ordered SH-0 / attention renders
 bool tile_bwd_supported(const DevCfg& c, int deg);
-void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st);
+void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
 
 // voxe_render_scatter.hip: line-dense scatter backward for unordered rays (SH-0 / attention)
 bool packed_scatter_supported(int deg);

@@ -175,17 +175,31 @@ __device__ __forceinline__ void gather(const DevGrid& g, const float* __restrict
       v = fmaf(t[k].y, w, v);
     }
   } else {
+    // View-dependent texels (13 / 28 / 49 channels): contract every corner with the SH basis first and interpolate the
+    // COUT resulting values -- the same sum as interpolating COUT * NCU coefficients and contracting afterwards
+    // (process.py:45-78), re-associated so that COUT accumulators stay live instead of COUT * NCU (48 at degree 3:
+    // the kernels spilled 0.5 - 1.3 KB per lane before)
 #pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) rad[ch] = 0.0f;
+    // corners in flight at once: all 8 would be 8 x C loaded values (392 registers at degree 3)
+    constexpr int kCornersInFlight = C > 28 ? 1 : (C > 13 ? 2 : 8);
+#pragma unroll kCornersInFlight
     for (int k = 0; k < 8; ++k) {
-      const float w = wxy[k & 3] * cell.w[2][k >> 2];
+      // (selects, not array indexing: k is a run-time value in the partially unrolled loop)
+      const float wx = (k & 1) ? cell.w[0][1] : cell.w[0][0], wy = (k & 2) ? cell.w[1][1] : cell.w[1][0];
+      const float w = (wx * wy) * ((k & 4) ? cell.w[2][1] : cell.w[2][0]);
       const float* __restrict__ src =
           packed + (long long)(ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz) * C;
 #pragma unroll
-      for (int ch = 0; ch < COUT; ++ch)
+      for (int ch = 0; ch < COUT; ++ch) {
+        float r = basis[0] * src[ch * NCM];
 #pragma unroll
-        for (int j = 0; j < NCU; ++j) f[ch * NCU + j] = fmaf(src[ch * NCM + j], w, f[ch * NCU + j]);
+        for (int j = 1; j < NCU; ++j) r = fmaf(basis[j], src[ch * NCM + j], r);
+        rad[ch] = fmaf(r, w, rad[ch]);
+      }
       v = fmaf(src[C - 1], w, v);
     }
+    return;
   }
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) {

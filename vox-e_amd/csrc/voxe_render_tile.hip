@@ -96,9 +96,12 @@ struct Window {
   // of neighbouring layers lands in different LDS banks
   __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + VOXE_TILE_ROT * ring_slot(key)) & 63; }
 };
-template <int C>
+// WC = channels held by the window, CM = channels of a packed texel, memch = texel channel of THIS lane's window
+// channel (lane % WC)
+template <int WC>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
-                                            const Window& w, int key, int lane) {
+                                            const Window& w, int key, int lane, int CM, int memch) {
+  constexpr int C = WC;
   const int im = w.sgn * key;
   const int offu = w.off_u(im), offv = w.off_v(im);
   const int lbase = ring_slot(key) * kLayerSlots;
@@ -113,24 +116,33 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
       win[idx] = 0.0;
       const int iu = (ab >> 3) + offu, iv = (ab & 7) + offv;
       const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
-      atomicAdd(gpacked + vox * C + ch, (float)val);
+      atomicAdd(gpacked + vox * CM + memch, (float)val);
     }
   }
 }
 
-template <int COUT, bool WANT_D, bool WANT_F>
+// View-dependent grids (SH degree 1-3: NCU = 4 / 9 / 16 coefficients per colour): the window still holds 4 channels;
+// the COUT * NCU + 1 gradient channels are split into GROUPS of 4 that run as sibling blocks (like the tile parts), each
+// re-marching the segment (full gather: the colour needs every coefficient) and depositing its own 4 channels --
+// d rad_c / d coef_cj = basis_j of the ray, a per-lane constant of the pass.  Per-voxel atomics stay combined in LDS;
+// the cost is ngroups x the march instead of (8 corners x channels) global atomics per sample (135 ms -> see DESIGN.md).
+template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F>
 // launch bounds swept: (64, 3) best; 2 and 4..6 are 6-9 % slower (register budget vs the LDS-bound residency)
 #ifndef VOXE_TILE_LB
 #define VOXE_TILE_LB 3
 #endif
-__global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
+__global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
-    const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit) {
-  constexpr int C = COUT + 1;
+    const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit, const int grp_begin,
+    const int ngrp) {
+  constexpr int CM = COUT * NCM + 1;          // channels of a packed texel
+  constexpr int NG = COUT * NCU + 1;          // channels that receive a gradient (the used coefficients + density)
+  constexpr int C = NG < 4 ? NG : 4;          // channels held by the LDS window
+  constexpr int NGRP = (NG + C - 1) / C;      // channel groups (1 for SH-0 / diffuse / attention renders)
   __shared__ double win[C * kPlane];
   const int lane = threadIdx.x;
   for (int i = lane; i < C * kPlane; i += 64) win[i] = 0.0;
@@ -146,10 +158,16 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
   // on the 32 CUs of an XCD whenever nseg divides 32 (measured: kSegLen 32 -> 0.87 ms, 24 -> 0.68 ms for the same
   // work before this ordering).  Tiles are spread over the XCDs by logical_tile_of() (default: tile t on XCD t % 8).
   const int nseg = num_segments(c.S);
-  const int ntp = gridDim.x / (nseg * qsplit);  // tile slots (a multiple of 8 >= ntx * nty)
-  const int part = blockIdx.x / ntp;
+  const int ntp = gridDim.x / (nseg * qsplit * (NGRP == 1 ? 1 : ngrp));  // tile slots (a multiple of 8 >= ntx * nty)
+  int part = blockIdx.x / ntp;
+  int grp = 0;                                   // channel group of this block (outermost: group-major block order)
+  if constexpr (NGRP > 1) {
+    const int g_local = part / (nseg * qsplit);
+    part -= g_local * nseg * qsplit;
+    grp = grp_begin + g_local;
+  }
   const int quad = part / nseg, seg = part - quad * nseg;
-  const int tile = logical_tile_of(c, blockIdx.x - part * ntp, ntp, ntx, nty);
+  const int tile = logical_tile_of(c, blockIdx.x % ntp, ntp, ntx, nty);
   if (tile < 0) return;  // launch padding (wave-uniform)
   const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
   const int ty = tile / ntx, tx = tile - ty * ntx;
@@ -157,7 +175,7 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
   const bool alive = (px < W) && (py < H);
   const long long r = alive ? (long long)py * W + px : 0;
 
-  RayCtx<COUT, 1, 1> rc;
+  RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
 
   // ---- pixel footprint: does the 8x8 tile fit the 8x8 lateral LDS window? ------------------------------
@@ -263,6 +281,29 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
     for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
     if (white) prefix -= gsum * pre_a;
 
+    // window channel s of this block = gradient channel q = grp * C + s: coefficient j of colour ch = q / NCU (texel
+    // channel ch * NCM + j, factor basis_j of this ray) or, last, the density (texel channel CM - 1, factor 1).
+    // NGRP == 1: grp == 0 and everything below is a compile-time constant.
+    int chsel[C], memch[C];     // wave-uniform: which of (d rad_0 .. d rad_{COUT-1}, d v) feeds the slot; -1 = unused
+    float mult[C];
+  #pragma unroll
+    for (int s = 0; s < C; ++s) {
+      const int q = grp * C + s;
+      if (q >= NG) { chsel[s] = -1; memch[s] = 0; mult[s] = 0.0f; }
+      else if (q == NG - 1) { chsel[s] = COUT; memch[s] = CM - 1; mult[s] = 1.0f; }
+      else {
+        const int ch = q / NCU, j = q - ch * NCU;
+        chsel[s] = ch; memch[s] = ch * NCM + j;
+        float b = rc.basis[0];
+  #pragma unroll
+        for (int t = 1; t < NCU; ++t) b = (j == t) ? rc.basis[t] : b;
+        mult[s] = b;
+      }
+    }
+    int my_memch = memch[0];    // texel channel of window channel lane % C (flush)
+  #pragma unroll
+    for (int s = 1; s < C; ++s) my_memch = (lane % C == s) ? memch[s] : my_memch;
+
     // first sample of every ray (rolling: z_cur / fp_cur always describe sample max(k, k_lo))
     float z_cur = 0.0f;
     Footprint fp_cur;
@@ -299,7 +340,7 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
           Cell cell;
           make_cell_fast(g, fp, cell);
           float v, rad[COUT];
-          gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
+          gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
           float sigma, dpost;
           post_activate_vg(g.post_act, v, sigma, dpost);
           const float dl = last ? kInfinity : (z_next - z);
@@ -316,16 +357,21 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
           const float suffix = last ? 0.0f : (total - prefix);
           const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
           const float dsig = (delta * e) * fmaf(T, dldw, -tail);
-          // per-channel gradient of the packed texel: (d rad_c * C0 ..., d v)
+          // gradient w.r.t. (rad_0 .. rad_{COUT-1}, v), then per window channel: x basis_j (SH-0: C0) resp. x 1
+          float gsrc[COUT + 1];
+  #pragma unroll
+          for (int ch = 0; ch < COUT; ++ch) gsrc[ch] = WANT_F ? (wk * gc[ch]) * (col[ch] * (1.0f - col[ch])) : 0.0f;
+          gsrc[COUT] = WANT_D ? dsig * dpost : 0.0f;
           float gch[C];
           bool any = false;
   #pragma unroll
-          for (int ch = 0; ch < COUT; ++ch) {
-            gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
-            any = any || (gch[ch] != 0.0f);
+          for (int s = 0; s < C; ++s) {
+            float x = 0.0f;
+  #pragma unroll
+            for (int t = 0; t <= COUT; ++t) x = (chsel[s] == t) ? gsrc[t] : x;
+            gch[s] = (chsel[s] == COUT) ? x : x * mult[s];
+            any = any || (gch[s] != 0.0f);
           }
-          gch[COUT] = WANT_D ? dsig * dpost : 0.0f;
-          any = any || (gch[COUT] != 0.0f);
           T = T * om;
 
           if (any) {
@@ -357,7 +403,7 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
               // corner bits of instruction cc are (constant bit) ^ (lane bit): every operand pair is swapped ONCE per
               // sample ("A" = value used where the constant bit is 0, "B" where it is 1) and the unrolled loop below
               // contains no selects at all.
-              constexpr bool kAllCh = WANT_D && WANT_F;
+              constexpr bool kAllCh = (WANT_D && WANT_F) || NGRP > 1;   // (several groups: slots are not channels)
               const bool r0 = rot & 1, r1 = rot & 2, r2 = rot & 4;
               const float wmA = r0 ? wm[1] : wm[0], wmB = r0 ? wm[0] : wm[1];
               const float wuA = r1 ? wu[1] : wu[0], wuB = r1 ? wu[0] : wu[1];
@@ -408,7 +454,7 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
                     const int idx = ring_slot(key) * kLayerSlots + w.layer_pos(key, a * kLat + b);
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
-                      if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))
+                      if (NGRP > 1 || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
                         __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -416,7 +462,8 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
                     const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
-                      if ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)) atomicAdd(gpacked + vox * C + ch, gch[ch] * wgt);
+                      if (NGRP > 1 ? (chsel[ch] >= 0) : ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)))
+                        atomicAdd(gpacked + vox * CM + memch[ch], gch[ch] * wgt);
                     }
                   }
                 }
@@ -437,14 +484,14 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
         __syncthreads();
         const long long adv = (long long)newbase - (long long)w.base;
         const int nflush = adv < kRing ? (int)adv : kRing;
-        for (int i = 0; i < nflush; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
+        for (int i = 0; i < nflush; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane, CM, my_memch);
         w.base = newbase;
         __syncthreads();
       }
     }
     __syncthreads();
     if (w.base != INT_MAX) {
-      for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane);
+      for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane, CM, my_memch);
     }
 
   };
@@ -472,33 +519,40 @@ __global__ __launch_bounds__(64, VOXE_TILE_LB) void render_bwd_tile_kernel(
 // VOXE_TILE_MIN_RAYS overrides the threshold (the parity tests set 0 so that small images exercise this kernel).
 bool tile_bwd_supported(const DevCfg& c, int deg) {
   static const long long min_rays = [] { const char* e = getenv("VOXE_TILE_MIN_RAYS"); return e ? atoll(e) : 8192ll; }();
-  return c.image_width > 0 && deg == 0 && c.R >= min_rays;
+  (void)deg;   // every SH degree: view-dependent grids run their gradient channels as groups of 4 (sibling blocks)
+  return c.image_width > 0 && c.R >= min_rays;
 }
 
-void launch_bwd_tile(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
+template <int COUT, int NCM, int NCU>
+static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
   const long long W = c.image_width, H = c.R / W;
   // The parts (halves / quadrants) of a tile run as sibling blocks instead of consecutive passes while the launch is
   // small enough for the extra blocks to pay off (LDS bounds residency at 9 blocks per CU, 2304 on the chip; siblings
   // of a tile that fits the window whole retire at once); measured cross-over on MI355X with the segment-major block
   // order: 15 % better at 266x266 (9248 tile-segments), equal at 320x320 (12800), 3 % worse at 400x400, 8 % at 800x800
   static const int env_q = [] { const char* e = getenv("VOXE_TILE_QSPLIT"); return e ? atoi(e) : 0; }();
-  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S);
+  constexpr int NG = COUT * NCU + 1, WC = NG < 4 ? NG : 4, NGRP = (NG + WC - 1) / WC;
+  // channel groups: all of them for a feature gradient; only the one holding the density channel (the last) otherwise
+  const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
+  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S) * ngrp;
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
-  const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S) * qsplit;
-#define VOXE_TBWD(COUT, WD, WF)                                                                   \
-  render_bwd_tile_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                   \
+  const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S) * qsplit * ngrp;
+#define VOXE_TBWD(WD, WF)                                                                         \
+  render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF><<<nb, 64, 0, st>>>(                              \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit)
-  if (c.attn) {
-    if (a.want_d && a.want_f) VOXE_TBWD(1, true, true);
-    else if (a.want_d) VOXE_TBWD(1, true, false);
-    else VOXE_TBWD(1, false, true);
-  } else {
-    if (a.want_d && a.want_f) VOXE_TBWD(3, true, true);
-    else if (a.want_d) VOXE_TBWD(3, true, false);
-    else VOXE_TBWD(3, false, true);
-  }
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, grp_begin, ngrp)
+  if (a.want_d && a.want_f) VOXE_TBWD(true, true);
+  else if (a.want_d) VOXE_TBWD(true, false);
+  else VOXE_TBWD(false, true);
 #undef VOXE_TBWD
+}
+
+void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st) {
+  if (c.attn) launch_bwd_tile_t<1, 1, 1>(g, c, a, st);
+  else if (deg == 0) launch_bwd_tile_t<3, 1, 1>(g, c, a, st);
+  else if (deg == 1) { if (diffuse) launch_bwd_tile_t<3, 4, 1>(g, c, a, st); else launch_bwd_tile_t<3, 4, 4>(g, c, a, st); }
+  else if (deg == 2) { if (diffuse) launch_bwd_tile_t<3, 9, 1>(g, c, a, st); else launch_bwd_tile_t<3, 9, 9>(g, c, a, st); }
+  else { if (diffuse) launch_bwd_tile_t<3, 16, 1>(g, c, a, st); else launch_bwd_tile_t<3, 16, 16>(g, c, a, st); }
 }
 
 }  // namespace voxe
