@@ -160,6 +160,10 @@ int voxe_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_off
  *   outputs colour [R,Cout] (Cout = 3 SH / 1 attn), depth [R], acc [R], disparity [R]
  *   (any of depth/acc/disparity may be NULL).
  * ---------------------------------------------------------------------------------------------- */
+/* Workspace: [packed grid | packed gradient | per-ray depth-segment states | segment partials | per-sample gradient
+ * sources].  voxe_workspace_bytes() is the size that lets every kernel take its fast route; the forward needs only the
+ * packed grid, and the backward needs everything but the last region (16 B per sample of image-ordered renders of SH
+ * degree >= 1, capped at 4 GB): without it their gradient-channel groups re-march the rays instead of sharing one march. */
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R);
 
 int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,

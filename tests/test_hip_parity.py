@@ -427,11 +427,15 @@ def test_sample_counts_across_segment_boundaries(S):
 
 
 @pytest.mark.parametrize("deg", [1, 2, 3])
-@pytest.mark.parametrize("mode", ["full", "diffuse"])
-def test_sh_degrees_image_ordered_backward(deg, mode):
+@pytest.mark.parametrize("mode", ["full", "diffuse", "full_single_kernel"])
+def test_sh_degrees_image_ordered_backward(deg, mode, monkeypatch):
     """view-dependent grids with image-ordered rays: the LDS-window backward runs the 3 * (deg + 1)^2 + 1 gradient
     channels as groups of 4 (sibling blocks); gradients vs the oracle, vs the ray-order-agnostic kernel, and with one of
-    the two tensors frozen (density only: just the group that holds the density channel is launched)"""
+    the two tensors frozen (density only: just the group that holds the density channel is launched).  "full" takes the
+    two-phase route (per-sample gradient sources in the workspace, then one deposit block per group),
+    "full_single_kernel" the groups that re-march (what runs when the workspace has no room for the sources)"""
+    if mode == "full_single_kernel":
+        monkeypatch.setenv("VOXE_TILE_TWO_PHASE", "0")
     g = load_golden("frames32.npz")
     base = grid_from_golden(g, "", "softplus")
     rng = np.random.default_rng(deg)

@@ -25,6 +25,9 @@ int bwd_mode_override() {
 }
 bool force_scatter_bwd() { return bwd_mode_override() == 1; }
 bool force_no_tile_bwd() { return bwd_mode_override() != 0; }
+// VOXE_TILE_TWO_PHASE=0: view-dependent grids run the single-kernel channel groups even when the workspace has room for
+// the per-sample sources (read on every call: the tests flip it)
+bool two_phase_disabled() { const char* e = getenv("VOXE_TILE_TWO_PHASE"); return e && e[0] == '0'; }
 
 // block -> tile mapping (see logical_tile_of()).  Default: image-ordered rays are interleaved over the XCDs (load
 // balance wins: neighbouring pixels share their voxels inside a wave anyway); rays in arbitrary order run in bands
@@ -101,7 +104,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, seg_off, fwd_total, total;
+  size_t packed_off, grad_off, state_off, seg_off, src_off, fwd_total, total, total_with_src;
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t nvox = (size_t)g->X * g->Y * g->Z;
@@ -121,6 +124,11 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   l.seg_off = bytes + gbytes + state;
   l.fwd_total = bytes;  // the forward alone needs only the packed grid (states / segments are used when they fit)
   l.total = bytes + gbytes + state + seg;
+  // per-sample gradient sources of the two-phase backward of view-dependent grids (optional: without it the channel
+  // groups re-march the segment)
+  l.src_off = l.total;
+  l.total_with_src = l.total + (c ? align_up(tile_src_bytes(R, c->image_width, c->num_samples, c->sh_degree, c->render_diffuse,
+                                                           g->feature_kind == VOXE_FEAT_ATTN), 256) : 0);
   return l;
 }
 
@@ -241,7 +249,7 @@ int voxe_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_off
 
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
-  return ws_layout(grid, cfg, R).total;
+  return ws_layout(grid, cfg, R).total_with_src;
 }
 
 int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
@@ -298,6 +306,8 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
+    if (tiled && l.total_with_src > l.total && workspace_bytes >= l.total_with_src && !two_phase_disabled())
+      a.sample_src = (float*)((char*)workspace + l.src_off);
     if ((tiled || packed_bwd) && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);

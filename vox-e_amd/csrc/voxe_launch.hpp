@@ -18,6 +18,7 @@ struct BwdArgs {
   float* gpacked;
   bool want_d, want_f;
   const float* ray_state;  // states written by the forward for the same rays (tile backward only)
+  float* sample_src = nullptr;   // scratch of the two-phase tile backward of view-dependent grids (tile_src_bytes())
 };
 struct ProbeArgs {
   const float *packed, *rays_o, *rays_d, *jitter;
@@ -48,6 +49,8 @@ void launch_query(const DevGrid& g, int C, const float* packed, const float* poi
 
 // voxe_render_tile.hip: LDS-window backward for image-ordered SH-0 / attention renders
 bool tile_bwd_supported(const DevCfg& c, int deg);
+// bytes of BwdArgs::sample_src for an image of R rays, width W, S samples (0: that render does not use it)
+size_t tile_src_bytes(long long R, int W, int S, int deg, int diffuse, int attn);
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
 
 // voxe_render_scatter.hip: line-dense scatter backward for unordered rays (SH-0 / attention)

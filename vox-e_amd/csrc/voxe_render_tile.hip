@@ -126,26 +126,33 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
 // re-marching the segment (full gather: the colour needs every coefficient) and depositing its own 4 channels --
 // d rad_c / d coef_cj = basis_j of the ray, a per-lane constant of the pass.  Per-voxel atomics stay combined in LDS;
 // the cost is ngroups x the march instead of (8 corners x channels) global atomics per sample (135 ms -> see DESIGN.md).
-template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F>
+//
+// With a scratch buffer (BwdArgs::sample_src, 16 bytes per sample) the groups do not even re-march: MODE 1 marches ONCE
+// (full gather, all the math) and stores the 4 per-sample gradient sources (d rad_0..2, d v); MODE 2 (one block per
+// group) recomputes only the footprints, loads the sources and deposits its 4 channels.  MODE 0 does both in one kernel
+// (every single-group render; view-dependent grids without the scratch buffer).
+template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE>
 // launch bounds swept: (64, 3) best; 2 and 4..6 are 6-9 % slower (register budget vs the LDS-bound residency)
 #ifndef VOXE_TILE_LB
 #define VOXE_TILE_LB 3
 #endif
-__global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
+__global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
     const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit, const int grp_begin,
-    const int ngrp) {
+    const int ngrp, float4* __restrict__ sample_src) {
   constexpr int CM = COUT * NCM + 1;          // channels of a packed texel
   constexpr int NG = COUT * NCU + 1;          // channels that receive a gradient (the used coefficients + density)
   constexpr int C = NG < 4 ? NG : 4;          // channels held by the LDS window
   constexpr int NGRP = (NG + C - 1) / C;      // channel groups (1 for SH-0 / diffuse / attention renders)
-  __shared__ double win[C * kPlane];
+  static_assert(MODE == 0 || (COUT == 3 && NGRP > 1), "the two-phase backward is for view-dependent grids");
+  constexpr int kWinDoubles = MODE == 1 ? 1 : C * kPlane;   // (the source pass has no window)
+  __shared__ double win[kWinDoubles];
   const int lane = threadIdx.x;
-  for (int i = lane; i < C * kPlane; i += 64) win[i] = 0.0;
+  for (int i = lane; i < kWinDoubles; i += 64) win[i] = 0.0;
 
   // ---- tile -> ray (XCD-banded like map_ray) ----------------------------------------------------
   const int W = c.image_width, H = (int)(c.R / W);
@@ -158,10 +165,10 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
   // on the 32 CUs of an XCD whenever nseg divides 32 (measured: kSegLen 32 -> 0.87 ms, 24 -> 0.68 ms for the same
   // work before this ordering).  Tiles are spread over the XCDs by logical_tile_of() (default: tile t on XCD t % 8).
   const int nseg = num_segments(c.S);
-  const int ntp = gridDim.x / (nseg * qsplit * (NGRP == 1 ? 1 : ngrp));  // tile slots (a multiple of 8 >= ntx * nty)
+  const int ntp = gridDim.x / (nseg * qsplit * ((NGRP == 1 || MODE == 1) ? 1 : ngrp));  // tile slots (a multiple of 8 >= ntx * nty)
   int part = blockIdx.x / ntp;
   int grp = 0;                                   // channel group of this block (outermost: group-major block order)
-  if constexpr (NGRP > 1) {
+  if constexpr (NGRP > 1 && MODE != 1) {
     const int g_local = part / (nseg * qsplit);
     part -= g_local * nseg * qsplit;
     grp = grp_begin + g_local;
@@ -170,6 +177,8 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
   const int tile = logical_tile_of(c, blockIdx.x % ntp, ntp, ntx, nty);
   if (tile < 0) return;  // launch padding (wave-uniform)
   const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
+  // two-phase backward: slot of (tile, segment, sample k, lane) in the source buffer
+  const long long src_base = ((long long)tile * nseg + seg) * kSegLen * 64 + lane - (long long)ks * 64;
   const int ty = tile / ntx, tx = tile - ty * ntx;
   const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
   const bool alive = (px < W) && (py < H);
@@ -310,6 +319,7 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
     fp_cur.inside = false;
   #pragma unroll
     for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
+    bool dead = false;          // early ray termination reached (term_eps > 0)
     int first_key = INT_MAX;
     if (has) {
       z_cur = rc.dg.z(k_lo);
@@ -339,29 +349,41 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
         if (fp.inside) {
           Cell cell;
           make_cell_fast(g, fp, cell);
-          float v, rad[COUT];
-          gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
-          float sigma, dpost;
-          post_activate_vg(g.post_act, v, sigma, dpost);
-          const float dl = last ? kInfinity : (z_next - z);
-          const float delta = dl * rc.dnorm;
-          const float e = fast_exp(-(sigma * delta));
-          const float alpha = 1.0f - e;
-          const float om = 1.0f - alpha;
-          const float wk = alpha * T;
-          float col[COUT], dldw = fmaf(gdep, z, gacc);
-  #pragma unroll
-          for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
-          if (white) dldw -= gsum;
-          prefix = fmaf(dldw, wk, prefix);
-          const float suffix = last ? 0.0f : (total - prefix);
-          const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
-          const float dsig = (delta * e) * fmaf(T, dldw, -tail);
-          // gradient w.r.t. (rad_0 .. rad_{COUT-1}, v), then per window channel: x basis_j (SH-0: C0) resp. x 1
+          // gradient w.r.t. (rad_0 .. rad_{COUT-1}, v) of this sample
           float gsrc[COUT + 1];
+          if constexpr (MODE == 2) {
+            const float4 t4 = sample_src[src_base + (long long)k * 64];
+            gsrc[0] = t4.x; gsrc[1] = t4.y; gsrc[2] = t4.z; gsrc[3] = t4.w;
+          } else {
   #pragma unroll
-          for (int ch = 0; ch < COUT; ++ch) gsrc[ch] = WANT_F ? (wk * gc[ch]) * (col[ch] * (1.0f - col[ch])) : 0.0f;
-          gsrc[COUT] = WANT_D ? dsig * dpost : 0.0f;
+            for (int ch = 0; ch <= COUT; ++ch) gsrc[ch] = 0.0f;
+            if (!dead) {
+              float v, rad[COUT];
+              gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
+              float sigma, dpost;
+              post_activate_vg(g.post_act, v, sigma, dpost);
+              const float dl = last ? kInfinity : (z_next - z);
+              const float delta = dl * rc.dnorm;
+              const float e = fast_exp(-(sigma * delta));
+              const float alpha = 1.0f - e;
+              const float om = 1.0f - alpha;
+              const float wk = alpha * T;
+              float col[COUT], dldw = fmaf(gdep, z, gacc);
+  #pragma unroll
+              for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
+              if (white) dldw -= gsum;
+              prefix = fmaf(dldw, wk, prefix);
+              const float suffix = last ? 0.0f : (total - prefix);
+              const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+              const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+  #pragma unroll
+              for (int ch = 0; ch < COUT; ++ch) gsrc[ch] = WANT_F ? (wk * gc[ch]) * (col[ch] * (1.0f - col[ch])) : 0.0f;
+              gsrc[COUT] = WANT_D ? dsig * dpost : 0.0f;
+              T = T * om;
+            }
+            if constexpr (MODE == 1) sample_src[src_base + (long long)k * 64] = make_float4(gsrc[0], gsrc[1], gsrc[2], gsrc[3]);
+          }
+          // per window channel: x basis_j (SH-0: C0) resp. x 1
           float gch[C];
           bool any = false;
   #pragma unroll
@@ -372,9 +394,9 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
             gch[s] = (chsel[s] == COUT) ? x : x * mult[s];
             any = any || (gch[s] != 0.0f);
           }
-          T = T * om;
+          if constexpr (MODE == 1) any = false;   // the source pass deposits nothing
 
-          if (any) {
+          if (MODE != 1 && any) {
             // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
             const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
             float wm[2], wu[2], wv[2];
@@ -470,10 +492,13 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
               }
             }
           }
-          if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k;
+          if constexpr (MODE == 0) { if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k; }
+          // (two-phase: the source pass keeps writing zeros so that the deposit pass reads defined values)
+          if constexpr (MODE == 1) { if (c.term_eps > 0.0f && T < c.term_eps) dead = true; }
         }
       }
       // ---- slide the window: flush every layer no lane can reach any more ---------------------------
+      if constexpr (MODE == 1) continue;
       int lb = INT_MAX;
       if (has) {
         if (k + 1 < k_lo) lb = first_key;
@@ -490,8 +515,10 @@ __global__ __launch_bounds__(64, NCU > 1 ? 2 : VOXE_TILE_LB) void render_bwd_til
       }
     }
     __syncthreads();
-    if (w.base != INT_MAX) {
-      for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane, CM, my_memch);
+    if constexpr (MODE != 1) {
+      if (w.base != INT_MAX) {
+        for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane, CM, my_memch);
+      }
     }
 
   };
@@ -537,14 +564,29 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S) * ngrp;
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
   const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S) * qsplit * ngrp;
-#define VOXE_TBWD(WD, WF)                                                                         \
-  render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF><<<nb, 64, 0, st>>>(                              \
+#define VOXE_TBWD(WD, WF, MODE, NB, GB, NGR)                                                     \
+  render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE><<<NB, 64, 0, st>>>(                        \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, grp_begin, ngrp)
-  if (a.want_d && a.want_f) VOXE_TBWD(true, true);
-  else if (a.want_d) VOXE_TBWD(true, false);
-  else VOXE_TBWD(false, true);
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src))
+  if constexpr (NGRP > 1) {
+    if (a.sample_src && a.want_f) {   // two-phase: march once for the per-sample sources, then one deposit block per group
+      if (a.want_d) VOXE_TBWD(true, true, 1, nb / ngrp, 0, 1);
+      else VOXE_TBWD(false, true, 1, nb / ngrp, 0, 1);
+      VOXE_TBWD(true, true, 2, nb, 0, ngrp);
+      return;
+    }
+  }
+  if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, nb, grp_begin, ngrp);
+  else if (a.want_d) VOXE_TBWD(true, false, 0, nb, grp_begin, ngrp);
+  else VOXE_TBWD(false, true, 0, nb, grp_begin, ngrp);
 #undef VOXE_TBWD
+}
+
+size_t tile_src_bytes(long long R, int W, int S, int deg, int diffuse, int attn) {
+  if (W <= 0 || R <= 0 || deg <= 0 || diffuse || attn) return 0;   // single-group renders do not use it
+  const long long H = R / W, tiles = ((W + 7) / 8) * ((H + 7) / 8);
+  const size_t bytes = (size_t)tiles * num_segments(S) * kSegLen * 64 * sizeof(float4);
+  return bytes <= ((size_t)4 << 30) ? bytes : 0;   // above 4 GB the single-kernel groups run instead
 }
 
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st) {
