@@ -107,7 +107,7 @@ def test_random_configuration(seed):
         _close(name, got_g, ref_g)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(max(12, int(os.environ.get("VOXE_FUZZ_SEEDS", "40")) // 4)))
 def test_random_configuration_sh_degrees(seed):
     """same sweep with view-dependent colour (SH degree 1..3, 3 * (deg + 1)^2 feature channels), full and diffuse"""
     grid, cfg, o, d, jitter, (h, w), rng = _case(100 + seed)
@@ -117,7 +117,7 @@ def test_random_configuration_sh_degrees(seed):
     dims = grid.densities.shape[:3]
     grid.features = rng.uniform(-1, 1, dims + (3 * (deg + 1) ** 2,)).astype(np.float32)
     cfg.sh_degree = deg
-    cfg.render_diffuse = int(seed % 4 == 0)
+    cfg.render_diffuse = int(seed % 4 == 0 or seed % 7 == 3)   # (diffuse with both ray orders)
     width = w if seed % 2 else 0
     ref = vo.render_fwd(grid, cfg, o, d, jitter)
     got = gh.hip_forward(grid, cfg, o, d, jitter, image_width=width)

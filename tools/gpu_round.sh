@@ -21,6 +21,7 @@ timeout 300 python bench.py --optimizer split --no-cpu-baseline 2>/dev/null | ta
 timeout 300 env VOXE_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/bench_400_rccl_1rank.json
 timeout 300 python tools/refine_bench.py 160 2>/dev/null | tail -4 > $O/refine_bench.txt; cat $O/refine_bench.txt
 timeout 300 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench.txt; cat $O/recon_bench.txt
+(timeout 300 python tools/sh_bench.py 160 400 123; timeout 300 python tools/sh_bench.py 160 180 123 random) 2>/dev/null > $O/sh_bench.txt; cat $O/sh_bench.txt
 for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_refine -o ${TAG}_refine -- python $GRAFT_REPO_ROOT/tools/refine_bench.py 160 > /dev/null 2>&1

@@ -319,7 +319,7 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     if (tiled)
       launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
     else if (packed_bwd) {
-      launch_bwd_packed_scatter(dg, dc, a, s);
+      launch_bwd_packed_scatter(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
       *bricked = true;  // that kernel accumulates into the bricked layout
     } else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);

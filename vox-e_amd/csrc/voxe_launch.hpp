@@ -55,7 +55,7 @@ void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, co
 
 // voxe_render_scatter.hip: line-dense scatter backward for unordered rays (SH-0 / attention)
 bool packed_scatter_supported(int deg);
-void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st);
+void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
 
 // voxe_grid_ops.hip
 void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,

@@ -20,7 +20,12 @@
 
 namespace voxe {
 
-template <int COUT, bool WANT_D, bool WANT_F>
+// View-dependent grids (NCU = 4 / 9 / 16 used coefficients per colour, texels of CM = 13 / 28 / 49 channels): the wave
+// stages the 4 gradient SOURCES of a sample (d rad_0..2, d v) and the SH basis of its ray; the lanes of one atomic
+// instruction are (corner j, 8 consecutive gradient channels) of ONE sample, i.e. 32 contiguous bytes per corner, and a
+// sample takes ceil((3 NCU + 1) / 8) instructions -- 16 requests per sample at SH-1 instead of the 104 of
+// render_bwd_kernel.
+template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F>
 __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
@@ -28,12 +33,15 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
     const float* __restrict__ ray_state, float* __restrict__ gpacked) {
-  constexpr int C = COUT + 1;
+  constexpr int C = COUT + 1;                             // gradient sources per sample (= channels when NCU == 1)
+  constexpr int CM = COUT * NCM + 1;                      // channels of a packed texel
+  constexpr int NG = COUT * NCU + 1;                      // channels that receive a gradient
   constexpr int kLanesPerSample = 8 * C;                  // (corner, channel)
   constexpr int kSamplesPerInstr = 64 / kLanesPerSample;  // 2 (C = 4) or 4 (C = 2)
   __shared__ int s_cell[3][64];  // cell corner (x0, y0, z0); x0 = -1: nothing to deposit
   __shared__ float s_w[8][64];
   __shared__ float s_g[C][64];
+  __shared__ float s_basis[NCU > 1 ? NCU : 1][64];
   const int lane = threadIdx.x;
 
   // With the forward's depth-segment states (ray_state != nullptr) a block is (64 rays, 32-sample depth segment),
@@ -49,8 +57,12 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
   const bool alive = r0 < c.R;
   const long long r = alive ? r0 : 0;
 
-  RayCtx<COUT, 1, 1> rc;
+  RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
+  if constexpr (NCU > 1) {   // one ray per lane for the whole kernel: its basis is staged once (visible after the first barrier)
+#pragma unroll
+    for (int t = 0; t < NCU; ++t) s_basis[t][lane] = rc.basis[t];
+  }
   const int ks = ray_state ? seg * kSegLen : 0, ke = ray_state ? min(c.S, ks + kSegLen) - 1 : c.S - 1;
   const int k_lo = max(rc.k_lo, ks);
   int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
         Cell cell;
         make_cell_fast(g, fp, cell);
         float v, rad[COUT];
-        gather<COUT, 1, 1>(g, packed, cell, rc.basis, v, rad);
+        gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
         float sigma, dpost;
         post_activate_vg(g.post_act, v, sigma, dpost);
         const float dl = last ? kInfinity : (z_next - z);
@@ -135,7 +147,9 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
         bool any = false;
 #pragma unroll
         for (int ch = 0; ch < COUT; ++ch) {
-          gch[ch] = WANT_F ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
+          // NCU == 1: the channel gradient itself (x C0); otherwise the source d rad_ch (x basis_j at the deposit)
+          const float src = (wk * gc[ch]) * (col[ch] * (1.0f - col[ch]));
+          gch[ch] = WANT_F ? (NCU == 1 ? src * kC0 : src) : 0.0f;
           any = any || (gch[ch] != 0.0f);
         }
         gch[COUT] = WANT_D ? dsig * dpost : 0.0f;
@@ -162,43 +176,69 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) s_g[ch][lane] = gch[ch];
     __syncthreads();
-    const int j = (lane / C) & 7, ch = lane % C;  // corner (x bit 0, y bit 1, z bit 2) and channel of this lane
+    if constexpr (NCU == 1) {
+      const int j = (lane / C) & 7, ch = lane % C;  // corner (x bit 0, y bit 1, z bit 2) and channel of this lane
+      const int mem = (ch == COUT) ? CM - 1 : ch * NCM;   // (diffuse renders of wider texels: coefficient 0 of colour ch)
 #pragma unroll 4
-    for (int grp = 0; grp < 64 / kSamplesPerInstr; ++grp) {
-      const int s = grp * kSamplesPerInstr + lane / kLanesPerSample;
-      const int b = s_cell[0][s];
-      if (b >= 0) {
-        const float gv = s_g[ch][s];
+      for (int grp = 0; grp < 64 / kSamplesPerInstr; ++grp) {
+        const int s = grp * kSamplesPerInstr + lane / kLanesPerSample;
+        const int b = s_cell[0][s];
+        if (b >= 0) {
+          const float gv = s_g[ch][s];
+          const float w = s_w[j][s];
+          if (gv != 0.0f && w != 0.0f) {
+            // (a size-1 axis has both corners on the same voxel; make_cell gives the second one weight 0)
+            const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
+            const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
+            atomicAdd(gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM + mem, gv * w);
+          }
+        }
+      }
+    } else {
+      const int j = lane >> 3, cc = lane & 7;       // corner and channel-in-chunk of this lane
+      for (int s = 0; s < 64; ++s) {
+        const int b = s_cell[0][s];
+        if (b < 0) continue;                        // wave-uniform
         const float w = s_w[j][s];
-        if (gv != 0.0f && w != 0.0f) {
-          // (a size-1 axis has both corners on the same voxel; make_cell gives the second one weight 0)
-          const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
-          const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
-          atomicAdd(gpacked + brick_slot(x, y, z, g.Y, g.Z) * C + ch, gv * w);
+        const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
+        const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
+        float* __restrict__ texel = gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM;
+#pragma unroll
+        for (int chunk = 0; chunk < (NG + 7) / 8; ++chunk) {
+          const int q = chunk * 8 + cc;             // gradient channel: (colour ch, coefficient jj) or, last, the density
+          if (q < NG) {
+            const int ch = q / NCU, jj = q - ch * NCU;
+            const bool dens = (q == NG - 1);
+            const float gv = dens ? s_g[COUT][s] : s_g[ch][s] * s_basis[jj][s];
+            if (gv != 0.0f && w != 0.0f) atomicAdd(texel + (dens ? CM - 1 : ch * NCM + jj), gv * w);
+          }
         }
       }
     }
   }
 }
 
-bool packed_scatter_supported(int deg) { return deg == 0; }
+bool packed_scatter_supported(int deg) { (void)deg; return true; }
 
-void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
+template <int COUT, int NCM, int NCU>
+static void launch_bwd_packed_scatter_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
   const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * (a.ray_state ? num_segments(c.S) : 1);
-#define VOXE_PBWD(COUT, WD, WF)                                                                     \
-  render_bwd_packed_scatter_kernel<COUT, WD, WF><<<nb, 64, 0, st>>>(                                \
+#define VOXE_PBWD(WD, WF)                                                                            \
+  render_bwd_packed_scatter_kernel<COUT, NCM, NCU, WD, WF><<<nb, 64, 0, st>>>(                       \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, \
       a.d_acc, a.ray_state, a.gpacked)
-  if (c.attn) {
-    if (a.want_d && a.want_f) VOXE_PBWD(1, true, true);
-    else if (a.want_d) VOXE_PBWD(1, true, false);
-    else VOXE_PBWD(1, false, true);
-  } else {
-    if (a.want_d && a.want_f) VOXE_PBWD(3, true, true);
-    else if (a.want_d) VOXE_PBWD(3, true, false);
-    else VOXE_PBWD(3, false, true);
-  }
+  if (a.want_d && a.want_f) VOXE_PBWD(true, true);
+  else if (a.want_d) VOXE_PBWD(true, false);
+  else VOXE_PBWD(false, true);
 #undef VOXE_PBWD
+}
+
+void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st) {
+  if (c.attn) launch_bwd_packed_scatter_t<1, 1, 1>(g, c, a, st);
+  else if (deg == 0) launch_bwd_packed_scatter_t<3, 1, 1>(g, c, a, st);
+  else if (deg == 1) { if (diffuse) launch_bwd_packed_scatter_t<3, 4, 1>(g, c, a, st); else launch_bwd_packed_scatter_t<3, 4, 4>(g, c, a, st); }
+  else if (deg == 2) { if (diffuse) launch_bwd_packed_scatter_t<3, 9, 1>(g, c, a, st); else launch_bwd_packed_scatter_t<3, 9, 9>(g, c, a, st); }
+  else { if (diffuse) launch_bwd_packed_scatter_t<3, 16, 1>(g, c, a, st); else launch_bwd_packed_scatter_t<3, 16, 16>(g, c, a, st); }
 }
 
 }  // namespace voxe
