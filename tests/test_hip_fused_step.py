@@ -145,6 +145,8 @@ CASES = {
     "sh0_extras_scatter": (40, 3, 64, False, None, "sh", "identity", "softplus", {"extras": True, "renders": 2}),
     "attn_frozen_density": (40, 1, 96, True, None, "attn", "identity", "relu", {"freeze_density": True}),
     "sh1_linear": (24, 12, 48, True, None, "sh1", "identity", "softplus", {}),
+    "sh1_scatter_bricked_odd": (24, 12, 48, False, (23, 24, 21), "sh1", "identity", "softplus", {"extras": True}),
+    "sh1_frozen_density": (24, 12, 48, True, None, "sh1", "abs", "relu", {"freeze_density": True}),
 }
 
 
@@ -170,7 +172,7 @@ def test_fused_step_equals_split_step(case):
         if name.startswith("exp_avg_sq") or not float(y.abs().max()):
             continue
         assert _rel(x, y) < 5e-4, f"{name}: rel-L2 {_rel(x, y):.3e}"
-    expect = abi.GRAD_LINEAR if (ordered or kind == "sh1") else abi.GRAD_BRICKED   # scatter: unordered SH-0 rays only
+    expect = abi.GRAD_LINEAR if ordered else abi.GRAD_BRICKED   # LDS-window backward / line-dense scatter
     assert fused.layouts == {expect}
     assert not torch.equal(fused.feat, feat)             # the run really moved the parameters
     if kw.get("freeze_density"):

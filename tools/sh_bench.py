@@ -44,6 +44,7 @@ def main():
         def step():
             n_it[0] += 1
             rng = (42, n_it[0])
+            ws.invalidate()          # a training step changes the grid: re-pack it
             ops.render_fwd_into(spec, params, dens, feat, ro, rd, None, *outs, ws, rng)
             ops.render_bwd_into(spec, params, dens, feat, ro, rd, None, outs[0], outs[1], outs[2], g_colour, None, None,
                                 d_dens, d_feat, ws, rng)
@@ -62,7 +63,7 @@ def main():
         ops.profile_enable(False)
         print(f"SH-{deg} ({F + 1} channels, grid {G}^3 = {G ** 3 * (F + 1) * 4 / 1e6:.0f} MB), {hw}x{hw} ({order} order), S=256: {dt * 1e3:.2f} ms per "
               f"fwd+bwd ({R / dt / 1e6:.2f} M rays/s); kernels: fwd {p['ms_fwd'] / max(p['n_fwd'], 1):.3f} "
-              f"bwd {p['ms_bwd'] / max(p['n_bwd'], 1):.3f} memset {p['ms_memset'] / max(p['n_memset'], 1):.3f} "
+              f"pack {p['ms_pack'] / max(p['n_pack'], 1):.3f} bwd {p['ms_bwd'] / max(p['n_bwd'], 1):.3f} memset {p['ms_memset'] / max(p['n_memset'], 1):.3f} "
               f"unpack {p['ms_unpack'] / max(p['n_unpack'], 1):.3f} ms", flush=True)
         del feat, d_feat, ws
 

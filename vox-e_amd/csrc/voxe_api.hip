@@ -392,6 +392,7 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
                         void* workspace, size_t workspace_bytes, void* stream) {
   if (!grid || !grid->densities || !grid->features) return VOXE_ERR_NULL_POINTER;
   if (grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0 || step < 1) return VOXE_ERR_BAD_SHAPE;
+  if ((long long)grid->X * grid->Y * grid->Z * (grid->F + 1) >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
   if (x_begin < 0 || x_end > grid->X || x_begin > x_end) return VOXE_ERR_BAD_SHAPE;
   if (grad_layout == VOXE_GRAD_BRICKED && (x_begin & 1) && x_begin != x_end) return VOXE_ERR_BAD_SHAPE;
   if ((exp_avg_d == nullptr) != (exp_avg_sq_d == nullptr) || (exp_avg_f == nullptr) != (exp_avg_sq_f == nullptr))

@@ -89,6 +89,45 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(const float* __restric
   }
 }
 
+// Wide texels (13 / 28 / 49 channels): one thread per ELEMENT of the packed array, so that consecutive lanes touch
+// consecutive floats of both layouts (a thread per voxel strides by C floats: 64 cache lines per wave instruction).
+template <int C>
+__global__ __launch_bounds__(256) void pack_grid_wide_kernel(const float* __restrict__ dens, const float* __restrict__ feat,
+                                                             float* __restrict__ packed, long long nvox, float scale,
+                                                             int pre_act) {
+  constexpr int F = C - 1;
+  // (32-bit index math: validate() bounds nvox * C below 2^31)
+  const unsigned n = (unsigned)(nvox * C), stride = gridDim.x * blockDim.x;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const unsigned i = e / C, ch = e - i * C;
+    packed[e] = ch < F ? feat[i * F + ch] : pre_activate(pre_act, dens[i], scale);
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void unpack_grad_wide_kernel(const float* __restrict__ gpacked,
+                                                               const float* __restrict__ dens, float* __restrict__ d_dens,
+                                                               float* __restrict__ d_feat, long long nvox, float scale,
+                                                               int pre_act, int accumulate, int bricked, int Y, int Z) {
+  constexpr int F = C - 1;
+  const unsigned n = (unsigned)(nvox * C), stride = gridDim.x * blockDim.x;
+  for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+    const unsigned i = e / C, ch = e - i * C;
+    long long si = i;
+    if (bricked) {
+      const int z = (int)(i % (unsigned)Z), y = (int)((i / (unsigned)Z) % (unsigned)Y), x = (int)(i / ((unsigned)Y * (unsigned)Z));
+      si = brick_slot(x, y, z, Y, Z);
+    }
+    const float v = gpacked[si * C + ch];
+    if (ch < F) {
+      if (d_feat) d_feat[i * F + ch] = accumulate ? d_feat[i * F + ch] + v : v;
+    } else if (d_dens) {
+      const float gval = v * pre_activate_grad(pre_act, dens[i], scale);
+      d_dens[i] = accumulate ? d_dens[i] + gval : gval;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused optimiser step: un-pack the gradient (+ chain rule of the density pre-activation), Adam on both parameter
 // tensors, re-pack the updated grid, clear the gradient -- one streaming pass instead of four
@@ -172,11 +211,64 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
   }
 }
 
+// the same step with one thread per ELEMENT of the packed arrays (wide texels, see pack_grid_wide_kernel)
+template <int C>
+__global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__ gpacked, float* __restrict__ dens,
+                                                             float* __restrict__ feat, const float* __restrict__ extra_d,
+                                                             const float* __restrict__ extra_f, float* __restrict__ m_d,
+                                                             float* __restrict__ v_d, float* __restrict__ m_f,
+                                                             float* __restrict__ v_f, float* __restrict__ packed,
+                                                             long long vox_begin, long long vox_end, float scale,
+                                                             int pre_act, int bricked, int Y, int Z, AdamHyper h) {
+  constexpr int F = C - 1;
+  const unsigned e_end = (unsigned)(vox_end * C), stride = gridDim.x * blockDim.x;
+  for (unsigned e = (unsigned)(vox_begin * C) + blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += stride) {
+    const unsigned i = e / C, ch = e - i * C;
+    long long si = i;
+    if (bricked) {
+      const int z = (int)(i % (unsigned)Z), y = (int)((i / (unsigned)Z) % (unsigned)Y), x = (int)(i / ((unsigned)Y * (unsigned)Z));
+      si = brick_slot(x, y, z, Y, Z);
+    }
+    const float g = gpacked[si * C + ch];
+    gpacked[si * C + ch] = 0.0f;
+    if (ch < F) {
+      const unsigned j = i * F + ch;
+      float p = feat[j];
+      if (m_f) {
+        const float gi = extra_f ? g + extra_f[j] : g;
+        float m = m_f[j], v = v_f[j];
+        p = adam_update(p, gi, m, v, h);
+        feat[j] = p; m_f[j] = m; v_f[j] = v;
+      }
+      packed[e] = p;
+    } else {
+      float d = dens[i];
+      if (m_d) {
+        const float gd = g * pre_activate_grad(pre_act, d, scale);
+        const float gi = extra_d ? gd + extra_d[i] : gd;
+        float m = m_d[i], v = v_d[i];
+        d = adam_update(d, gi, m, v, h);
+        dens[i] = d; m_d[i] = m; v_d[i] = v;
+      }
+      packed[e] = pre_activate(pre_act, d, scale);
+    }
+  }
+}
+
 template <int C>
 static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d,
                                const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h,
                                float* packed_out, hipStream_t st) {
   const long long plane = (long long)gd->Y * gd->Z, nvox = (x_end - x_begin) * plane;
+  if constexpr (C > 4) {
+    const long long n = nvox * C;
+    const int nbw = (int)((n + 255) / 256 < 4 * VOXE_GA_BLOCKS ? (n + 255) / 256 : 4 * VOXE_GA_BLOCKS);
+    grid_adam_wide_kernel<C><<<nbw, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
+                                                  extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane,
+                                                  x_end * plane, gd->density_scale, gd->density_pre_act, bricked ? 1 : 0, gd->Y,
+                                                  gd->Z, h);
+    return;
+  }
   const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
   grid_adam_kernel<C><<<nb, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
                                           extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane, x_end * plane, gd->density_scale,
@@ -685,6 +777,13 @@ static inline int blocks_for(const DevCfg& c) {
 template <int C>
 static void launch_pack(const VoxeGridDesc* gd, float* packed, hipStream_t st) {
   const long long nvox = (long long)gd->X * gd->Y * gd->Z;
+  if constexpr (C > 4) {
+    const long long n = nvox * C;
+    const int nbw = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    pack_grid_wide_kernel<C><<<nbw, 256, 0, st>>>(gd->densities, gd->features, packed, nvox, gd->density_scale,
+                                                  gd->density_pre_act);
+    return;
+  }
   const int nb = (int)((nvox + 255) / 256 < 4096 ? (nvox + 255) / 256 : 4096);
   pack_grid_kernel<C><<<nb, 256, 0, st>>>(gd->densities, gd->features, packed, nvox,
                                           gd->density_scale, gd->density_pre_act);
@@ -694,6 +793,13 @@ template <int C>
 static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
                           int accumulate, int bricked, hipStream_t st) {
   const long long nvox = (long long)gd->X * gd->Y * gd->Z;
+  if constexpr (C > 4) {
+    const long long n = nvox * C;
+    const int nbw = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    unpack_grad_wide_kernel<C><<<nbw, 256, 0, st>>>(gpacked, gd->densities, d_dens, d_feat, nvox, gd->density_scale,
+                                                    gd->density_pre_act, accumulate, bricked, gd->Y, gd->Z);
+    return;
+  }
   const int nb = (int)((nvox + 255) / 256 < 4096 ? (nvox + 255) / 256 : 4096);
   unpack_grad_kernel<C><<<nb, 256, 0, st>>>(gpacked, gd->densities, d_dens, d_feat, nvox,
                                             gd->density_scale, gd->density_pre_act, accumulate, bricked, gd->Y, gd->Z);
