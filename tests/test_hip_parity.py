@@ -114,11 +114,14 @@ def test_sh_degrees(deg, mode):
     tag = f"deg{deg}_{mode}_"
     cfg = cfg_from_bounds(g["bounds"], 32, white_bkgd=True, sh_degree=deg, render_diffuse=(mode == "diffuse"))
     o, d = g["rays_o"], g["rays_d"]
-    out = gh.hip_forward(grid, cfg, o, d)
-    np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=1e-5)
-    gd, gf = gh.hip_backward(grid, cfg, o, d, g[tag + "g_colour"])
-    assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
-    assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
+    # the golden rays are a 10x10 image: width 0 = rays as an unordered list (line-dense scatter backward), width 10 =
+    # image-ordered (LDS-window backward, channel groups) -- both against the reference's autograd gradients
+    for width in (0, 10):
+        out = gh.hip_forward(grid, cfg, o, d, image_width=width)
+        np.testing.assert_allclose(out["colour"], g[tag + "colour"], rtol=0, atol=1e-5)
+        gd, gf = gh.hip_backward(grid, cfg, o, d, g[tag + "g_colour"], image_width=width)
+        assert rel_l2(gd, g[tag + "grad_densities"]) < GRAD_REL_L2
+        assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
 
 
 def test_jitter_stream_matches_oracle_stream():
