@@ -471,3 +471,25 @@ def test_sh_degrees_image_ordered_backward(deg, mode, monkeypatch):
             assert ft.grad is None and rel_l2(gh.n(dt.grad), rd) < GRAD_REL_L2
         else:
             assert dt.grad is None and rel_l2(gh.n(ft.grad), rf) < GRAD_REL_L2
+
+
+def test_early_termination_sh1_routes_agree(monkeypatch):
+    """term_eps > 0 on a view-dependent grid: the two-phase window backward (the source pass keeps writing zeros after a
+    ray terminated), the single-kernel channel groups and the line-dense scatter all differentiate the same forward"""
+    g = load_golden("frames32.npz")
+    base = grid_from_golden(g, "", "softplus")
+    rng = np.random.default_rng(4)
+    feats = rng.uniform(-1, 1, base.densities.shape[:3] + (12,)).astype(np.float32)
+    grid = vo.Grid(base.densities, feats, base.aabb, base.density_scale, base.density_pre_act, base.density_post_act)
+    o, d = vo.cast_rays(40, 40, 0.5 * 40 / np.tan(0.5 * 0.6911112), g["rot"][3], g["trans"][3])
+    cfg = cfg_from_bounds(g["bounds"], 128, white_bkgd=True, sh_degree=1)
+    gc = rng.standard_normal((1600, 3)).astype(np.float32)
+    two_d, two_f = gh.hip_backward(grid, cfg, o, d, gc, image_width=40, term_eps=1e-3)
+    monkeypatch.setenv("VOXE_TILE_TWO_PHASE", "0")
+    one_d, one_f = gh.hip_backward(grid, cfg, o, d, gc, image_width=40, term_eps=1e-3)
+    monkeypatch.delenv("VOXE_TILE_TWO_PHASE")
+    sc_d, sc_f = gh.hip_backward(grid, cfg, o, d, gc, term_eps=1e-3)
+    full_d, full_f = gh.hip_backward(grid, cfg, o, d, gc, image_width=40)
+    assert rel_l2(two_d, one_d) < 1e-5 and rel_l2(two_f, one_f) < 1e-5
+    assert rel_l2(two_d, sc_d) < 1e-4 and rel_l2(two_f, sc_f) < 1e-5
+    assert 0 < rel_l2(two_f, full_f) < 0.05      # (the cut really changes the gradient, a little)
