@@ -4,10 +4,12 @@
 Workload (BASELINE.json configs[1] / SURVEY.md 8d): 160^3 SH-0 softplus grid (U(-1,1) init, seed 42,
 expected_density_scale 100/3), one 400x400 synthetic camera per GPU, S = 256 samples per ray with the
 reference's always-on stratified jitter (in-kernel counter hash), white background, upstream gradient
-d_colour ~ N(0,1) (seed 43).  One STEP = render forward + render backward through the C ABI
-(pack + forward kernel + gradient memset + backward kernel + unpack), the RCCL all-reduce of the
-voxel-grid gradient when N > 1, and the fused Adam update of both grid tensors (so the grid really
-changes every step and nothing is cached across steps).  Inputs are resident in HBM before timing.
+d_colour ~ N(0,1) (seed 43).  One STEP = render forward + render backward through the C ABI (voxe_render_fwd,
+voxe_render_bwd_acc: the gradient stays in the workspace), the RCCL exchange when N > 1 (reduce-scatter of the
+gradient over x-slabs of the grid, all-gather of the updated packed grid: thre3d_atom/modules/parallel.py) and the
+fused Adam update of both grid tensors (voxe_grid_adam_step) -- so the grid really changes every step and nothing is
+cached across steps.  Inputs are resident in HBM before timing.  `--optimizer split` = the same arithmetic as
+voxe_render_bwd + all-reduce + voxe_adam_step per tensor.
 
     python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
 
@@ -123,18 +125,8 @@ def main():
     del inside
 
     step_no = [0]
-    # N > 1: ONE all-reduce of the flat gradient, then the replicated Adam.  VOXE_BENCH_SHARDED_OPT=1 selects the
-    # ZeRO-1 style alternative (reduce-scatter, Adam on 1/world of the buffer, all-gather of the parameters: the same
-    # wire bytes, the optimiser pass divided by `world`, one more collective launch) -- not measured on > 1 GPU yet,
-    # so it is not the default.
-    sharded_opt = dist is not None and flat_p.numel() % world == 0 and os.environ.get("VOXE_BENCH_SHARDED_OPT") == "1"
-    if sharded_opt:
-        per = flat_p.numel() // world
-        lo, hi = rank * per, (rank + 1) * per
-        g_shard = torch.empty(per, dtype=torch.float32, device=dev)
-        p_shard = torch.empty(per, dtype=torch.float32, device=dev)
-
-    fused = args.optimizer == "fused" and not args.no_adam and not sharded_opt
+    # `--optimizer split`, N > 1: ONE all-reduce of the flat gradient, then the replicated Adam on every rank
+    fused = args.optimizer == "fused" and not args.no_adam
     first = [True]
     if fused:
         from thre3d_atom.modules.parallel import ShardedGridAdam
@@ -164,14 +156,6 @@ def main():
         ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
         ops.render_bwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, g_colour, None,
                             None, d_dens, d_feat, ws, rng)
-        if dist is not None and sharded_opt and not args.no_adam:
-            # gradient sum as reduce-scatter, Adam on this rank's 1/world slice of the flat buffer, all-gather of the
-            # updated parameters: the wire bytes of one all-reduce, the optimiser pass divided by `world`
-            dist.reduce_scatter_tensor(g_shard, flat_g)
-            ops.adam_step_(flat_p[lo:hi], g_shard, exp_avg[lo:hi], exp_avg_sq[lo:hi], step_no[0], lr=1e-4)
-            p_shard.copy_(flat_p[lo:hi])
-            dist.all_gather_into_tensor(flat_p, p_shard)
-            return
         if dist is not None:
             dist.all_reduce(flat_g)  # sum over ranks (RCCL, xGMI)
         if not args.no_adam:
@@ -347,7 +331,7 @@ def main():
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
                             f"{'' if args.no_adam else (' + Adam (fused grid step)' if fused else ' + Adam')}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
-                "grad_exchange": (opt.mode if fused else ("reduce-scatter + sharded Adam + all-gather" if sharded_opt else ("all-reduce" if dist is not None else "none"))), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
+                "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
                 "replicas_consistent": replicas_consistent,
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
             },
