@@ -133,7 +133,11 @@ def main():
 
         # N = 1: the fused step.  N > 1: reduce-scatter of the gradient region over x-slabs, the fused step on this
         # rank's slab, all-gather of the packed grid (thre3d_atom/modules/parallel.py)
-        opt = ShardedGridAdam(spec, dens, feat, lr=1e-4, exercise_collectives=os.environ.get("VOXE_BENCH_FORCE_DIST") == "1")
+        # VOXE_GRAD_EXCHANGE = auto (default: time the three exchanges on this job's ranks before the warm-up and keep
+        # the fastest) | reduce-scatter | all-to-all | all-reduce
+        want_exchange = os.environ.get("VOXE_GRAD_EXCHANGE", "auto")
+        opt = ShardedGridAdam(spec, dens, feat, lr=1e-4, exercise_collectives=os.environ.get("VOXE_BENCH_FORCE_DIST") == "1",
+                              exchange="reduce-scatter" if want_exchange == "auto" else want_exchange)
         exp_avg = exp_avg_sq = None   # (the split path's moments; the fused optimiser owns its own)
 
     def fused_step(prm, ro, rd, outs, gcol, wsx):
@@ -168,6 +172,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if fused and dist is not None and want_exchange == "auto":
+        # outside the timed region: one render so that the workspace exists and holds the packed grid, then dry optimiser
+        # steps (zero gradient, zero moments: no parameter bit changes) through each exchange
+        ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, (42, 0))
+        layout0 = ops.render_bwd_acc(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, g_colour, None,
+                                     None, ws, (42, 0), zero_first=True)
+        opt.autotune(ws, layout0)
+        first[0] = False                      # autotune left the gradient region cleared
     for _ in range(args.warmup):
         step()
     barrier()
@@ -333,6 +345,7 @@ def main():
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
                 "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
                 "replicas_consistent": replicas_consistent,
+                "exchange_autotune_ms": (opt.tuned_ms if fused else None),
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
             },
             "roofline": roofline, "secondary": secondary,

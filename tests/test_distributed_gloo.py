@@ -182,7 +182,33 @@ def _sharded_worker(rank, world, port, results):
         for k, per_rank in enumerate(grads):
             _CpuOps.store_gradient(rws, sum(per_rank[1:], per_rank[0]), layout)
             _CpuOps.grid_adam_step_(None, rd, rf, layout, rws, k + 1, 0.05, rm[0], rm[1])
-        # this rank of the sharded job
+        # this rank of the sharded job: every exchange must give the single-process result (2 ranks: a + b is exact in
+        # any order), and so must whatever autotune() picks
+        for exchange in ("reduce-scatter", "all-to-all", "all-reduce", "auto"):
+            d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
+            opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps,
+                                           exchange="reduce-scatter" if exchange == "auto" else exchange)
+            if exchange == "auto":
+                ws.packed.copy_(torch.cat((f, d), dim=-1).reshape(-1))
+                ws.grad.fill_(123.0)                       # autotune clears the region itself
+                picked = opt.autotune(ws, layout, iters=2)
+                assert picked in opt.EXCHANGES and set(opt.tuned_ms) == set(opt.EXCHANGES)
+                assert torch.equal(d, dens0) and torch.equal(f, feat0) and opt.steps == 0     # dry steps change nothing
+                assert float(opt.state_features[0].abs().max()) == 0.0 and float(ws.grad.abs().max()) == 0.0
+                chosen = [None] * world
+                dist.all_gather_object(chosen, picked)
+                assert len(set(chosen)) == 1, "ranks disagree on the exchange"
+            for per_rank in grads:
+                _CpuOps.store_gradient(ws, per_rank[rank], layout)
+                opt.step(ws, layout)
+                assert float(ws.grad.abs().max()) == 0.0
+            assert torch.equal(ws.packed, rws.packed), (name, exchange)
+            opt.gather_parameters()
+            assert torch.equal(d, rd) and torch.equal(f, rf), (name, exchange)
+            if exchange == "all-to-all" and name in ("linear", "bricked"):
+                assert opt.mode.startswith("all-to-all")
+            if exchange == "all-reduce":
+                assert opt.mode.startswith("all-reduce")
         d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
         opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps)
         for per_rank in grads:

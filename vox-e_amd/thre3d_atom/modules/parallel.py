@@ -130,29 +130,47 @@ class ShardedGridAdam:
     """Optimiser step of ONE voxel grid in a data-parallel job, on top of the fused grid step
     (voxe_render_bwd_acc leaves every rank's gradient in its workspace; voxe_grid_adam_step consumes it).
 
-    world == 1                 : the plain fused step.
-    X divisible by the world   : ZeRO-1 over x-slabs -- reduce-scatter of the gradient region (each rank receives the
-        sum of ITS slab), fused Adam on that slab only (raw parameters + moments of the other slabs are never touched
-        on this rank), all-gather of the packed grid's slabs, in place, so every rank renders the same updated grid.
-        Same wire bytes as one all-reduce; the optimiser's HBM pass shrinks by `world`.
-    otherwise                  : all-reduce of the gradient region + the replicated full step.
+    world == 1 : the plain fused step.  Otherwise one of three exchanges (`exchange=`):
+      "reduce-scatter" (default) ZeRO-1 over x-slabs: reduce-scatter of the gradient region (each rank receives the sum
+          of ITS slab), fused Adam on that slab only (raw parameters + moments of the other slabs are never touched on
+          this rank), all-gather of the packed grid's slabs, in place, so every rank renders the same updated grid.
+          Same wire bytes as one all-reduce; the optimiser's HBM pass shrinks by `world`.
+      "all-to-all"  the same with the reduce-scatter spelled as ONE all-to-all of the slabs (point-to-point over every
+          xGMI link at once instead of the library's ring) + a local sum over the `world` received slabs.
+      "all-reduce"  all-reduce of the whole gradient region + the replicated full step (also the fallback whenever X is
+          not divisible by the world size).
+    `autotune()` times the three on the job's own ranks and links (dry steps before training: zero gradient + zero
+    moments leave every parameter bit-unchanged) and keeps the fastest -- the same choice on every rank.
     `gather_parameters()` makes the raw tensors whole again on every rank (checkpoints, upsampling between stages).
 
     `backend` is voxe_hip.ops; tests substitute a CPU stand-in with the same four functions."""
 
+    EXCHANGES = ("reduce-scatter", "all-to-all", "all-reduce")
+    _MODE_NAMES = {
+        "reduce-scatter": "reduce-scatter + sharded step + all-gather of the packed grid",
+        "all-to-all": "all-to-all + local sum + sharded step + all-gather of the packed grid",
+        "all-reduce": "all-reduce + replicated step",
+    }
+
     def __init__(self, spec, densities: torch.Tensor, features: torch.Tensor, lr: float, betas=(0.9, 0.999),
                  eps: float = 1e-8, train_densities: bool = True, train_features: bool = True, backend=None,
-                 exercise_collectives: bool = False):
+                 exercise_collectives: bool = False, exchange: str = "reduce-scatter"):
         if backend is None:
             from voxe_hip import ops as backend
+        if exchange not in self.EXCHANGES:
+            raise ValueError(f"exchange must be one of {self.EXCHANGES}, got {exchange!r}")
         self.ops, self.spec, self.densities, self.features = backend, spec, densities, features
         self.lr, self.betas, self.eps = lr, betas, eps
         self.state_densities = (torch.zeros_like(densities), torch.zeros_like(densities)) if train_densities else None
         self.state_features = (torch.zeros_like(features), torch.zeros_like(features)) if train_features else None
         self.steps = 0
         self.exercise_collectives = exercise_collectives   # run the collectives even in a 1-rank group (bring-up)
+        self.exchange = exchange
+        self.tuned_ms = None        # autotune(): {exchange: milliseconds per dry step, max over ranks}
         self._shard = None
+        self._recv = None
         self.mode = "single"
+        self._sharded_ran = False
 
     def _slab(self, grad_layout: int):
         """(x_begin, x_end, floats per slab in the gradient region, floats per slab in the packed grid) or None"""
@@ -167,44 +185,93 @@ class ShardedGridAdam:
         g_per = (planes // 2) * ((Y + 1) // 2) * ((Z + 1) // 2) * 8 * C if bricked else planes * Y * Z * C
         return xr[0], xr[1], g_per, planes * Y * Z * C
 
-    @torch.no_grad()
-    def step(self, workspace, grad_layout: int) -> None:
+    def _collective(self) -> bool:
+        _, world = world_info()
+        return world > 1 or (self.exercise_collectives and dist.is_initialized())
+
+    def _run(self, workspace, grad_layout: int, exchange: str, step_no: int) -> str:
+        """one exchange + optimiser step; returns the name of what ran"""
         rank, world = world_info()
-        self.steps += 1
         kw = dict(state_densities=self.state_densities, state_features=self.state_features, beta1=self.betas[0],
                   beta2=self.betas[1], eps=self.eps)
-        args = (self.spec, self.densities, self.features, grad_layout, workspace, self.steps, self.lr)
-        if world == 1 and not (self.exercise_collectives and dist.is_initialized()):
-            self.mode = "single"
-            return self.ops.grid_adam_step_(*args, **kw)
+        args = (self.spec, self.densities, self.features, grad_layout, workspace, step_no, self.lr)
+        if not self._collective():
+            self.ops.grid_adam_step_(*args, **kw)
+            return "single"
         region = self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace)
         slab = self._slab(grad_layout)
-        if slab is None:
-            self.mode = "all-reduce + replicated step"
+        if slab is None or exchange == "all-reduce":
             dist.all_reduce(region)
-            return self.ops.grid_adam_step_(*args, **kw)
-        self.mode = "reduce-scatter + sharded step + all-gather of the packed grid"
+            self.ops.grid_adam_step_(*args, **kw)
+            return self._MODE_NAMES["all-reduce"]
         x0, x1, g_per, p_per = slab
-        if self._shard is None or self._shard.numel() != g_per:
-            self._shard = torch.empty(g_per, dtype=region.dtype, device=region.device)
-        dist.reduce_scatter_tensor(self._shard, region[: world * g_per])
-        # the step reads (and clears) the gradient in place: put the summed slab where the kernel expects it and clear
-        # what this rank's own backward left in the other slabs
+        mine = region[rank * g_per: (rank + 1) * g_per]
+        if exchange == "all-to-all":
+            if self._recv is None or self._recv.numel() != world * g_per:
+                self._recv = torch.empty(world * g_per, dtype=region.dtype, device=region.device)
+            dist.all_to_all_single(self._recv, region[: world * g_per])      # slab j of every rank -> rank j
+            torch.sum(self._recv.view(world, g_per), dim=0, out=mine)
+        else:
+            if self._shard is None or self._shard.numel() != g_per:
+                self._shard = torch.empty(g_per, dtype=region.dtype, device=region.device)
+            dist.reduce_scatter_tensor(self._shard, region[: world * g_per])
+            mine.copy_(self._shard)
+        # the step reads (and clears) the gradient in place: the summed slab is where the kernel expects it; clear what
+        # this rank's own backward left in the other slabs
         region[: rank * g_per].zero_()
         region[(rank + 1) * g_per:].zero_()
-        region[rank * g_per: (rank + 1) * g_per].copy_(self._shard)
         self.ops.grid_adam_step_(*args, x_range=(x0, x1), **kw)
         packed = self.ops.workspace_packed_view(self.spec, self.densities, self.features, workspace)
         dist.all_gather_into_tensor(packed, packed[rank * p_per: (rank + 1) * p_per])
+        self._sharded_ran = True
+        return self._MODE_NAMES[exchange]
+
+    @torch.no_grad()
+    def step(self, workspace, grad_layout: int) -> None:
+        self.steps += 1
+        self.mode = self._run(workspace, grad_layout, self.exchange, self.steps)
+
+    @torch.no_grad()
+    def autotune(self, workspace, grad_layout: int, iters: int = 5, sync=None) -> str:
+        """Time every exchange with `iters` dry steps and keep the fastest (max over ranks, so all ranks agree).
+        Call before the first real step, with the workspace holding a packed grid: the gradient region is cleared here,
+        and with zero gradient and zero moments a step changes no parameter bit.  `sync`: device synchronisation around
+        the timed loops (default: torch.cuda.synchronize when the grid lives on a GPU)."""
+        import time
+
+        if self.steps != 0:
+            raise RuntimeError("autotune() must run before the first optimiser step")
+        if not self._collective():
+            return self.exchange
+        if sync is None:
+            sync = torch.cuda.synchronize if self.densities.is_cuda else (lambda: None)
+        self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace).zero_()
+        times = []
+        for exchange in self.EXCHANGES:
+            self._run(workspace, grad_layout, exchange, 1)          # buffers, communicator warm-up
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                self._run(workspace, grad_layout, exchange, 1)
+            sync()
+            times.append((time.perf_counter() - t0) / iters * 1e3)
+        t = torch.tensor(times, dtype=torch.float64, device=self.densities.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.tuned_ms = {e: round(float(v), 4) for e, v in zip(self.EXCHANGES, t.tolist())}
+        self.exchange = min(self.tuned_ms, key=self.tuned_ms.get)
+        self._sharded_ran = False      # (dry steps changed nothing: the raw tensors are still whole)
+        return self.exchange
 
     @torch.no_grad()
     def gather_parameters(self) -> None:
-        """all ranks -> the full raw tensors (a no-op unless the sharded mode ran)"""
+        """all ranks -> the full raw tensors (a no-op unless a sharded step ran)"""
         rank, world = world_info()
-        if not self.mode.startswith("reduce-scatter"):
+        if not self._sharded_ran:
             return
         for t in (self.densities, self.features):
             flat = t.view(-1)
             per = flat.numel() // world
             dist.all_gather_into_tensor(flat, flat[rank * per: (rank + 1) * per].clone())
             torch.autograd.graph.increment_version(t)
+        self._sharded_ran = False
