@@ -135,8 +135,9 @@ class ShardedGridAdam:
           of ITS slab), fused Adam on that slab only (raw parameters + moments of the other slabs are never touched on
           this rank), all-gather of the packed grid's slabs, in place, so every rank renders the same updated grid.
           Same wire bytes as one all-reduce; the optimiser's HBM pass shrinks by `world`.
-      "all-to-all"  the same with the reduce-scatter spelled as ONE all-to-all of the slabs (point-to-point over every
-          xGMI link at once instead of the library's ring) + a local sum over the `world` received slabs.
+      "all-to-all"  the same with both collectives spelled as direct transfers: ONE all-to-all of the gradient slabs
+          (point-to-point over every xGMI link at once instead of the library's ring) + a local sum over the `world`
+          received slabs, and the packed slabs sent to every peer as one batch of point-to-point operations.
       "all-reduce"  all-reduce of the whole gradient region + the replicated full step (also the fallback whenever X is
           not divisible by the world size).
     `autotune()` times the three on the job's own ranks and links (dry steps before training: zero gradient + zero
@@ -148,7 +149,7 @@ class ShardedGridAdam:
     EXCHANGES = ("reduce-scatter", "all-to-all", "all-reduce")
     _MODE_NAMES = {
         "reduce-scatter": "reduce-scatter + sharded step + all-gather of the packed grid",
-        "all-to-all": "all-to-all + local sum + sharded step + all-gather of the packed grid",
+        "all-to-all": "all-to-all + local sum + sharded step + point-to-point all-gather of the packed grid",
         "all-reduce": "all-reduce + replicated step",
     }
 
@@ -222,7 +223,17 @@ class ShardedGridAdam:
         region[(rank + 1) * g_per:].zero_()
         self.ops.grid_adam_step_(*args, x_range=(x0, x1), **kw)
         packed = self.ops.workspace_packed_view(self.spec, self.densities, self.features, workspace)
-        dist.all_gather_into_tensor(packed, packed[rank * p_per: (rank + 1) * p_per])
+        if exchange == "all-to-all":
+            # the all-gather as direct sends too: this rank's packed slab to every peer, theirs into place
+            if world > 1:
+                sends = [dist.P2POp(dist.isend, packed[rank * p_per: (rank + 1) * p_per], peer)
+                         for peer in range(world) if peer != rank]
+                recvs = [dist.P2POp(dist.irecv, packed[peer * p_per: (peer + 1) * p_per], peer)
+                         for peer in range(world) if peer != rank]
+                for req in dist.batch_isend_irecv(sends + recvs):
+                    req.wait()
+        else:
+            dist.all_gather_into_tensor(packed, packed[rank * p_per: (rank + 1) * p_per])
         self._sharded_ran = True
         return self._MODE_NAMES[exchange]
 
@@ -248,14 +259,17 @@ class ShardedGridAdam:
         self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace).zero_()
         times = []
         for exchange in self.EXCHANGES:
-            self._run(workspace, grad_layout, exchange, 1)          # buffers, communicator warm-up
-            sync()
-            dist.barrier()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                self._run(workspace, grad_layout, exchange, 1)
-            sync()
-            times.append((time.perf_counter() - t0) / iters * 1e3)
+            try:
+                self._run(workspace, grad_layout, exchange, 1)          # buffers, communicator warm-up
+                sync()
+                dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self._run(workspace, grad_layout, exchange, 1)
+                sync()
+                times.append((time.perf_counter() - t0) / iters * 1e3)
+            except RuntimeError:       # a backend without this collective: never pick it (MAX over ranks below)
+                times.append(float("inf"))
         t = torch.tensor(times, dtype=torch.float64, device=self.densities.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         self.tuned_ms = {e: round(float(v), 4) for e, v in zip(self.EXCHANGES, t.tolist())}
