@@ -122,6 +122,35 @@ def test_reconstruction_trainer_fits_synthetic_views(tmp_path):
     assert min(psnrs) > 20.0, psnrs  # a random grid renders at ~8 dB
 
 
+def test_reconstruction_trainer_view_dependent_field(tmp_path):
+    """the same run with an SH degree-1 field (12 feature channels): random-ray batches go through the line-dense scatter
+    backward of 13-channel texels, the diffuse render through the single-group path, full-image renders through the
+    wider gather"""
+    torch.manual_seed(2)
+    truth = _sphere_model(side=24, samples=96)
+    intr = CameraIntrinsics(48, 48, 0.5 * 48 / np.tan(0.5 * 0.6911112))
+    poses, images = [], []
+    for i in range(16):
+        pose = pose_spherical(360.0 * i / 16, 20.0 + 50.0 * ((i * 0.618) % 1.0), 4.0311)
+        poses.append(torch.cat([pose.rotation, pose.translation], dim=1))
+        images.append(truth.render(pose, intr, perturb_sampled_points=False).colour.permute(2, 0, 1).cpu())
+    data = InMemoryPosedImages(torch.stack(images), torch.stack(poses), intr, CameraBounds(1.8, 6.6))
+    g = torch.Generator().manual_seed(4)
+    vg = VoxelGrid(torch.empty(24, 24, 24, 1).uniform_(-1, 1, generator=g), torch.empty(24, 24, 24, 12).uniform_(-1, 1, generator=g),
+                   VoxelSize(0.125, 0.125, 0.125), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=100.0 / 3.0, tunable=True)
+    vm = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(96, CameraBounds(1.8, 6.6), white_bkgd=True), device=DEV)
+    train_sh_vox_grid_vol_mod_with_posed_images(vm, data, tmp_path, ray_batch_size=4096, num_stages=1,
+                                                num_iterations_per_stage=250, summary_freq=250, save_freq=10 ** 6)
+    assert vm.thre3d_repr.features.shape[-1] == 12
+    psnrs = []
+    for i in (0, 5, 11):
+        pose = pose_spherical(360.0 * i / 16, 20.0 + 50.0 * ((i * 0.618) % 1.0), 4.0311)
+        img = vm.render(pose, intr, perturb_sampled_points=False).colour.permute(2, 0, 1).cpu()
+        psnrs.append(-10 * np.log10(float(((img - data.images[i]) ** 2).mean())))
+    assert min(psnrs) > 20.0, psnrs
+
+
 def test_render_entry_point(tmp_path):
     import importlib.util
 
