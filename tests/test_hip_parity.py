@@ -493,3 +493,22 @@ def test_early_termination_sh1_routes_agree(monkeypatch):
     assert rel_l2(two_d, one_d) < 1e-5 and rel_l2(two_f, one_f) < 1e-5
     assert rel_l2(two_d, sc_d) < 1e-4 and rel_l2(two_f, sc_f) < 1e-5
     assert 0 < rel_l2(two_f, full_f) < 0.05      # (the cut really changes the gradient, a little)
+
+
+@pytest.mark.parametrize("kl", [8, 10])
+@pytest.mark.parametrize("hw,cam", [((40, 56), 2), ((33, 47), 5), ((96, 96), 3)])
+def test_window_width_variants(kl, hw, cam, monkeypatch):
+    """the LDS-window backward with both lateral window widths (8: fine images, 10: about one pixel per voxel or fewer),
+    whatever the launch heuristic would pick: gradients vs the oracle"""
+    monkeypatch.setenv("VOXE_TILE_KL", str(kl))
+    g = load_golden("frames32.npz")
+    grid = grid_from_golden(g, "", "softplus")
+    h, w = hw
+    o, d = vo.cast_rays(h, w, 0.5 * w / np.tan(0.5 * 0.6911112), g["rot"][cam], g["trans"][cam])
+    cfg = cfg_from_bounds(g["bounds"], 96, white_bkgd=True)
+    rng = np.random.default_rng(kl + cam)
+    gc = rng.standard_normal((h * w, 3)).astype(np.float32)
+    gdep = rng.standard_normal(h * w).astype(np.float32) * 0.1
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, image_width=w)
+    assert rel_l2(gd, rd) < GRAD_REL_L2 and rel_l2(gf, rf) < GRAD_REL_L2

@@ -43,9 +43,9 @@ __device__ __forceinline__ int ring_slot(int key) {
   const int m = key % VOXE_TILE_RING;
   return m < 0 ? m + VOXE_TILE_RING : m;
 }
-constexpr int kLat = 8;                  // lateral window edge (voxels)
-constexpr int kLayerSlots = kLat * kLat; // 64
-constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
+// Lateral window edge KL (voxels): 8 for images whose pixels are at most ~0.5 voxel apart (a whole 8x8-pixel tile then
+// spans < 5.5 voxels); 10 for coarse images (about one pixel per voxel or fewer), where an 8-wide window would force
+// most tiles into 16-lane quadrants.  The price is LDS: 12.4 / 19.4 KB per one-wave block (12 did not pay: 27.8 KB).
 // channel planes are padded by a few doubles so the C channels of one voxel, read together by the
 // flush, sit in different bank groups; the plane offset folds into the ds instruction's immediate
 #ifndef VOXE_TILE_PAD
@@ -63,7 +63,21 @@ constexpr int kWinSlots = kRing * kLayerSlots;  // 512 slots per channel
 // LDS mapping constants, swept on hardware with tools/variants.py + tools/ab_variants.sh (three cameras): channel
 // rotation by lane & 3 instead of (lane >> 1) & 3: backward -6.5 %; layer rotation 9 / 17 / 25 ~ equal, 21 +0.4 %;
 // plane padding 6 ~ 10 < 2 < 4 << 8 (+35 %: bank aliasing)
-constexpr int kPlane = kWinSlots + VOXE_TILE_PAD;   // padding swept on hardware (0: 1.05 ms, 8: 0.98, 16: 1.05, 6: 0.953 per 400x400 backward)
+template <int KL>
+struct Lat {
+  static constexpr int kLat = KL;
+  static constexpr int kLayerSlots = KL * KL;               // 64 for KL = 8
+  static constexpr int kPlane = kRing * KL * KL + VOXE_TILE_PAD;   // padding swept on hardware (KL = 8; 0: 1.05 ms, 8: 0.98, 16: 1.05, 6: 0.953 per 400x400 backward)
+  static constexpr int kCentre = KL / 2 - 1;                // lateral cells below the reference ray
+  // storage position of lateral cell ab inside its layer: KL = 8 rotates it per layer (64 slots = one bank period, so
+  // the same (a, b) of neighbouring layers would share banks); 100 / 144-slot layers are staggered by their size
+  static __device__ __forceinline__ int pos(int key, int ab) {
+    if constexpr (KL == 8) return (ab + VOXE_TILE_ROT * ring_slot(key)) & 63;
+    return ab;
+  }
+  static __device__ __forceinline__ int rot_of(int key) { return KL == 8 ? VOXE_TILE_ROT * ring_slot(key) : 0; }
+  static __device__ __forceinline__ int wrap(int x) { return KL == 8 ? (x & 63) : x; }
+};
 
 // wave-wide integer min / max, result wave-uniform (DPP inside rows of 16, readlane across rows).
 // Must be called with all 64 lanes active.
@@ -89,32 +103,32 @@ struct Window {
   float Au, Bu, Av, Bv; // lateral position of the reference ray as a function of the m index
   int stride_m, stride_u, stride_v;
   int base;             // lowest live layer key
+  int ctr;              // lateral cells below the reference ray (Lat<KL>::kCentre)
 
-  __device__ __forceinline__ int off_u(int im) const { return (int)floorf(Au + Bu * (float)im) - 3; }
-  __device__ __forceinline__ int off_v(int im) const { return (int)floorf(Av + Bv * (float)im) - 3; }
-  // storage position of lateral cell (a, b) inside its layer: rotated per layer so that the same (a, b)
-  // of neighbouring layers lands in different LDS banks
-  __device__ __forceinline__ int layer_pos(int key, int ab) const { return (ab + VOXE_TILE_ROT * ring_slot(key)) & 63; }
+  __device__ __forceinline__ int off_u(int im) const { return (int)floorf(Au + Bu * (float)im) - ctr; }
+  __device__ __forceinline__ int off_v(int im) const { return (int)floorf(Av + Bv * (float)im) - ctr; }
 };
 // WC = channels held by the window, CM = channels of a packed texel, memch = texel channel of THIS lane's window
 // channel (lane % WC)
-template <int WC>
+template <int WC, int KL>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
                                             const Window& w, int key, int lane, int CM, int memch) {
   constexpr int C = WC;
+  constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots, kPlane = Lat<KL>::kPlane;
   const int im = w.sgn * key;
   const int offu = w.off_u(im), offv = w.off_v(im);
   const int lbase = ring_slot(key) * kLayerSlots;
   constexpr int kPerInstr = 64 / C;  // voxels per wave instruction (C == 4 -> 16, C == 2 -> 32)
 #pragma unroll
-  for (int j = 0; j < kLayerSlots / kPerInstr; ++j) {
-    const int ab = j * kPerInstr + lane / C;  // lateral cell: a = ab >> 3, b = ab & 7 (b is the z-run)
+  for (int j = 0; j < (kLayerSlots + kPerInstr - 1) / kPerInstr; ++j) {
+    const int ab = j * kPerInstr + lane / C;  // lateral cell: a = ab / KL, b = ab % KL (b is the z-run)
+    if (kLayerSlots % kPerInstr != 0 && ab >= kLayerSlots) continue;
     const int ch = lane % C;
-    const int idx = ch * kPlane + lbase + w.layer_pos(key, ab);
+    const int idx = ch * kPlane + lbase + Lat<KL>::pos(key, ab);
     const double val = win[idx];
     if (val != 0.0) {
       win[idx] = 0.0;
-      const int iu = (ab >> 3) + offu, iv = (ab & 7) + offv;
+      const int iu = ab / kLat + offu, iv = ab % kLat + offv;
       const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
       atomicAdd(gpacked + vox * CM + memch, (float)val);
     }
@@ -131,12 +145,12 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
 // (full gather, all the math) and stores the 4 per-sample gradient sources (d rad_0..2, d v); MODE 2 (one block per
 // group) recomputes only the footprints, loads the sources and deposits its 4 channels.  MODE 0 does both in one kernel
 // (every single-group render; view-dependent grids without the scratch buffer).
-template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE>
+template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE, int KL>
 // launch bounds swept: (64, 3) best; 2 and 4..6 are 6-9 % slower (register budget vs the LDS-bound residency)
 #ifndef VOXE_TILE_LB
 #define VOXE_TILE_LB 3
 #endif
-__global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
+__global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
@@ -149,6 +163,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
   constexpr int C = NG < 4 ? NG : 4;          // channels held by the LDS window
   constexpr int NGRP = (NG + C - 1) / C;      // channel groups (1 for SH-0 / diffuse / attention renders)
   static_assert(MODE == 0 || (COUT == 3 && NGRP > 1), "the two-phase backward is for view-dependent grids");
+  constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots, kPlane = Lat<KL>::kPlane;
   constexpr int kWinDoubles = MODE == 1 ? 1 : C * kPlane;   // (the source pass has no window)
   __shared__ double win[kWinDoubles];
   const int lane = threadIdx.x;
@@ -209,7 +224,8 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
         halfx = fmaxf(halfx, 3.0f * ex + 7.0f * ey);
         halfy = fmaxf(halfy, 7.0f * ex + 3.0f * ey);
       }
-      if (full > 5.5f) split = (fminf(halfx, halfy) <= 5.5f) ? (halfx <= halfy ? 1 : 2) : 3;
+      constexpr float kFit = (float)KL - 2.5f;   // lateral extent (voxels) a pass may have: 5.5 for the 8-wide window
+      if (full > kFit) split = (fminf(halfx, halfy) <= kFit) ? (halfx <= halfy ? 1 : 2) : 3;
     }
   }
   auto run_pass = [&](const bool alive_q, const int centre_lane) {
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
 
     // ---- window geometry from a reference ray (the lane next to the tile centre, if it has samples) ----
     Window w;
+    w.ctr = Lat<KL>::kCentre;
     {
       const unsigned long long hm = __ballot(has);
       const int ref = ((hm >> centre_lane) & 1ull) ? centre_lane : (__ffsll((long long)hm) - 1);
@@ -416,7 +433,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
               fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
                      ((unsigned)b0 < (unsigned)(kLat - 1));
               lofs[s] = ring_slot(key) * kLayerSlots;
-              ab0[s] = a0 * kLat + b0 + VOXE_TILE_ROT * ring_slot(key);  // + the per-layer rotation of layer_pos()
+              ab0[s] = a0 * kLat + b0 + Lat<KL>::rot_of(key);  // + the per-layer rotation of Lat::pos()
             }
             if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
               // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
               for (int cc = 0; cc < 8; ++cc) {
                 const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;  // compile-time bits of this instruction
                 const float wgt = wmu[bm + 2 * bu] * (bv ? wvB : wvA);
-                const int idx = (bm ? lofB : lofA) + ((abu[bm + 2 * bu] + (bv ? vB : vA)) & 63);
+                const int idx = (bm ? lofB : lofA) + Lat<KL>::wrap(abu[bm + 2 * bu] + (bv ? vB : vA));
   #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
                   if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
                   const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
                                      ((unsigned)b < (unsigned)kLat);
                   if (inwin) {
-                    const int idx = ring_slot(key) * kLayerSlots + w.layer_pos(key, a * kLat + b);
+                    const int idx = ring_slot(key) * kLayerSlots + Lat<KL>::pos(key, a * kLat + b);
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
                       if (NGRP > 1 || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
@@ -509,7 +526,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
         __syncthreads();
         const long long adv = (long long)newbase - (long long)w.base;
         const int nflush = adv < kRing ? (int)adv : kRing;
-        for (int i = 0; i < nflush; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane, CM, my_memch);
+        for (int i = 0; i < nflush; ++i) flush_layer<C, KL>(win, gpacked, w, w.base + i, lane, CM, my_memch);
         w.base = newbase;
         __syncthreads();
       }
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(64, (NCU > 1 && MODE != 2) ? 2 : VOXE_TILE_LB) void
     __syncthreads();
     if constexpr (MODE != 1) {
       if (w.base != INT_MAX) {
-        for (int i = 0; i < kRing; ++i) flush_layer<C>(win, gpacked, w, w.base + i, lane, CM, my_memch);
+        for (int i = 0; i < kRing; ++i) flush_layer<C, KL>(win, gpacked, w, w.base + i, lane, CM, my_memch);
       }
     }
 
@@ -564,21 +581,40 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S) * ngrp;
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
   const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S) * qsplit * ngrp;
-#define VOXE_TBWD(WD, WF, MODE, NB, GB, NGR)                                                     \
-  render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE><<<NB, 64, 0, st>>>(                        \
+#define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
+  render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE, KL><<<NB, 64, 0, st>>>(                    \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
       a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src))
   if constexpr (NGRP > 1) {
     if (a.sample_src && a.want_f) {   // two-phase: march once for the per-sample sources, then one deposit block per group
-      if (a.want_d) VOXE_TBWD(true, true, 1, nb / ngrp, 0, 1);
-      else VOXE_TBWD(false, true, 1, nb / ngrp, 0, 1);
-      VOXE_TBWD(true, true, 2, nb, 0, ngrp);
+      if (a.want_d) VOXE_TBWD(true, true, 1, 8, nb / ngrp, 0, 1);
+      else VOXE_TBWD(false, true, 1, 8, nb / ngrp, 0, 1);
+      VOXE_TBWD(true, true, 2, 8, nb, 0, ngrp);
       return;
     }
+    if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, 8, nb, grp_begin, ngrp);
+    else if (a.want_d) VOXE_TBWD(true, false, 0, 8, nb, grp_begin, ngrp);
+    else VOXE_TBWD(false, true, 0, 8, nb, grp_begin, ngrp);
+  } else {
+    // lateral window edge: pixels that are far apart (in voxels) need a wider window to keep larger parts of a tile in one
+    // pass.  The pixel spacing is not known on the host; for a camera that frames the volume it is ~ grid side / image
+    // width.  Measured on MI355X (160^3, backward ms, window 8 / 10 / 12): 400 px 0.58 / 0.78 / 1.06, 266 px 0.38 / 0.40 /
+    // 0.55, 200 px 0.36 / 0.31 / 0.36, 100 px 0.30 / 0.26 / 0.26 -- the wider window costs residency (19.4 KB of LDS
+    // per block) and only pays once most tiles of the 8-wide window would run as halves or quadrants.
+    const char* env_kl_s = getenv("VOXE_TILE_KL");     // 8 | 10 overrides the choice (read per launch: the tests flip it)
+    const int env_kl = env_kl_s ? atoi(env_kl_s) : 0;
+    const int side = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
+    const int kl = env_kl ? env_kl : ((float)side >= 0.75f * (float)W ? 10 : 8);
+#define VOXE_TBWD_KL(KL)                                                       \
+    do {                                                                       \
+      if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, KL, nb, 0, 1);         \
+      else if (a.want_d) VOXE_TBWD(true, false, 0, KL, nb, 0, 1);               \
+      else VOXE_TBWD(false, true, 0, KL, nb, 0, 1);                             \
+    } while (0)
+    if (kl == 10) VOXE_TBWD_KL(10);
+    else VOXE_TBWD_KL(8);
+#undef VOXE_TBWD_KL
   }
-  if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, nb, grp_begin, ngrp);
-  else if (a.want_d) VOXE_TBWD(true, false, 0, nb, grp_begin, ngrp);
-  else VOXE_TBWD(false, true, 0, nb, grp_begin, ngrp);
 #undef VOXE_TBWD
 }
 
