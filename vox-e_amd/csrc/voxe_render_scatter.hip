@@ -25,6 +25,15 @@ namespace voxe {
 // instruction are (corner j, 8 consecutive gradient channels) of ONE sample, i.e. 32 contiguous bytes per corner, and a
 // sample takes ceil((3 NCU + 1) / 8) instructions -- 16 requests per sample at SH-1 instead of the 104 of
 // render_bwd_kernel.
+//
+// Consecutive samples of a ray are about a voxel apart (S = 256 over 160 voxels), so the 2x2x2 footprints of samples
+// k and k + 1 share a face: every lane keeps the footprint of its current cell PENDING in registers (8 corners x C
+// channels), adds the next sample into it when the cell did not change, and otherwise hands over only the corners that
+// left the footprint -- the others move to their place in the new cell's footprint.  The scatter is bound by atomic
+// REQUESTS, and a request is now a voxel-channel that a ray is done with (~4 texels per sample instead of 8).
+#ifndef VOXE_SCATTER_PEND
+#define VOXE_SCATTER_PEND 1
+#endif
 template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F>
 __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
@@ -42,6 +51,8 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
   __shared__ float s_w[8][64];
   __shared__ float s_g[C][64];
   __shared__ float s_basis[NCU > 1 ? NCU : 1][64];
+  constexpr bool kPend = VOXE_SCATTER_PEND != 0;   // (view-dependent grids: the 4 SOURCES per corner are pending)
+  __shared__ float s_val[kPend ? 8 * C : 1][64];          // handed-over corner values (weights already applied)
   const int lane = threadIdx.x;
 
   // With the forward's depth-segment states (ray_state != nullptr) a block is (64 rays, 32-sample depth segment),
@@ -107,15 +118,23 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
   for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
   if (white) prefix -= gsum * pre_a;
   float z_next = has ? rc.dg.z(k_lo) : 0.0f;
-  for (int i = 0; i < trips; ++i) {
+  // pending footprint of this lane's ray: cell (pc0 == INT_MIN: none) and its 8 x C accumulated values
+  int pc0 = INT_MIN, pc1 = 0, pc2 = 0;
+  float pend[8][C];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) pend[j][ch] = 0.0f;
+  for (int i = 0; i < trips + (kPend ? 1 : 0); ++i) {   // (+1: the iteration after a lane's last sample hands over the rest)
     const int k = k_lo + i;
+    const bool active = has && k <= k_hi;
     int base = -1, cy0 = 0, cz0 = 0;
     float wc[8], gch[C];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wc[j] = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) gch[ch] = 0.0f;
-    if (has && k <= k_hi) {
+    if (active) {
       const float z = z_next;
       const bool last = (k == c.S - 1);
       if (!last) z_next = rc.dg.z(k + 1);
@@ -165,18 +184,93 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
         if (c.term_eps > 0.0f && T < c.term_eps) k_hi = k;
       }
     }
+    float fv[kPend ? 8 : 1][C];   // corners handed over this iteration (cell base / cy0 / cz0 after the block below)
+    if constexpr (kPend) {
+      const bool contrib = base >= 0;
+      const int n0 = base, n1 = cy0, n2 = cz0;
+      base = -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int ch = 0; ch < C; ++ch) fv[j][ch] = 0.0f;
+      if (pc0 != INT_MIN && (!active || (contrib && (n0 != pc0 || n1 != pc1 || n2 != pc2)))) {
+        // the ray is done (or moved on): hand over the pending corners that are not part of the new footprint.
+        // Corner j of the pending cell sits at pc + bits(j); it stays iff on every axis bit - d is 0 or 1 (d = new - old)
+        const int d0 = active ? n0 - pc0 : 4, d1 = active ? n1 - pc1 : 4, d2 = active ? n2 - pc2 : 4;
+        const bool k00 = d0 == 0 || d0 == -1, k01 = d0 == 0 || d0 == 1;   // axis 0: corner bit 0 / bit 1 stays
+        const bool k10 = d1 == 0 || d1 == -1, k11 = d1 == 0 || d1 == 1;
+        const bool k20 = d2 == 0 || d2 == -1, k21 = d2 == 0 || d2 == 1;
+        base = pc0; cy0 = pc1; cz0 = pc2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool stay = ((j & 1) ? k01 : k00) && ((j & 2) ? k11 : k10) && ((j & 4) ? k21 : k20);
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) {
+            fv[j][ch] = stay ? 0.0f : pend[j][ch];
+            pend[j][ch] = stay ? pend[j][ch] : 0.0f;
+          }
+        }
+        // move the survivors to their corner of the new cell, one axis at a time (what is shifted out is already 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const int d = a == 0 ? d0 : (a == 1 ? d1 : d2);
+          const int bit = 1 << a;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (j & bit) continue;
+#pragma unroll
+            for (int ch = 0; ch < C; ++ch) {
+              const float lo = pend[j][ch], hi = pend[j | bit][ch];
+              pend[j][ch] = d == 1 ? hi : (d == -1 ? 0.0f : lo);
+              pend[j | bit][ch] = d == -1 ? lo : (d == 1 ? 0.0f : hi);
+            }
+          }
+        }
+        pc0 = INT_MIN;
+      }
+      if (contrib) {
+        pc0 = n0; pc1 = n1; pc2 = n2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch) pend[j][ch] = fmaf(gch[ch], wc[j], pend[j][ch]);
+      }
+    }
     if (__ballot(base >= 0) == 0ull) continue;  // wave-uniform: nothing to deposit this iteration
     // ---- stage the 64 footprints, then deposit them transposed ------------------------------------
     __syncthreads();
     s_cell[0][lane] = base;
     s_cell[1][lane] = cy0;
     s_cell[2][lane] = cz0;
+    if constexpr (kPend) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s_w[j][lane] = wc[j];
+      for (int j = 0; j < 8; ++j)
 #pragma unroll
-    for (int ch = 0; ch < C; ++ch) s_g[ch][lane] = gch[ch];
+        for (int ch = 0; ch < C; ++ch) s_val[j * C + ch][lane] = fv[j][ch];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s_w[j][lane] = wc[j];
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) s_g[ch][lane] = gch[ch];
+    }
     __syncthreads();
-    if constexpr (NCU == 1) {
+    if constexpr (kPend && NCU == 1) {
+      const int j = (lane / C) & 7, ch = lane % C;  // corner (x bit 0, y bit 1, z bit 2) and channel of this lane
+      const int mem = (ch == COUT) ? CM - 1 : ch * NCM;   // (diffuse renders of wider texels: coefficient 0 of colour ch)
+#pragma unroll 4
+      for (int grp = 0; grp < 64 / kSamplesPerInstr; ++grp) {
+        const int s = grp * kSamplesPerInstr + lane / kLanesPerSample;
+        const int b = s_cell[0][s];
+        if (b >= 0) {
+          const float gv = s_val[j * C + ch][s];
+          if (gv != 0.0f) {
+            const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
+            const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
+            atomicAdd(gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM + mem, gv);
+          }
+        }
+      }
+    } else if constexpr (NCU == 1) {
       const int j = (lane / C) & 7, ch = lane % C;  // corner (x bit 0, y bit 1, z bit 2) and channel of this lane
       const int mem = (ch == COUT) ? CM - 1 : ch * NCM;   // (diffuse renders of wider texels: coefficient 0 of colour ch)
 #pragma unroll 4
@@ -199,7 +293,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
       for (int s = 0; s < 64; ++s) {
         const int b = s_cell[0][s];
         if (b < 0) continue;                        // wave-uniform
-        const float w = s_w[j][s];
+        const float w = kPend ? 1.0f : s_w[j][s];   // (pending footprints carry their weights already)
         const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
         const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
         float* __restrict__ texel = gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM;
@@ -209,7 +303,8 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
           if (q < NG) {
             const int ch = q / NCU, jj = q - ch * NCU;
             const bool dens = (q == NG - 1);
-            const float gv = dens ? s_g[COUT][s] : s_g[ch][s] * s_basis[jj][s];
+            const float src = kPend ? s_val[j * C + (dens ? COUT : ch)][s] : s_g[dens ? COUT : ch][s];
+            const float gv = dens ? src : src * s_basis[jj][s];
             if (gv != 0.0f && w != 0.0f) atomicAdd(texel + (dens ? CM - 1 : ch * NCM + jj), gv * w);
           }
         }
