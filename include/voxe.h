@@ -97,7 +97,8 @@ typedef struct VoxeRenderCfg {
                                  0: the backward first re-marches the rays to rebuild them.       */
 } VoxeRenderCfg;
 
-/* depth-segment length of the image-ordered backward (samples per segment) */
+/* depth-segment length of the segmented kernels (samples per segment); launches of at most 20000 rays use 16: they
+ * leave the chip under-filled, and shorter dependent chains then matter more than the extra boundary states     */
 #ifndef VOXE_SEGMENT_SAMPLES
 #define VOXE_SEGMENT_SAMPLES 32
 #endif

@@ -98,6 +98,7 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->image_width = c->image_width;
   dc->map_mode = tile_map_mode(c->image_width);
   dc->R = R;
+  dc->seg_len = seg_len_for(R);
 }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -110,7 +111,7 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t nvox = (size_t)g->X * g->Y * g->Z;
   const size_t bytes = align_up(nvox * (size_t)(g->F + 1) * sizeof(float), 256);
   const int cout = g->feature_kind == VOXE_FEAT_ATTN ? 1 : 3;
-  const int nseg = c ? num_segments(c->num_samples) : 1;
+  const int nseg = c ? num_segments(c->num_samples, seg_len_for(R)) : 1;
   const size_t state = align_up((size_t)(nseg - 1) * (size_t)(cout + 3) * (size_t)(R > 0 ? R : 0) * sizeof(float), 256);
   // the gradient region also fits the 2x2x2-bricked layout of the scatter backward (dims rounded up to even)
   const size_t bvox = (size_t)((g->X + 1) / 2) * ((g->Y + 1) / 2) * ((g->Z + 1) / 2) * 8;

@@ -36,6 +36,7 @@ struct DevCfg {
   int image_width;            // 0 = linear ray order
   int map_mode;               // block -> tile mapping: 0 XCD bands, 1 linear, 2 tile rows interleaved over XCDs
   long long R;
+  int seg_len;                // samples per depth segment of the segmented kernels (seg_len_for(R))
 };
 
 // ------------------------------------------------------------------------------------------------

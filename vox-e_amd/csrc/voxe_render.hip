@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
 
   // depth-segment states for the segmented backward: state BEFORE sample b * kSegLen
-  const int nbound = ray_state ? num_segments(c.S) - 1 : 0;
+  const int nbound = ray_state ? num_segments(c.S, c.seg_len) - 1 : 0;
   int nextb = 1;
   auto save_state = [&](int b) {
     constexpr int NC = COUT + 3;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
   if (rc.k_lo <= rc.k_hi) {
     float z_next = rc.dg.z(rc.k_lo);
     for (int k = rc.k_lo; k <= rc.k_hi; ++k) {
-      while (nextb <= nbound && nextb * kSegLen <= k) { save_state(nextb); ++nextb; }
+      while (nextb <= nbound && nextb * c.seg_len <= k) { save_state(nextb); ++nextb; }
       const float z = z_next;
       const bool last = (k == c.S - 1);
       if (!last) z_next = rc.dg.z(k + 1);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
                                                              const float* __restrict__ jitter,
                                                              float* __restrict__ segbuf) {
   constexpr int NC = COUT + 3;
-  const int nseg = num_segments(c.S);
+  const int nseg = num_segments(c.S, c.seg_len);
   // one thread = `fseg` consecutive depth segments of one ray (fseg = 1: finest split, used for small images)
   const int ncoarse = (nseg + fseg - 1) / fseg;
   // Block order: SEGMENT-MAJOR -- all ray blocks at coarse segment 0, then all at segment 1, ...  The first and last
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
   float z_next = 0.0f;
   int z_for = -1;  // sample index z_next belongs to
   for (int seg = cseg * fseg; seg < s_end; ++seg) {
-    const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;
+    const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
     const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
     float csum[COUT];
 #pragma unroll
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void render_fwd_combine_kernel(DevCfg c, const
   constexpr int NC = COUT + 3;
   const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= c.R) return;
-  const int nseg = num_segments(c.S);
+  const int nseg = num_segments(c.S, c.seg_len);
   float csum[COUT];
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
@@ -807,7 +807,7 @@ static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d
 
 template <int COUT, int NCM, int NCU>
 static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
-  const int nseg = num_segments(c.S);
+  const int nseg = num_segments(c.S, c.seg_len);
   // The march of every ray block is split into depth segments handled by different blocks (a 100x100 image alone
   // is 40 blocks; at 400x400 the finer split hides the gather latency better): with the segment-major block order
   // one 32-sample segment per task is fastest at every image size (400x400, mean of three cameras: fseg 1 / 2 / 4 / 8

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
   // segment-major like the other render kernels: a 32768-ray batch is 512 waves if every wave marches whole rays --
   // half a wave per SIMD, latency bound far below the atomic-request ceiling -- and 4096 with segments.
   const int nt = (int)((c.R + 63) / 64);
-  const int nseg = ray_state ? num_segments(c.S) : 1;
+  const int nseg = ray_state ? num_segments(c.S, c.seg_len) : 1;
   const int nrb = gridDim.x / nseg;
   const int seg = blockIdx.x / nrb;
   const int logical = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, 1, nt);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
 #pragma unroll
     for (int t = 0; t < NCU; ++t) s_basis[t][lane] = rc.basis[t];
   }
-  const int ks = ray_state ? seg * kSegLen : 0, ke = ray_state ? min(c.S, ks + kSegLen) - 1 : c.S - 1;
+  const int ks = ray_state ? seg * c.seg_len : 0, ke = ray_state ? min(c.S, ks + c.seg_len) - 1 : c.S - 1;
   const int k_lo = max(rc.k_lo, ks);
   int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
   bool has = k_lo <= k_hi;
@@ -317,7 +317,7 @@ bool packed_scatter_supported(int deg) { (void)deg; return true; }
 
 template <int COUT, int NCM, int NCU>
 static void launch_bwd_packed_scatter_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
-  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * (a.ray_state ? num_segments(c.S) : 1);
+  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * (a.ray_state ? num_segments(c.S, c.seg_len) : 1);
 #define VOXE_PBWD(WD, WF)                                                                            \
   render_bwd_packed_scatter_kernel<COUT, NCM, NCU, WD, WF><<<nb, 64, 0, st>>>(                       \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, \

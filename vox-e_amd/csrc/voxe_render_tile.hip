@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   // blocks instead, "empty" and "full" blocks alternate with period nseg, which aliases with the round-robin placement
   // on the 32 CUs of an XCD whenever nseg divides 32 (measured: kSegLen 32 -> 0.87 ms, 24 -> 0.68 ms for the same
   // work before this ordering).  Tiles are spread over the XCDs by logical_tile_of() (default: tile t on XCD t % 8).
-  const int nseg = num_segments(c.S);
+  const int nseg = num_segments(c.S, c.seg_len);
   const int ntp = gridDim.x / (nseg * qsplit * ((NGRP == 1 || MODE == 1) ? 1 : ngrp));  // tile slots (a multiple of 8 >= ntx * nty)
   int part = blockIdx.x / ntp;
   int grp = 0;                                   // channel group of this block (outermost: group-major block order)
@@ -191,9 +191,9 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   const int quad = part / nseg, seg = part - quad * nseg;
   const int tile = logical_tile_of(c, blockIdx.x % ntp, ntp, ntx, nty);
   if (tile < 0) return;  // launch padding (wave-uniform)
-  const int ks = seg * kSegLen, ke = min(c.S, ks + kSegLen) - 1;  // samples of this segment
+  const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;  // samples of this segment
   // two-phase backward: slot of (tile, segment, sample k, lane) in the source buffer
-  const long long src_base = ((long long)tile * nseg + seg) * kSegLen * 64 + lane - (long long)ks * 64;
+  const long long src_base = ((long long)tile * nseg + seg) * c.seg_len * 64 + lane - (long long)ks * 64;
   const int ty = tile / ntx, tx = tile - ty * ntx;
   const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
   const bool alive = (px < W) && (py < H);
@@ -578,9 +578,9 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   constexpr int NG = COUT * NCU + 1, WC = NG < 4 ? NG : 4, NGRP = (NG + WC - 1) / WC;
   // channel groups: all of them for a feature gradient; only the one holding the density channel (the last) otherwise
   const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
-  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S) * ngrp;
+  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S, c.seg_len) * ngrp;
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
-  const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S) * qsplit * ngrp;
+  const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S, c.seg_len) * qsplit * ngrp;
 #define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
   render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE, KL><<<NB, 64, 0, st>>>(                    \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
@@ -621,7 +621,8 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
 size_t tile_src_bytes(long long R, int W, int S, int deg, int diffuse, int attn) {
   if (W <= 0 || R <= 0 || deg <= 0 || diffuse || attn) return 0;   // single-group renders do not use it
   const long long H = R / W, tiles = ((W + 7) / 8) * ((H + 7) / 8);
-  const size_t bytes = (size_t)tiles * num_segments(S) * kSegLen * 64 * sizeof(float4);
+  const int seg = seg_len_for(R);
+  const size_t bytes = (size_t)tiles * num_segments(S, seg) * seg * 64 * sizeof(float4);
   return bytes <= ((size_t)4 << 30) ? bytes : 0;   // above 4 GB the single-kernel groups run instead
 }
 
