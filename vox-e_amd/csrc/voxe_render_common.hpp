@@ -24,7 +24,10 @@ constexpr int kSegLen = VOXE_SEGMENT_SAMPLES;
 // Small launches leave the chip under-filled, and what a wave then costs is its dependent chain of samples (~7 us each):
 // half-length segments double the waves (64x64: backward 0.26 -> 0.15 ms, 100x100: 0.26 -> 0.22 ms); at 400x400 the
 // chip is full either way and 16 / 32 are equal, 8 is 8 % slower (more state traffic, more partial windows).
-__host__ __device__ inline int seg_len_for(long long R) { return (R <= 20000 && kSegLen > 16) ? 16 : kSegLen; }
+#ifndef VOXE_SEG16_MAX_RAYS
+#define VOXE_SEG16_MAX_RAYS 20000
+#endif
+__host__ __device__ inline int seg_len_for(long long R) { return (R <= VOXE_SEG16_MAX_RAYS && kSegLen > 16) ? 16 : kSegLen; }
 __host__ __device__ inline int num_segments(int S, int seg_len) { return (S + seg_len - 1) / seg_len; }
 __device__ __forceinline__ long long ray_state_index(int boundary, int comp, int ncomp, long long R, long long r) {
   return ((long long)(boundary - 1) * ncomp + comp) * R + r;
