@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)   # (the first ~10 steps run below the sustained clocks)
     ap.add_argument("--grid", type=int, default=160)
     ap.add_argument("--image", type=int, default=400)
     ap.add_argument("--samples", type=int, default=256)
