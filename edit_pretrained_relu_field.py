@@ -28,7 +28,23 @@ from thre3d_atom.thre3d_reprs.voxels import (  # noqa: E402
 )
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS  # noqa: E402
 from thre3d_atom.utils.imaging_utils import scale_camera_intrinsics  # noqa: E402
+from thre3d_atom.utils.cli_compat import accepted_options, report_unused  # noqa: E402
+from thre3d_atom.utils.logging import log  # noqa: E402
 from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
+
+# options the reference's script declares and never reads on this path (it loads a trained model), or that configure
+# machinery this build does not have (data-loader workers, wandb accounts, periodic test-set evaluation)
+COMPAT_ONLY = [
+    ("--separate_train_test_folders", click.BOOL, True, 1), ("--grid_dims", click.INT, (160, 160, 160), 3),
+    ("--grid_location", click.FLOAT, (0.0, 0.0, 0.0), 3), ("--normalize_scene_scale", click.BOOL, False, 1),
+    ("--grid_world_size", click.FLOAT, (3.0, 3.0, 3.0), 3), ("--sh_degree", click.INT, 0, 1),
+    ("--use_relu_field", click.BOOL, True, 1), ("--use_softplus_field", click.BOOL, True, 1),
+    ("--parallel_rays_chunk_size", click.INT, 32768, 1), ("--ray_batch_size", click.INT, 84672, 1),
+    ("--scale_factor", click.FLOAT, 2.0, 1), ("--apply_diffuse_render_regularization", click.BOOL, True, 1),
+    ("--num_workers", click.INT, 4, 1), ("--wandb_username", click.STRING, "etaisella", 1),
+    ("--wandb_project_name", click.STRING, "Vox-E", 1), ("--test_frequency", click.INT, 500, 1),
+    ("--verbose_rendering", click.BOOL, False, 1), ("--fast_debug_mode", click.BOOL, False, 1),
+]
 
 
 @click.command()
@@ -68,7 +84,8 @@ from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
 @click.option("-t", "--timestamp", type=click.INT, default=200, show_default=True, help="refinement: diffusion timestamp")
 @click.option("-a", "--hf_auth_token", type=click.STRING, default="", help="refinement: hugging face token (SD 1.4)")
 @click.option("--num_iterations_refine", type=click.INT, default=1500, show_default=True)
-@click.option("--learning_rate_refine", type=click.FLOAT, default=0.028, show_default=True)
+@click.option("--learning_rate_refine", type=click.FLOAT, default=None,
+              help="alias of --learning_rate_attn_learning (takes precedence when given)")
 @click.option("--attn_tv_weight", type=click.FLOAT, default=0.01, show_default=True)
 @click.option("--kval", type=click.FLOAT, default=5.0, show_default=True)
 @click.option("--edit_mask_thresh", type=click.FLOAT, default=0.992, show_default=True)
@@ -77,8 +94,18 @@ from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
 @click.option("--top_k_edit_thresh", type=click.INT, default=300, show_default=True)
 @click.option("--top_k_obj_thresh", type=click.INT, default=200, show_default=True)
 @click.option("--downsample_refine_grid", type=click.BOOL, default=False, show_default=True)
+@click.option("--uncoupled_l2_mode", type=click.BOOL, default=False, show_default=True)
+@click.option("--l2_mode", type=click.BOOL, default=False, show_default=True)
+@click.option("--l1_mode", type=click.BOOL, default=False, show_default=True)
+@click.option("--log_wandb", type=click.BOOL, default=False, show_default=True)
+@click.option("--learning_rate_attn_learning", type=click.FLOAT, default=0.035, show_default=True,
+              help="learning rate of the attention-grid refinement (the reference's option)")
+@accepted_options(COMPAT_ONLY)
 def main(**kwargs) -> None:
     cfg = type("Config", (), kwargs)
+    report_unused(kwargs, COMPAT_ONLY, log)
+    if cfg.learning_rate_refine is None:
+        cfg.learning_rate_refine = cfg.learning_rate_attn_learning
     if cfg.do_refinement and not cfg.edit_idx:
         raise click.UsageError("--do_refinement needs --edit_idx (token indices of the edit words in the prompt)")
     device = torch.device("cuda")
@@ -107,7 +134,8 @@ def main(**kwargs) -> None:
         tv_features_weight=cfg.tv_features_weight, do_sds=cfg.do_sds, sds_t_freq=cfg.sds_t_freq,
         sds_t_start=cfg.sds_t_start, sds_t_gamma=cfg.sds_t_gamma, uncoupled_mode=cfg.uncoupled_mode,
         data_pose_mode=cfg.data_pose_mode, camera_intrinsics=intrinsics, camera_bounds=extra[CAMERA_BOUNDS],
-        hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
+        hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311), uncoupled_l2_mode=cfg.uncoupled_l2_mode,
+        l2_mode=cfg.l2_mode, l1_mode=cfg.l1_mode, log_wandb=cfg.log_wandb,
     )
     saved = output_path / "saved_models"
     extra_info = {CAMERA_BOUNDS: extra[CAMERA_BOUNDS], CAMERA_INTRINSICS: intrinsics,

@@ -23,7 +23,27 @@ from thre3d_atom.thre3d_reprs.voxels import (  # noqa: E402
     create_voxel_grid_from_saved_info_dict_attn,
 )
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS  # noqa: E402
+from thre3d_atom.utils.cli_compat import accepted_options, report_unused  # noqa: E402
+from thre3d_atom.utils.logging import log  # noqa: E402
 from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
+
+# options the reference's script declares and never reads on this path (it loads trained models), or that configure
+# machinery this build does not have (data-loader workers, wandb accounts, periodic test-set evaluation, LR stages of a
+# single-stage run)
+COMPAT_ONLY = [
+    ("--separate_train_test_folders", click.BOOL, True, 1), ("--grid_dims", click.INT, (160, 160, 160), 3),
+    ("--grid_location", click.FLOAT, (0.0, 0.0, 0.0), 3), ("--normalize_scene_scale", click.BOOL, False, 1),
+    ("--grid_world_size", click.FLOAT, (3.0, 3.0, 3.0), 3), ("--sh_degree", click.INT, 0, 1),
+    ("--use_relu_field", click.BOOL, True, 1), ("--use_softplus_field", click.BOOL, True, 1),
+    ("--render_num_samples_per_ray", click.INT, 1024, 1), ("--parallel_rays_chunk_size", click.INT, 32768, 1),
+    ("--ray_batch_size", click.INT, 84672, 1), ("--train_num_samples_per_ray", click.INT, 256, 1),
+    ("--num_stages", click.INT, 1, 1), ("--scale_factor", click.FLOAT, 2.0, 1),
+    ("--lr_decay_steps_per_stage", click.INT, 5000 * 100, 1), ("--lr_decay_gamma_per_stage", click.FLOAT, 0.1, 1),
+    ("--stagewise_lr_decay_gamma", click.FLOAT, 0.9, 1), ("--apply_diffuse_render_regularization", click.BOOL, True, 1),
+    ("--num_workers", click.INT, 4, 1), ("--test_frequency", click.INT, 250, 1),
+    ("--verbose_rendering", click.BOOL, False, 1), ("--directional_dataset", click.BOOL, True, 1),
+    ("--wandb_username", click.STRING, "etaisella", 1), ("--wandb_project_name", click.STRING, "Vox-E-refine", 1),
+]
 
 
 @click.command()
@@ -53,8 +73,11 @@ from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
 @click.option("--min_num_edit_voxels", type=click.INT, default=300, show_default=True)
 @click.option("--top_k_edit_thresh", type=click.INT, default=300, show_default=True)
 @click.option("--top_k_obj_thresh", type=click.INT, default=200, show_default=True)
+@click.option("--log_wandb", type=click.BOOL, default=False, show_default=True)
+@accepted_options(COMPAT_ONLY)
 def main(**kwargs) -> None:
     cfg = type("Config", (), kwargs)
+    report_unused(kwargs, COMPAT_ONLY, log)
     device = torch.device("cuda")
     output_path = Path(cfg.output_path)
     log_config_to_disk(kwargs, output_path)
@@ -86,6 +109,7 @@ def main(**kwargs) -> None:
         top_k_obj_thresh=cfg.top_k_obj_thresh, data_pose_mode=cfg.data_pose_mode,
         downsample_refine_grid=cfg.downsample_refine_grid, camera_intrinsics=extra[CAMERA_INTRINSICS],
         camera_bounds=extra[CAMERA_BOUNDS], hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
+        log_wandb=cfg.log_wandb,
     )
 
 

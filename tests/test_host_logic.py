@@ -236,3 +236,49 @@ def test_product_never_imports_the_oracle():
             "bad = [m for m in sys.modules if m.split('.')[0] == 'oracle' or 'voxe_oracle' in m]; "
             "assert not bad, bad" % os.path.join(root, "vox-e_amd"))
     subprocess.check_call([sys.executable, "-c", code])
+
+
+def test_entry_points_accept_every_reference_option():
+    """the reference's shell scripts must run unchanged: every option its four entry points declare
+    (tests/golden/cli_options.json, tools/gen_cli_options.py) is accepted by this build's entry point of the same name"""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "cli_options.json")))
+    for script, options in ref.items():
+        spec = importlib.util.spec_from_file_location("entry_" + script[:-3], os.path.join(root, script))
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        params = {o: p for p in module.main.params for o in p.opts}
+        missing = sorted(set(options) - set(params))
+        assert not missing, (script, missing)
+        for name, info in options.items():     # short aliases too (-i, -o, -p ...)
+            for alias in info["names"]:
+                assert alias in params or alias in {o for p in module.main.params for o in p.secondary_opts}, (script, alias)
+            if info["nargs"]:
+                assert params[name].nargs == info["nargs"], (script, name)
+
+
+def test_entry_point_defaults_equal_the_reference():
+    """options that exist in the reference keep the reference's default values"""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = json.load(open(os.path.join(root, "tests", "golden", "cli_options.json")))
+    for script, options in ref.items():
+        spec = importlib.util.spec_from_file_location("entry2_" + script[:-3], os.path.join(root, script))
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        params = {o: p for p in module.main.params for o in p.opts}
+        for name, info in options.items():
+            if info["default"] is None:
+                continue
+            try:
+                want = eval(info["default"], {}, {})      # literals only ("5000 * 100", "(3.0, 3.0, 3.0)", '"Vox-E"')
+            except Exception:
+                continue
+            got = params[name].default
+            got = tuple(got) if isinstance(want, tuple) else got
+            assert got == want, (script, name, got, want)

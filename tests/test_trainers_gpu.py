@@ -151,6 +151,43 @@ def test_reconstruction_trainer_view_dependent_field(tmp_path):
     assert min(psnrs) > 20.0, psnrs
 
 
+def test_train_entry_point_with_reference_style_options(tmp_path):
+    """the reconstruction CLI on a tiny synthetic scene written in the reference's on-disk format (train/ images +
+    train_camera_params.json), called with options the reference's shell scripts pass"""
+    import importlib.util
+    import json
+
+    from click.testing import CliRunner
+    from PIL import Image
+
+    from thre3d_atom.data.constants import BOUNDS, EXTRINSIC, FOCAL, HEIGHT, INTRINSIC, ROTATION, TRANSLATION, WIDTH
+
+    truth = _sphere_model(side=16, samples=64)
+    intr = CameraIntrinsics(32, 32, 0.5 * 32 / np.tan(0.5 * 0.6911112))
+    data = tmp_path / "data"
+    (data / "train").mkdir(parents=True)
+    params = {}
+    for i in range(8):
+        pose = pose_spherical(360.0 * i / 8, 20.0 + 50.0 * ((i * 0.618) % 1.0), 4.0311)
+        img = truth.render(pose, intr, perturb_sampled_points=False).colour.clamp(0, 1).cpu().numpy()
+        Image.fromarray((img * 255).astype(np.uint8)).save(data / "train" / f"r_{i}.png")
+        params[f"r_{i}.png"] = {EXTRINSIC: {ROTATION: pose.rotation.cpu().numpy().tolist(), TRANSLATION: pose.translation.cpu().numpy().tolist()},
+                                INTRINSIC: {HEIGHT: 32, WIDTH: 32, FOCAL: float(intr.focal), BOUNDS: [2.0, 6.0]}}
+    (data / "train_camera_params.json").write_text(json.dumps(params))
+    spec = importlib.util.spec_from_file_location("train_cli", os.path.join(ROOT, "train_sh_based_voxel_grid_with_posed_images.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(mod.main, [
+        "-d", str(data), "-o", str(out), "--grid_dims", "16", "16", "16", "--num_stages", "1", "--num_iterations_per_stage", "30",
+        "--ray_batch_size", "1024", "--train_num_samples_per_ray", "48", "--render_num_samples_per_ray", "64",
+        "--separate_train_test_folders", "True", "--normalize_scene_scale", "False", "--num_workers", "2",
+        "--save_frequency", "1000", "--test_frequency", "1000", "--feedback_frequency", "1000", "--summary_frequency", "10",
+        "--verbose_rendering", "False", "--fast_debug_mode", "True", "--sh_degree", "0", "--lpips_weight", "0.0"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    assert (out / "saved_models" / "model_final.pth").exists()
+
+
 def test_render_entry_point(tmp_path):
     import importlib.util
 

@@ -17,7 +17,12 @@ from thre3d_atom.rendering.volumetric.utils.misc import compute_expected_density
 from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid  # noqa: E402
 from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelGridLocation, VoxelSize  # noqa: E402
 from thre3d_atom.utils.constants import NUM_COLOUR_CHANNELS  # noqa: E402
+from thre3d_atom.utils.cli_compat import accepted_options, report_unused  # noqa: E402
+from thre3d_atom.utils.logging import log  # noqa: E402
 from thre3d_atom.utils.misc import log_config_to_disk  # noqa: E402
+
+# options of the reference's script that this build has no use for (the dataset is cached on the GPU: no loader workers)
+COMPAT_ONLY = [("--num_workers", click.INT, 4, 1)]
 
 
 def density_activations(use_relu_field: bool, use_softplus_field: bool, grid_world_size):
@@ -32,7 +37,7 @@ def density_activations(use_relu_field: bool, use_softplus_field: bool, grid_wor
 @click.command()
 @click.option("-d", "--data_path", type=click.Path(file_okay=False, dir_okay=True), required=True)
 @click.option("-o", "--output_path", type=click.Path(file_okay=False, dir_okay=True), required=True)
-@click.option("--data_downsample_factor", type=click.FloatRange(min=1.0), default=2.0, show_default=True)
+@click.option("--data_downsample_factor", type=click.FloatRange(min=1.0), default=1.0, show_default=True)
 @click.option("--grid_dims", type=click.INT, nargs=3, default=(160, 160, 160), show_default=True)
 @click.option("--grid_location", type=click.FLOAT, nargs=3, default=(0.0, 0.0, 0.0), show_default=True)
 @click.option("--grid_world_size", type=click.FLOAT, nargs=3, default=(3.0, 3.0, 3.0), show_default=True)
@@ -44,24 +49,38 @@ def density_activations(use_relu_field: bool, use_softplus_field: bool, grid_wor
 @click.option("--train_num_samples_per_ray", type=click.INT, default=256, show_default=True)
 @click.option("--render_num_samples_per_ray", type=click.INT, default=1024, show_default=True)
 @click.option("--num_stages", type=click.INT, default=4, show_default=True)
-@click.option("--num_iterations_per_stage", type=click.INT, default=2000, show_default=True)
+@click.option("--num_iterations_per_stage", type=click.INT, default=500, show_default=True)
 @click.option("--scale_factor", type=click.FLOAT, default=2.0, show_default=True)
 @click.option("--learning_rate", type=click.FLOAT, default=0.03, show_default=True)
-@click.option("--lr_decay_steps_per_stage", type=click.INT, default=1000, show_default=True)
+@click.option("--lr_decay_steps_per_stage", type=click.INT, default=400, show_default=True)
 @click.option("--lr_decay_gamma_per_stage", type=click.FLOAT, default=0.1, show_default=True)
 @click.option("--stagewise_lr_decay_gamma", type=click.FLOAT, default=0.9, show_default=True)
 @click.option("--apply_diffuse_render_regularization", type=click.BOOL, default=True)
 @click.option("--optimized_sampling", type=click.BOOL, default=False, show_default=True)
 @click.option("--linear_disparity_sampling", type=click.BOOL, default=False, show_default=True)
 @click.option("--fast_debug_mode", type=click.BOOL, default=False, show_default=True)
+@click.option("--separate_train_test_folders", type=click.BOOL, default=True, show_default=True,
+              help="<data_path>/train + train_camera_params.json (else <data_path>/images + camera_params.json)")
+@click.option("--normalize_scene_scale", type=click.BOOL, default=False, show_default=True)
+@click.option("--parallel_rays_chunk_size", type=click.INT, default=32768, show_default=True)
+@click.option("--save_frequency", type=click.INT, default=250, show_default=True)
+@click.option("--test_frequency", type=click.INT, default=250, show_default=True)
+@click.option("--feedback_frequency", type=click.INT, default=100, show_default=True)
+@click.option("--summary_frequency", type=click.INT, default=50, show_default=True)
+@click.option("--verbose_rendering", type=click.BOOL, default=False, show_default=True)
+@click.option("--lpips_weight", type=click.FLOAT, default=0.0, show_default=True)
+@accepted_options(COMPAT_ONLY)
 def main(**kwargs) -> None:
     cfg = type("Config", (), kwargs)
     device = torch.device("cuda")
     data_path, output_path = Path(cfg.data_path), Path(cfg.output_path)
     log_config_to_disk(kwargs, output_path)
-    train_dir = data_path / "train" if (data_path / "train").is_dir() else data_path / "images"
-    params = data_path / ("train_camera_params.json" if (data_path / "train_camera_params.json").exists() else "camera_params.json")
-    dataset = PosedImagesDataset(train_dir, params, downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
+    report_unused(kwargs, COMPAT_ONLY, log)
+    separate = cfg.separate_train_test_folders and (data_path / "train").is_dir()
+    train_dir = data_path / "train" if separate else data_path / "images"
+    params = data_path / ("train_camera_params.json" if separate and (data_path / "train_camera_params.json").exists() else "camera_params.json")
+    dataset = PosedImagesDataset(train_dir, params, normalize_scene_scale=cfg.normalize_scene_scale,
+                                 downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
     densities = torch.empty((*cfg.grid_dims, 1), dtype=torch.float32, device=device).uniform_(-1.0, 1.0)
     num_sh = NUM_COLOUR_CHANNELS * ((cfg.sh_degree + 1) ** 2)
     features = torch.empty((*cfg.grid_dims, num_sh), dtype=torch.float32, device=device).uniform_(-1.0, 1.0)
@@ -71,13 +90,17 @@ def main(**kwargs) -> None:
     vol_mod = VolumetricModel(grid, render_sh_voxel_grid, SHVoxGridRenderConfig(
         num_samples_per_ray=cfg.train_num_samples_per_ray, camera_bounds=dataset.camera_bounds, white_bkgd=cfg.white_bkgd,
         render_num_samples_per_ray=cfg.render_num_samples_per_ray, optimized_sampling=cfg.optimized_sampling,
-        linear_disparity_sampling=cfg.linear_disparity_sampling), device=device)
+        linear_disparity_sampling=cfg.linear_disparity_sampling, parallel_rays_chunk_size=cfg.parallel_rays_chunk_size),
+        device=device)
     train_sh_vox_grid_vol_mod_with_posed_images(
         vol_mod, dataset, output_path, ray_batch_size=cfg.ray_batch_size, num_stages=cfg.num_stages,
         num_iterations_per_stage=cfg.num_iterations_per_stage, scale_factor=cfg.scale_factor,
         learning_rate=cfg.learning_rate, lr_decay_gamma_per_stage=cfg.lr_decay_gamma_per_stage,
         lr_decay_steps_per_stage=cfg.lr_decay_steps_per_stage, stagewise_lr_decay_gamma=cfg.stagewise_lr_decay_gamma,
-        apply_diffuse_render_regularization=cfg.apply_diffuse_render_regularization, fast_debug_mode=cfg.fast_debug_mode)
+        apply_diffuse_render_regularization=cfg.apply_diffuse_render_regularization, fast_debug_mode=cfg.fast_debug_mode,
+        save_freq=cfg.save_frequency, test_freq=cfg.test_frequency, feedback_freq=cfg.feedback_frequency,
+        summary_freq=cfg.summary_frequency, verbose_rendering=cfg.verbose_rendering, lpips_weight=cfg.lpips_weight,
+        num_workers=cfg.num_workers)
 
 
 if __name__ == "__main__":
