@@ -205,6 +205,17 @@ def test_datasets_on_disk_format_and_downsampling(tmp_path):
     half = ds.downsampled(2.0)
     assert half.images.shape == (3, 3, 6, 8) and half.camera_intrinsics == CameraIntrinsics(6, 8, 10.0)
     assert isinstance(half, InMemoryPosedImages)
+    # directional views (a direction prompt word per camera, reference datasets.py:41,85-88,331-335,387-390)
+    for i, word in enumerate(("front", "side", "back")):
+        params[f"r_{i}.png"]["dir"] = word
+    (tmp_path / "train_camera_params.json").write_text(json.dumps(params))
+    dd = PosedImagesDataset(img_dir, tmp_path / "train_camera_params.json", rgba_white_bkgd=True, directional=True)
+    img, pose, direction, idx = dd[2]
+    assert direction == "back" and idx == 2 and img.shape == (3, 12, 16)
+    assert PosedImagesDataset.extract_dir(dd.camera_parameters["r_1.png"]) == "side"
+    cam = PosedImagesDataset.extract_pose(dd.camera_parameters["r_1.png"])
+    assert cam.rotation.shape == (3, 3) and cam.translation.shape == (3, 1)
+    assert dd.get_config_dict()["rgba_white_bkgd"] is True and dd.get_config_dict()["downsample_factor"] == 1.0
 
 
 def test_product_never_imports_the_oracle():

@@ -39,7 +39,7 @@ STATE_DICT_NAMES = {"u_DENSITIES": "_densities", "u_FEATURES": "_features", "u_A
 # ---- *_camera_params.json -------------------------------------------------------------------------------
 CAMERA_JSON_KEYS = {
     "INTRINSIC": "intrinsic", "EXTRINSIC": "extrinsic", "BOUNDS": "bounds", "HEIGHT": "height", "WIDTH": "width",
-    "FOCAL": "focal", "ROTATION": "rotation", "TRANSLATION": "translation",
+    "FOCAL": "focal", "ROTATION": "rotation", "TRANSLATION": "translation", "DIRECTION": "dir",
 }
 
 

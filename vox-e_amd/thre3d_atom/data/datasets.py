@@ -8,7 +8,7 @@ Both expose what the trainers use: `camera_intrinsics`, `camera_bounds`,
 Image decoding is host I/O, outside the render hot path."""
 import json
 from pathlib import Path
-from typing import Tuple
+from typing import Any, Dict, Tuple
 
 import numpy as np
 import torch
@@ -16,9 +16,11 @@ import torch.nn.functional as F
 from torch import Tensor
 from torch.utils.data import Dataset
 
-from thre3d_atom.data.constants import BOUNDS, EXTRINSIC, FOCAL, HEIGHT, INTRINSIC, ROTATION, TRANSLATION, WIDTH
+from thre3d_atom.data.constants import (
+    BOUNDS, DIRECTION, EXTRINSIC, FOCAL, HEIGHT, INTRINSIC, ROTATION, TRANSLATION, WIDTH,
+)
 from thre3d_atom.utils.constants import NUM_COLOUR_CHANNELS
-from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics
+from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics, CameraPose
 
 
 class InMemoryPosedImages(Dataset):
@@ -59,8 +61,16 @@ class PosedImagesDataset(InMemoryPosedImages):
     Camera bounds are widened to (0.9 near, 1.1 far) like the reference (datasets.py:267-277)."""
 
     def __init__(self, images_dir: Path, camera_params_json: Path, image_data_range: Tuple[float, float] = (0.0, 1.0),
-                 normalize_scene_scale: bool = False, downsample_factor: float = 1.0, rgba_white_bkgd: bool = False):
+                 normalize_scene_scale: bool = False, downsample_factor: float = 1.0, rgba_white_bkgd: bool = False,
+                 directional: bool = False):
+        """directional: every view carries a direction prompt word (`"dir"` in its camera parameters; reference
+        datasets.py:41,85-88,331-335); items are then (image, pose, direction, index) like the reference's."""
         from PIL import Image
+
+        self.directional = bool(directional)
+        self._config = dict(images_dir=Path(images_dir), camera_params_json=Path(camera_params_json),
+                            image_data_range=image_data_range, normalize_scene_scale=normalize_scene_scale,
+                            downsample_factor=downsample_factor, rgba_white_bkgd=rgba_white_bkgd)
 
         images_dir = Path(images_dir)
         params = json.loads(Path(camera_params_json).read_text())
@@ -68,6 +78,8 @@ class PosedImagesDataset(InMemoryPosedImages):
         files = [p for p in files if p.name in params] or files
         if not files:
             raise FileNotFoundError(f"no images under {images_dir}")
+        self._camera_parameters = params
+        self.directions = [str(params[p.name][DIRECTION]) for p in files] if self.directional else None
         imgs, poses = [], []
         scale = 1.0
         if normalize_scene_scale:
@@ -95,3 +107,25 @@ class PosedImagesDataset(InMemoryPosedImages):
         if downsample_factor != 1.0:
             small = self.downsampled(downsample_factor)
             self.images, self.camera_intrinsics = small.images, small.camera_intrinsics
+
+    @property
+    def camera_parameters(self) -> Dict[str, Any]:
+        return self._camera_parameters
+
+    def get_config_dict(self) -> Dict[str, Any]:
+        return dict(self._config)
+
+    @staticmethod
+    def extract_pose(camera_params: Dict[str, Any]) -> CameraPose:
+        rotation = np.array(camera_params[EXTRINSIC][ROTATION], dtype=np.float32).reshape(3, 3)
+        translation = np.array(camera_params[EXTRINSIC][TRANSLATION], dtype=np.float32).reshape(3, 1)
+        return CameraPose(rotation=rotation, translation=translation)
+
+    @staticmethod
+    def extract_dir(camera_params: Dict[str, Any]) -> str:
+        return str(camera_params[DIRECTION])
+
+    def __getitem__(self, index: int):
+        if self.directional:
+            return self.images[index], self.poses[index], self.directions[index], index
+        return super().__getitem__(index)
