@@ -268,3 +268,20 @@ def test_cast_rays_indexed_equals_full_cast():
     o, d = vo.cast_rays_indexed(H, W, focal, poses, idx)
     assert np.array_equal(o, full_o[idx]) and np.array_equal(d, full_d[idx])
     assert len(g.files) > 0
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_sh_evaluation_host_helper_matches_reference(deg):
+    """thre3d_atom...spherical_harmonics.evaluate_spherical_harmonics (host helper, same name as the reference's) on
+    the reference's own evaluations (golden G8)"""
+    import os
+    import sys
+
+    import torch
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vox-e_amd"))
+    from thre3d_atom.rendering.volumetric.utils.spherical_harmonics import evaluate_spherical_harmonics
+
+    g = load_golden("render_shdeg.npz")
+    out = evaluate_spherical_harmonics(deg, torch.from_numpy(g[f"eval_deg{deg}_coeffs"]), torch.from_numpy(g[f"eval_deg{deg}_dirs"]))
+    np.testing.assert_allclose(out.numpy(), g[f"eval_deg{deg}_out"], rtol=0, atol=2e-6)

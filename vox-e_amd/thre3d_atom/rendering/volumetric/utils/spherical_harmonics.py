@@ -39,3 +39,13 @@ def sh_basis_torch(degree: int, viewdirs: Tensor) -> Tensor:
             C3[5] * z * (xx - yy), C3[6] * x * (xx - 3 * yy),
         ]
     return torch.stack(out, dim=-1)
+
+
+def evaluate_spherical_harmonics(degree: int, sh_coeffs: Tensor, viewdirs: Tensor) -> Tensor:
+    """Host helper with the reference's name and argument meaning (spherical_harmonics.py:64-132):
+    sh_coeffs [..., C, (degree+1)^2], unit viewdirs [..., 3] -> [..., C].  The renderer never calls it (the kernels
+    evaluate the basis per ray, voxe_device.hpp sh_basis); it exists for tools that bake or inspect SH grids."""
+    if sh_coeffs.shape[-1] < num_sh_coefficients(degree):
+        raise ValueError(f"degree {degree} needs {num_sh_coefficients(degree)} coefficients, got {sh_coeffs.shape[-1]}")
+    basis = sh_basis_torch(degree, viewdirs)                      # [..., n]
+    return (sh_coeffs[..., : basis.shape[-1]] * basis.unsqueeze(-2)).sum(dim=-1)
