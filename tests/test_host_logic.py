@@ -293,3 +293,44 @@ def test_entry_point_defaults_equal_the_reference():
             got = params[name].default
             got = tuple(got) if isinstance(want, tuple) else got
             assert got == want, (script, name, got, want)
+
+
+def test_nerf_blender_converter_round_trip(tmp_path):
+    """tools/convert_from_nerf_blender_dataset.py (reference tools/convert_from_nerf_blender_dataset.py:33-90): a tiny
+    NeRF-synthetic scene -> <split>_camera_params.json -> PosedImagesDataset gives back the poses, the focal length from
+    camera_angle_x and the widened [2, 6] bounds"""
+    import importlib.util
+    import json
+
+    from click.testing import CliRunner
+    from PIL import Image
+
+    from thre3d_atom.data.datasets import PosedImagesDataset
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+
+    src = tmp_path / "lego"
+    frames = []
+    (src / "train").mkdir(parents=True)
+    poses = []
+    for i in range(3):
+        pose = pose_spherical(50.0 * i, 25.0, 4.0311)
+        m = np.eye(4, dtype=np.float64)
+        m[:3, :3], m[:3, 3:] = pose.rotation.numpy(), pose.translation.numpy()
+        poses.append(m)
+        Image.fromarray((np.random.default_rng(i).random((10, 14, 3)) * 255).astype(np.uint8)).save(src / "train" / f"r_{i}.png")
+        frames.append({"file_path": f"./train/r_{i}", "rotation": 0.01, "transform_matrix": m.tolist()})
+    (src / "transforms_train.json").write_text(json.dumps({"camera_angle_x": 0.6911112, "frames": frames}))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("convert_cli", os.path.join(root, "tools", "convert_from_nerf_blender_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "converted"
+    res = CliRunner().invoke(mod.main, ["-d", str(src), "-o", str(out), "--link_images", "True"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    assert not (out / "val_camera_params.json").exists()            # absent splits are skipped
+    ds = PosedImagesDataset(out / "train", out / "train_camera_params.json")
+    assert len(ds) == 3 and ds.images.shape == (3, 3, 10, 14)
+    assert abs(ds.camera_intrinsics.focal - 0.5 * 14 / np.tan(0.5 * 0.6911112)) < 1e-4
+    assert abs(ds.camera_bounds.near - 1.8) < 1e-6 and abs(ds.camera_bounds.far - 6.6) < 1e-6
+    for i in range(3):
+        np.testing.assert_allclose(ds.poses[i].numpy(), poses[i][:3, :4].astype(np.float32), atol=1e-6)
