@@ -188,6 +188,40 @@ def test_train_entry_point_with_reference_style_options(tmp_path):
     assert (out / "saved_models" / "model_final.pth").exists()
 
 
+def test_attention_render_entry_point(tmp_path):
+    """render_sh_based_voxel_grid_attn.py: a model with an attention grid -> [colour | attention] stills + the video"""
+    import importlib.util
+
+    from click.testing import CliRunner
+    from PIL import Image
+
+    from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
+
+    vm = _sphere_model(side=16, samples=48)
+    grid = vm.thre3d_repr
+    ax = torch.linspace(-1.0, 1.0, 16, device=DEV)
+    attn = (4.0 * ax.view(16, 1, 1) + 0.0 * ax.view(1, 16, 1) + 0.0 * ax.view(1, 1, 16)).unsqueeze(-1).contiguous()
+    grid.add_attn_params(attn)                    # attention grows along x: the colour map must vary across the image
+    intr = CameraIntrinsics(40, 40, 0.5 * 40 / np.tan(0.5 * 0.6911112))
+    info = vm.get_save_info({CAMERA_BOUNDS: CameraBounds(1.8, 6.6), CAMERA_INTRINSICS: intr, HEMISPHERICAL_RADIUS: 4.0311})
+    torch.save(info, tmp_path / "model_attn.pth")
+    spec = importlib.util.spec_from_file_location("render_attn_cli", os.path.join(ROOT, "render_sh_based_voxel_grid_attn.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "frames"
+    res = CliRunner().invoke(mod.main, ["-i", str(tmp_path / "model_attn.pth"), "-o", str(out), "--num_frames", "3",
+                                        "--render_scale_factor", "1.0", "--overridden_num_samples_per_ray", "48",
+                                        "--load_attention", "True", "--sds_prompt", "a dog"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    stills = sorted(out.glob("frame_*.png"))
+    assert len(stills) == 2 and (out / "prompt.txt").read_text() == "a dog"
+    img = np.asarray(Image.open(stills[0]))
+    assert img.shape == (40, 80, 3)                                  # colour | attention side by side
+    right = img[:, 40:].reshape(-1, 3).astype(np.int32)
+    assert len(np.unique(right, axis=0)) > 20                        # a real colour-mapped attention image
+    assert np.allclose(mod.jet(np.array([0.0, 1.0])), [[0.0, 0.0, 0.5], [0.5, 0.0, 0.0]])
+
+
 def test_render_entry_point(tmp_path):
     import importlib.util
 
