@@ -228,7 +228,7 @@ def test_product_never_imports_the_oracle():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = glob.glob(os.path.join(root, "vox-e_amd", "**", "*.py"), recursive=True)
-    files += [os.path.join(root, n) for n in ("render_sh_based_voxel_grid.py", "render_sh_based_voxel_grid_attn.py", "edit_pretrained_relu_field.py",
+    files += [os.path.join(root, n) for n in ("render_sh_based_voxel_grid.py", "render_sh_based_voxel_grid_attn.py", "segment_attn_relu_field.py", "edit_pretrained_relu_field.py",
                                               "refine_edited_relu_field.py",
                                               "train_sh_based_voxel_grid_with_posed_images.py")]
     for path in files:

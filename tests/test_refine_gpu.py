@@ -202,3 +202,75 @@ def test_restore_outside_largest_component():
     few = model(torch.where(torch.from_numpy(largest)[..., None], 1.0, -1.0))
     assert restore_outside_largest_component(few, ref, k=10) == 1
     assert (few.thre3d_repr._densities.detach() == -0.25).all()
+
+
+def test_segment_entry_point(tmp_path):
+    """segment_attn_relu_field.py on checkpoints written to disk: edit / object attention grids with the hat lit up in
+    the edit one -> the saved model keeps the edited hat and is the reference field everywhere else"""
+    import importlib.util
+    import json
+    import os
+
+    from click.testing import CliRunner
+    from PIL import Image
+
+    from thre3d_atom.data.constants import BOUNDS, EXTRINSIC, FOCAL, HEIGHT, INTRINSIC, ROTATION, TRANSLATION, WIDTH
+    from thre3d_atom.modules.volumetric_model import create_volumetric_model_from_saved_model_attn
+    from thre3d_atom.thre3d_reprs.voxels import create_voxel_grid_from_saved_info_dict_attn
+    from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+
+    torch.manual_seed(0)
+    edited, reference, hat, body = _scene_models()
+    hat_d, body_d = hat.to(DEV), body.to(DEV)
+    intr = CameraIntrinsics(32, 32, 44.0)
+    extra = {CAMERA_BOUNDS: CameraBounds(1.8, 6.6), CAMERA_INTRINSICS: intr, HEMISPHERICAL_RADIUS: 4.0311}
+    vm_edit, vm_obj = copy.deepcopy(edited), copy.deepcopy(edited)
+    # "optimised" attention grids: the edit token lights up the hat, the object token the body
+    e = torch.full_like(vm_edit.thre3d_repr.attn.detach(), -4.0)
+    e[hat_d] = 3.0
+    o = torch.full_like(e, -4.0)
+    o[body_d] = 3.0
+    vm_edit.thre3d_repr.add_attn_params(e)
+    vm_obj.thre3d_repr.add_attn_params(o)
+    paths = {}
+    plain_ref, plain_sds = copy.deepcopy(reference), copy.deepcopy(edited)
+    for vm in (plain_ref, plain_sds):          # the reconstruction / SDS stages save fields without an attention grid
+        del vm.thre3d_repr.attn
+        vm.thre3d_repr.attn = None
+    for name, vm in (("ref", plain_ref), ("sds", plain_sds), ("edit", vm_edit), ("obj", vm_obj)):
+        paths[name] = tmp_path / f"{name}.pth"
+        torch.save(vm.get_save_info(extra), paths[name])
+    data = tmp_path / "data"
+    (data / "train").mkdir(parents=True)
+    params = {}
+    for i in range(2):
+        pose = pose_spherical(120.0 * i, 30.0, 4.0311)
+        Image.fromarray(np.zeros((32, 32, 3), np.uint8)).save(data / "train" / f"r_{i}.png")
+        params[f"r_{i}.png"] = {EXTRINSIC: {ROTATION: pose.rotation.numpy().tolist(), TRANSLATION: pose.translation.numpy().tolist()},
+                                INTRINSIC: {HEIGHT: 32, WIDTH: 32, FOCAL: 44.0, BOUNDS: [2.0, 6.0]}}
+    (data / "train_camera_params.json").write_text(json.dumps(params))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("segment_cli", os.path.join(root, "segment_attn_relu_field.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(mod.main, ["-d", str(data), "-ie", str(paths["edit"]), "-io", str(paths["obj"]), "-o", str(out),
+                                        "-r", str(paths["ref"]), "-i", str(paths["sds"]), "--edit_mask_thresh", "0.97",
+                                        "--num_obj_voxels_thresh", "400", "--min_num_edit_voxels", "10",
+                                        "--top_k_edit_thresh", "30", "--top_k_obj_thresh", "30", "--log_wandb", "False"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    assert (out / "training_logs" / "rendered_output" / "sds_refined_0.png").exists()
+    vm, saved_extra = create_volumetric_model_from_saved_model_attn(
+        out / "saved_models" / "model_final_refined.pth", create_voxel_grid_from_saved_info_dict_attn, device=DEV, load_attn=True)
+    assert abs(saved_extra[HEMISPHERICAL_RADIUS] - 4.0311) < 1e-3
+    keep = vm.thre3d_repr.attn.detach()[..., 0]
+    region = keep == 0
+    occupied = edited.thre3d_repr._densities.detach()[..., 0] > 0
+    cut = region & occupied
+    assert int(cut.sum()) > 0 and float((cut & hat_d).sum()) / float(cut.sum()) > 0.8
+    new_d, new_f = vm.thre3d_repr._densities.detach(), vm.thre3d_repr._features.detach()
+    ref_d, ref_f = reference.thre3d_repr._densities.detach(), reference.thre3d_repr._features.detach()
+    sds_d = edited.thre3d_repr._densities.detach()
+    assert torch.equal(new_d[~region], ref_d[~region]) and torch.equal(new_f[~region], ref_f[~region])
+    assert torch.equal(new_d[region], sds_d[region])

@@ -33,7 +33,8 @@ def options(path):
     return out
 if __name__ == "__main__":
     scripts = ["train_sh_based_voxel_grid_with_posed_images.py", "edit_pretrained_relu_field.py",
-               "refine_edited_relu_field.py", "render_sh_based_voxel_grid.py", "render_sh_based_voxel_grid_attn.py"]
+               "refine_edited_relu_field.py", "render_sh_based_voxel_grid.py", "render_sh_based_voxel_grid_attn.py",
+               "segment_attn_relu_field.py"]
     out = {f: options("/root/reference/" + f) for f in scripts}
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "cli_options.json")
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
