@@ -174,6 +174,15 @@ def test_train_entry_point_with_reference_style_options(tmp_path):
         params[f"r_{i}.png"] = {EXTRINSIC: {ROTATION: pose.rotation.cpu().numpy().tolist(), TRANSLATION: pose.translation.cpu().numpy().tolist()},
                                 INTRINSIC: {HEIGHT: 32, WIDTH: 32, FOCAL: float(intr.focal), BOUNDS: [2.0, 6.0]}}
     (data / "train_camera_params.json").write_text(json.dumps(params))
+    (data / "test").mkdir()
+    held_out = {}
+    for i in range(2):                             # a held-out split: evaluated at --test_frequency and at every stage end
+        pose = pose_spherical(45.0 + 180.0 * i, 40.0, 4.0311)
+        img = truth.render(pose, intr, perturb_sampled_points=False).colour.clamp(0, 1).cpu().numpy()
+        Image.fromarray((img * 255).astype(np.uint8)).save(data / "test" / f"t_{i}.png")
+        held_out[f"t_{i}.png"] = {EXTRINSIC: {ROTATION: pose.rotation.cpu().numpy().tolist(), TRANSLATION: pose.translation.cpu().numpy().tolist()},
+                                  INTRINSIC: {HEIGHT: 32, WIDTH: 32, FOCAL: float(intr.focal), BOUNDS: [2.0, 6.0]}}
+    (data / "test_camera_params.json").write_text(json.dumps(held_out))
     spec = importlib.util.spec_from_file_location("train_cli", os.path.join(ROOT, "train_sh_based_voxel_grid_with_posed_images.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
@@ -182,10 +191,14 @@ def test_train_entry_point_with_reference_style_options(tmp_path):
         "-d", str(data), "-o", str(out), "--grid_dims", "16", "16", "16", "--num_stages", "1", "--num_iterations_per_stage", "30",
         "--ray_batch_size", "1024", "--train_num_samples_per_ray", "48", "--render_num_samples_per_ray", "64",
         "--separate_train_test_folders", "True", "--normalize_scene_scale", "False", "--num_workers", "2",
-        "--save_frequency", "1000", "--test_frequency", "1000", "--feedback_frequency", "1000", "--summary_frequency", "10",
-        "--verbose_rendering", "False", "--fast_debug_mode", "True", "--sh_degree", "0", "--lpips_weight", "0.0"])
+        "--save_frequency", "1000", "--test_frequency", "1000", "--feedback_frequency", "20", "--summary_frequency", "10",
+        "--verbose_rendering", "False", "--fast_debug_mode", "False", "--sh_degree", "0", "--lpips_weight", "0.0"])
     assert res.exit_code == 0, (res.output, res.exception)
     assert (out / "saved_models" / "model_final.pth").exists()
+    stills = sorted(p.name for p in (out / "training_logs" / "rendered_output").glob("default_*.png"))
+    assert stills == ["default_1.png", "default_20.png", "default_30.png"], stills     # first, every 20th, last iteration
+    with Image.open(out / "training_logs" / "rendered_output" / "default_30.png") as still:
+        assert still.size == (64, 32)                                                  # [specular | diffuse]
 
 
 def test_attention_render_entry_point(tmp_path):

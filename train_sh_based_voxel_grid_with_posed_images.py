@@ -81,6 +81,11 @@ def main(**kwargs) -> None:
     params = data_path / ("train_camera_params.json" if separate and (data_path / "train_camera_params.json").exists() else "camera_params.json")
     dataset = PosedImagesDataset(train_dir, params, normalize_scene_scale=cfg.normalize_scene_scale,
                                  downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
+    test_dataset = None
+    if separate and (data_path / "test").is_dir() and (data_path / "test_camera_params.json").exists():
+        test_dataset = PosedImagesDataset(data_path / "test", data_path / "test_camera_params.json",
+                                          normalize_scene_scale=cfg.normalize_scene_scale,
+                                          downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
     densities = torch.empty((*cfg.grid_dims, 1), dtype=torch.float32, device=device).uniform_(-1.0, 1.0)
     num_sh = NUM_COLOUR_CHANNELS * ((cfg.sh_degree + 1) ** 2)
     features = torch.empty((*cfg.grid_dims, num_sh), dtype=torch.float32, device=device).uniform_(-1.0, 1.0)
@@ -93,7 +98,7 @@ def main(**kwargs) -> None:
         linear_disparity_sampling=cfg.linear_disparity_sampling, parallel_rays_chunk_size=cfg.parallel_rays_chunk_size),
         device=device)
     train_sh_vox_grid_vol_mod_with_posed_images(
-        vol_mod, dataset, output_path, ray_batch_size=cfg.ray_batch_size, num_stages=cfg.num_stages,
+        vol_mod, dataset, output_path, test_dataset=test_dataset, ray_batch_size=cfg.ray_batch_size, num_stages=cfg.num_stages,
         num_iterations_per_stage=cfg.num_iterations_per_stage, scale_factor=cfg.scale_factor,
         learning_rate=cfg.learning_rate, lr_decay_gamma_per_stage=cfg.lr_decay_gamma_per_stage,
         lr_decay_steps_per_stage=cfg.lr_decay_steps_per_stage, stagewise_lr_decay_gamma=cfg.stagewise_lr_decay_gamma,

@@ -15,12 +15,13 @@ import torch
 from torch import Tensor
 
 from thre3d_atom.modules.optim import VoxeAdam
+from thre3d_atom.modules.testers import test_sh_vox_grid_vol_mod_with_posed_images
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import sample_random_rays_and_pixels_from_cameras
 from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid
 from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, scale_voxel_grid_with_required_output_size
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
-from thre3d_atom.utils.imaging_utils import CameraPose
+from thre3d_atom.utils.imaging_utils import CameraPose, to8b
 from thre3d_atom.utils.logging import log
 from thre3d_atom.utils.metric_utils import mse2psnr
 from thre3d_atom.utils.misc import compute_thre3d_grid_sizes
@@ -71,6 +72,23 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
 
     extra_info = {CAMERA_BOUNDS: train_dataset.camera_bounds, CAMERA_INTRINSICS: train_dataset.camera_intrinsics,
                   HEMISPHERICAL_RADIUS: train_dataset.get_hemispherical_radius_estimate()}
+    # rendered feedback (trainers.py:164-175,409-432 of the reference): the given pose, else the first held-out / training
+    # view; stills go to training_logs/rendered_output as [specular | diffuse] PNGs
+    render_dir = output_dir / "training_logs" / "rendered_output"
+    if not fast_debug_mode:
+        render_dir.mkdir(exist_ok=True, parents=True)
+    if render_feedback_pose is None:
+        first = (test_dataset if test_dataset is not None else train_dataset).poses[0].to(device)
+        render_feedback_pose = CameraPose(rotation=first[:, :3], translation=first[:, 3:])
+
+    def rendered_feedback(step: int) -> None:
+        from PIL import Image
+
+        intr_full = train_dataset.camera_intrinsics
+        views = [vol_mod.render(render_feedback_pose, intr_full, gpu_render=True, verbose=verbose_rendering,
+                                render_diffuse=diffuse).colour for diffuse in (False, True)]
+        Image.fromarray(to8b(torch.cat(views, dim=1).cpu().numpy())).save(render_dir / f"default_{step}.png")
+
     global_step, trained = 0, 0.0
     gen = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
     for stage in range(1, num_stages + 1):
@@ -104,6 +122,13 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
                          f"loss: {float(loss.detach()): .3f} psnr: {float(psnr): .3f}")
             if it % lr_decay_steps_per_stage == 0:
                 scheduler.step()
+            last = it == num_iterations_per_stage
+            if not fast_debug_mode and (global_step % feedback_freq == 0 or it == 1 or last):
+                log.info(f"TIME CHECK: time spent actually training till now: {trained:.1f} s")
+                rendered_feedback(global_step)
+            if test_dataset is not None and not fast_debug_mode and (global_step % test_freq == 0 or last):
+                test_sh_vox_grid_vol_mod_with_posed_images(vol_mod, test_dataset, parallel_rays_chunk_size=ray_batch_size,
+                                                           global_step=global_step)
             if it % save_freq == 0 and not fast_debug_mode:
                 torch.save(vol_mod.get_save_info(extra_info), model_dir / f"model_stage_{stage}_iter_{it}.pth")
         if stage != num_stages:
