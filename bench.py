@@ -32,7 +32,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PRE_WARM_STEPS = 20    # untimed clock-settling steps before the W warm-up steps
+PRE_WARM_STEPS = int(os.environ.get("VOXE_BENCH_PRE_WARM", "20"))   # untimed clock-settling steps before the W warm-up steps
 
 
 def parse():
@@ -73,15 +73,22 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # VOXE_BENCH_BACKEND=gloo: bring-up aid for boxes with fewer GPUs than ranks -- the ranks share the visible GPUs and
+    # exchange through gloo (host staging); it exercises the N > 1 code with the real kernels, it is NOT a measurement
+    backend = os.environ.get("VOXE_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1 or os.environ.get("VOXE_BENCH_FORCE_DIST") == "1":  # FORCE: exercise the RCCL path on one GPU
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     G, HW, S = args.grid, args.image, args.samples
     dens_cpu, feat_cpu = random_grid(G) if args.scene == "random" else sphere_grid(G)
@@ -349,7 +356,7 @@ def main():
                             f"{'' if args.no_adam else (' + Adam (fused grid step)' if fused else ' + Adam')}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
                 "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
-                "replicas_consistent": replicas_consistent,
+                "replicas_consistent": replicas_consistent, "backend": (backend if dist is not None else None),
                 "exchange_autotune_ms": (opt.tuned_ms if fused else None),
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
                 "untimed_steps_before_timing": PRE_WARM_STEPS + args.warmup,

@@ -1,0 +1,42 @@
+"""bench.py with TWO ranks on the one visible GPU (VOXE_BENCH_BACKEND=gloo: the ranks share the device and exchange
+through host staging): the N > 1 code path -- x-slab reduce-scatter / all-to-all / all-reduce of the workspace gradient
+region, the sharded fused Adam, the all-gather of the packed grid, autotune -- runs with the real kernels and must leave
+every rank with the same packed grid.  Not a measurement (gloo), a correctness run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("exchange,expect", [("reduce-scatter", "reduce-scatter + sharded step"), ("all-to-all", "all-to-all + local sum"),
+                                             ("all-reduce", "all-reduce + replicated step"), ("auto", "")])
+def test_two_rank_bench_on_one_gpu(exchange, expect):
+    env = dict(os.environ, VOXE_BENCH_BACKEND="gloo", VOXE_GRAD_EXCHANGE=exchange, VOXE_BENCH_PRE_WARM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--grid", "32", "--image", "96", "--samples", "64"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.strip().splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["replicas_consistent"] is True and cfg["backend"] == "gloo" and cfg["optimizer"] == "fused"
+    assert cfg["grad_exchange"].startswith(expect)
+    assert cfg["rays_per_gpu_per_step"] == 96 * 96
+    if exchange == "auto":
+        assert set(cfg["exchange_autotune_ms"]) == {"reduce-scatter", "all-to-all", "all-reduce"}
