@@ -190,6 +190,15 @@ class ShardedGridAdam:
         _, world = world_info()
         return world > 1 or (self.exercise_collectives and dist.is_initialized())
 
+    def _host_staged(self) -> bool:
+        """device tensors over a backend that stages through the host (gloo bring-up runs): such transfers are not
+        ordered with the compute stream, so the exchange is fenced by device synchronisations (RCCL is stream-ordered)"""
+        return self.densities.is_cuda and dist.is_initialized() and dist.get_backend() != "nccl"
+
+    def _fence(self) -> None:
+        if self._host_staged():
+            torch.cuda.synchronize(self.densities.device)
+
     def _run(self, workspace, grad_layout: int, exchange: str, step_no: int) -> str:
         """one exchange + optimiser step; returns the name of what ran"""
         rank, world = world_info()
@@ -202,11 +211,14 @@ class ShardedGridAdam:
         region = self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace)
         slab = self._slab(grad_layout)
         if slab is None or exchange == "all-reduce":
+            self._fence()
             dist.all_reduce(region)
+            self._fence()
             self.ops.grid_adam_step_(*args, **kw)
             return self._MODE_NAMES["all-reduce"]
         x0, x1, g_per, p_per = slab
         mine = region[rank * g_per: (rank + 1) * g_per]
+        self._fence()
         if exchange == "all-to-all":
             if self._recv is None or self._recv.numel() != world * g_per:
                 self._recv = torch.empty(world * g_per, dtype=region.dtype, device=region.device)
@@ -217,12 +229,14 @@ class ShardedGridAdam:
                 self._shard = torch.empty(g_per, dtype=region.dtype, device=region.device)
             dist.reduce_scatter_tensor(self._shard, region[: world * g_per])
             mine.copy_(self._shard)
+        self._fence()
         # the step reads (and clears) the gradient in place: the summed slab is where the kernel expects it; clear what
         # this rank's own backward left in the other slabs
         region[: rank * g_per].zero_()
         region[(rank + 1) * g_per:].zero_()
         self.ops.grid_adam_step_(*args, x_range=(x0, x1), **kw)
         packed = self.ops.workspace_packed_view(self.spec, self.densities, self.features, workspace)
+        self._fence()
         if exchange == "all-to-all":
             # the all-gather as direct sends too: this rank's packed slab to every peer, theirs into place
             if world > 1:
@@ -234,6 +248,7 @@ class ShardedGridAdam:
                     req.wait()
         else:
             dist.all_gather_into_tensor(packed, packed[rank * p_per: (rank + 1) * p_per])
+        self._fence()
         self._sharded_ran = True
         return self._MODE_NAMES[exchange]
 
