@@ -10,7 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, _p)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 from synth import FAR, NEAR, RADIUS, focal_for, random_grid, synth_pose_angles  # noqa: E402
