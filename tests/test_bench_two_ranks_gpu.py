@@ -62,3 +62,17 @@ def test_two_ranks_equal_one_process(exchange):
         # Adam's first steps turn the rounding noise of near-zero gradients into +-lr moves: measure against the movement
         # (observed: features 3e-7, densities 3e-4 for a movement of 5e-2)
         assert r["rel_densities"] < 0.05 * r["moved"] and r["rel_features"] < 0.05 * r["moved"], r
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sds_loop_equals_one_process():
+    """the ray-sharded SDS edit loop (row bands per rank, all-gathered image, replicated guidance, one gradient
+    all-reduce) with 2 ranks vs the same 12 iterations in one process"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "two_rank_sds_worker.py")]
+    res = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-2500:]
+    line = [l for l in res.stdout.strip().splitlines() if l.startswith("{")][-1]
+    for r in json.loads(line)["ranks"]:
+        assert r["moved"] > 1e-3
+        assert r["rel_densities"] < 0.05 * r["moved"] and r["rel_features"] < 0.05 * r["moved"], r
