@@ -32,6 +32,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (MI355X_MICROARCH.md); the sustained clock under this load is lower
+# Same-host factor between the CPU oracle (kind "port") and the reference's PyTorch CPU path, measured in the 8-vCPU build
+# container: oracle 50.5 k rays/s vs reference 5.7 k rays/s at 160^3, 400x400, fwd+bwd, 8 threads
+ORACLE_VS_REFERENCE_400 = 8.9
+ORACLE_VS_REFERENCE_100 = 2.6
 PRE_WARM_STEPS = int(os.environ.get("VOXE_BENCH_PRE_WARM", "20"))   # untimed clock-settling steps before the W warm-up steps
 
 
@@ -233,32 +238,68 @@ def main():
     bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
     bytes_bwd = s_in_total * 256 + R * (24 + 12 + 20)
     if ms_bwd >= ms_fwd:
-        bwd_name = "render_bwd_tile_kernel<3,true,true>" if args.ray_order == "image" else "render_bwd_packed_scatter_kernel<3,true,true>"
+        bwd_name = "render_bwd_tile_kernel<3,1,1,true,true,0,8>" if args.ray_order == "image" else "render_bwd_packed_scatter_kernel<3,1,1,true,true>"
         kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
         kname, kbytes, kms = "render_fwd_seg_kernel<3,1,1>", bytes_fwd, ms_fwd
     achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    # HBM traffic of that kernel: PMC counters cannot be read from inside this process; they are collected by
-    # tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over THIS script) and committed
-    # as profiles/*_pmc_summary.json.  Only reported for the configuration they were measured on.
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    # Physical side of the picture (PMC counters cannot be read from inside this process; they are collected by
+    # tools/gpu_pmc.sh -- rocprofv3 --pmc in separate passes over THIS script -- and committed as
+    # profiles/rNN_pmc_summary.json; only reported for the configuration they were measured on):
+    #   traffic          HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md, HBM section:
+    #                    FETCH_SIZE tallies 128-B requests at 64 B on gfx950)
+    #   compulsory_bytes read the grid once + write the gradient once = 2 * G^3 * 4 ch * 4 B (131 MB at 160^3)
+    #   valu_issue_frac  SQ_INSTS_VALU * 4 clk / (1024 SIMDs * clk_hz * launch time): share of the launch the SIMDs'
+    #                    VALU issue ports are busy (a wave64 f32 instruction occupies its SIMD for 4 cycles)
+    #   lds_issue_frac   SQ_LDS_IDX_ACTIVE / (256 CUs * clk_hz * launch time): share the LDS pipelines are busy
+    # The kernel is bound by those two issue rates, not by HBM: `frac` (SURVEY.md 8(d)'s requested-bytes convention) can
+    # exceed 1 because corner fetches shared by neighbouring rays are served on chip; `binding` names the ceiling that
+    # actually limits the kernel and `binding_frac` its utilisation -- none of the physical fractions can exceed 1.
+    traffic, traffic_src, physical = None, None, None
     default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, args.ray_order) == (160, 400, 256, "random", 0.0, False, 3, "image")
-    if default_cfg and os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path))["kernels"]
-        key = "voxe::render_bwd_tile_kernel<3, true, true>" if ms_bwd >= ms_fwd else "voxe::render_fwd_seg_kernel<3, 1, 1>"
-        if key in pmc and "FETCH_SIZE" in pmc[key] and "WRITE_SIZE" in pmc[key]:
-            # KiB -> bytes; FETCH_SIZE counts 64 B per 128 B request on gfx950 (MI355X_MICROARCH.md, HBM section)
-            traffic = int((2.0 * pmc[key]["FETCH_SIZE"] + pmc[key]["WRITE_SIZE"]) * 1024)
-            traffic_src = "profiles/r01_pmc_summary.json (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB)"
+    pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
+    if default_cfg and pmc_files:
+        pmc_rel = os.path.join("profiles", pmc_files[-1])
+        pmc = json.load(open(os.path.join(ROOT, pmc_rel)))["kernels"]
+        prefix = "voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0," if ms_bwd >= ms_fwd else "voxe::render_fwd_seg_kernel<3, 1, 1>"
+        # (the backward's last template argument is the LDS window width; 400x400 at 160^3 runs the 8-wide one)
+        keys = [k for k in pmc if k.startswith(prefix) and (ms_bwd < ms_fwd or k.rstrip(">").endswith(" 8"))]
+        cnt = pmc[keys[0]] if keys else {}
+        if "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
+            traffic = int((2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"]) * 1024)
+            traffic_src = f"{pmc_rel} (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB), kernel {keys[0]}"
+        if "SQ_INSTS_VALU" in cnt and "SQ_LDS_IDX_ACTIVE" in cnt and kms > 0:
+            compulsory = 2 * nvox * 4 * 4
+            valu = cnt["SQ_INSTS_VALU"] * 4.0 / (1024 * SHADER_CLOCK_HZ * kms * 1e-3)
+            lds = cnt["SQ_LDS_IDX_ACTIVE"] / (256 * SHADER_CLOCK_HZ * kms * 1e-3)
+            hbm = traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+            ceilings = {"valu_issue": valu, "lds_issue": lds}
+            if hbm is not None:
+                ceilings["hbm"] = hbm
+            binding = max(ceilings, key=ceilings.get)
+            physical = {
+                "valu_issue_frac": round(valu, 4), "lds_issue_frac": round(lds, 4),
+                "hbm_frac_measured": round(hbm, 4) if hbm is not None else None,
+                "compulsory_bytes": int(compulsory),
+                "traffic_over_compulsory": round(traffic / compulsory, 2) if traffic else None,
+                "binding": binding, "binding_frac": round(ceilings[binding], 4),
+                "clock_hz_assumed": SHADER_CLOCK_HZ,
+                "counters": {k: cnt[k] for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+                                                 "FETCH_SIZE", "WRITE_SIZE") if k in cnt},
+                "note": "counter values are per launch from the committed PMC summary, the launch time is this run's "
+                        "(HIP events); fractions are of the 2.4 GHz peak clock, i.e. lower bounds on the utilisation at the "
+                        "sustained clock",
+            }
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kname, "alg_bytes_per_launch": int(kbytes), "launch_ms": round(kms, 4),
-        # `achieved` follows SURVEY.md 8(d)'s REQUESTED-bytes model (every trilinear corner fetch / scatter counted);
-        # neighbouring rays share corners and the kernels serve that reuse from L1 / L2 / the LDS gradient window, so
-        # it can exceed the HBM peak -- the HBM bytes actually moved are `traffic` (PMC), i.e. `hbm_measured_gbs`
+        # `achieved` / `frac` follow SURVEY.md 8(d)'s REQUESTED-bytes model (every trilinear corner fetch / scatter
+        # counted); they are a throughput figure in HBM units, not a physical utilisation -- see `physical`
+        "frac_is": "requested-bytes convention of SURVEY.md 8(d) (can exceed 1: corner fetches shared by neighbouring rays "
+                   "are served from L1 / L2 / the LDS gradient window); the physical ceilings are in `physical`",
         "hbm_measured_gbs": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None),
+        "physical": physical,
         "phases_ms": {"pack": round(prof["ms_pack"] / max(prof["n_pack"], 1), 4), "fwd": round(ms_fwd, 4),
                       "memset": round(prof["ms_memset"] / max(prof["n_memset"], 1), 4), "bwd": round(ms_bwd, 4),
                       "unpack": round(prof["ms_unpack"] / max(prof["n_unpack"], 1), 4)},
@@ -339,6 +380,11 @@ def main():
         threads = vo.num_threads()
         cpu_baseline = {
             "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+            # the port is FASTER than the reference's own CPU path: on the same 8 vCPUs (build container) it renders
+            # 8.9x the reference PyTorch's rays/s at 400x400 and 2.6x at 100x100, so the reference
+            # on these host cores would be about value / vs_reference_factor
+            "vs_reference_factor": ORACLE_VS_REFERENCE_400 if hw >= 256 else ORACLE_VS_REFERENCE_100,
+            "reference_equivalent_rays_per_s": round(hw * hw / dt / (ORACLE_VS_REFERENCE_400 if hw >= 256 else ORACLE_VS_REFERENCE_100), 1),
             "sample": f"{hw}x{hw} rays of camera {args.camera} (same {G}^3 grid, S={S}, jitter on), 1 forward + 1 backward "
                       f"of oracle/voxe_cpu.c with OpenMP: {dt:.1f} s wall x {threads} threads = {dt * threads:.0f} core-seconds",
         }

@@ -1,0 +1,230 @@
+"""BASELINE.json `configs` at their FULL sizes on the GPU, every one against the CPU oracle (not against another HIP
+kernel): the 400x400 backward over all rays (configs[1] / headline), the reconstruction loop's 32768-random-ray batch
+over 8 cameras through the unordered-ray backward (configs[1], thre3d_atom/modules/trainers.py:288-351), the 256^3 grid
+with an 800x800 camera (configs[4], one rank's share) and the attention render of the refinement loop at 160^3 / 266x266
+(configs[3], thre3d_atom/modules/attn_grid_trainer.py:335-378).  Tolerances: forward 1e-5 abs (colour / acc), gradients
+1e-4 rel-L2 (north_star: "within a stated float tolerance"; index math is bit exact and checked on a probe)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+from synth import FAR, NEAR, RADIUS, focal_for, random_grid, sphere_grid, synth_pose_angles
+from voxe_hip import abi
+from voxe_hip.desc import make_render_cfg
+
+from oracle import voxe_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import gpu_helpers as gh
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+
+AABB = [(-1.5, 1.5)] * 3
+S = 256
+GRAD_TOL = 1e-4
+FWD_ATOL = 1e-5
+
+
+def _grid(side=160, kind="random"):
+    dens, feat = random_grid(side) if kind == "random" else sphere_grid(side)
+    return vo.Grid(dens.numpy(), feat.numpy(), AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+
+
+def _pose(i, n=100):
+    yaw, pitch = synth_pose_angles(i, n)
+    return pose_spherical(yaw, pitch, RADIUS)
+
+
+def _rays(hw, i=3, n=100):
+    pose = _pose(i, n)
+    return vo.cast_rays(hw, hw, focal_for(hw), pose.rotation.numpy(), pose.translation.numpy())
+
+
+def _check_forward(out, ref):
+    np.testing.assert_allclose(out["colour"], ref["colour"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["acc"], ref["acc"], rtol=0, atol=FWD_ATOL)
+    np.testing.assert_allclose(out["depth"], ref["depth"], rtol=1e-5, atol=FWD_ATOL)
+
+
+# ---- configs[1] headline: 160^3, one 400x400 camera, every ray ---------------------------------------------------------
+@pytest.mark.parametrize("kind,cam,jitter", [("random", 3, True), ("sphere", 11, False), ("random", 58, False)])
+def test_cfg1_400x400_forward_backward_all_rays_vs_oracle(kind, cam, jitter):
+    """the bench workload itself (camera 3, in-kernel jitter on) and two more cameras: all 160 000 rays, forward
+    outputs and both gradients against the oracle; upstream gradients on colour, depth and accumulated weight"""
+    grid = _grid(160, kind)
+    o, d = _rays(400, cam)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=jitter, white_bkgd=True, seed=42, rng_offset=7)
+    rng = (42, 7)
+    _check_forward(gh.hip_forward(grid, cfg, o, d, rng=rng, image_width=400), vo.render_fwd(grid, cfg, o, d))
+    r = np.random.default_rng(100 + cam)
+    gc = r.standard_normal((o.shape[0], 3)).astype(np.float32)
+    gdep = (0.1 * r.standard_normal(o.shape[0])).astype(np.float32)
+    gacc = (0.1 * r.standard_normal(o.shape[0])).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, g_acc=gacc, rng=rng, image_width=400)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, d_acc=gacc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+    # voxels whose oracle gradient is exactly zero (no ray near them, or a float underflow of a vanishing density
+    # derivative) hold nothing but such underflow-sized values: nothing leaks out of the LDS window's flush
+    untouched = (rd == 0) & (rf == 0).all(axis=-1, keepdims=True)
+    assert np.abs(gd[untouched]).max(initial=0.0) <= 1e-9 * np.abs(rd).max()
+
+
+# ---- configs[1] training batch: 32768 random rays over 8 of 100 cameras, specular + diffuse --------------------------
+@pytest.mark.parametrize("order", ["draw", "memory"])
+def test_cfg2_random_ray_batch_vs_oracle(order):
+    """trainers.py:288-351: cast 8 cameras @ 400x400, collate, random subset of 32768 rays, render specular and
+    `render_diffuse=True` (fresh jitter each), L1 of both against the target pixels, one backward.  The batch is an
+    unordered ray list (image_width = 0), i.e. the random-batch backward of the product; `memory` = the batch sorted by
+    (camera, row, column) as `sample_random_rays_and_pixels_from_cameras(memory_order=True)` hands it over."""
+    grid = _grid(160, "random")
+    hw, ncam, B = 400, 8, 32768
+    cams = np.random.default_rng(0).choice(100, ncam, replace=False)
+    poses = np.stack([np.concatenate([_pose(int(i)).rotation.numpy(), _pose(int(i)).translation.numpy()], axis=-1) for i in cams])
+    subset = vo.random_subset(ncam * hw * hw, B, 42, 3)
+    assert len(np.unique(subset)) == B
+    if order == "memory":
+        subset = np.sort(subset)
+    o, d = vo.cast_rays_indexed(hw, hw, focal_for(hw), poses, subset)
+    # the product's indexed ray cast == the oracle's, bit for bit (a2)
+    from voxe_hip import ops
+    po, pd = ops.cast_rays_indexed(hw, hw, focal_for(hw), gh.t(poses.astype(np.float32)), gh.t(subset))
+    np.testing.assert_array_equal(gh.n(po), o)
+    np.testing.assert_array_equal(gh.n(pd), d)
+    pix = np.random.default_rng(1).random((B, 3)).astype(np.float32)
+    gd_sum = gf_sum = rd_sum = rf_sum = 0.0
+    for offset, diffuse in ((1, False), (2, True)):
+        cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, render_diffuse=diffuse, seed=42, rng_offset=offset)
+        ref = vo.render_fwd(grid, cfg, o, d)
+        _check_forward(gh.hip_forward(grid, cfg, o, d, rng=(42, offset)), ref)
+        # d(L1 mean)/d colour from the oracle's colours, fed to both sides (a sign taken from colours that differ by
+        # 1e-7 could flip for a pixel that sits exactly on its target)
+        gc = (np.sign(ref["colour"] - pix) / pix.size).astype(np.float32)
+        gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, offset))
+        rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+        assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (diffuse, rel_l2(gd, rd), rel_l2(gf, rf))
+        gd_sum, gf_sum, rd_sum, rf_sum = gd_sum + gd, gf_sum + gf, rd_sum + rd, rf_sum + rf
+    assert rel_l2(gd_sum, rd_sum) < GRAD_TOL and rel_l2(gf_sum, rf_sum) < GRAD_TOL
+
+
+def test_cfg2_trainer_batch_through_the_model_api():
+    """the same batch through the product's own loop body (VolumetricModel.render_rays twice + torch L1 + autograd):
+    the .grad the optimiser sees equals the oracle's gradient of that loss"""
+    from thre3d_atom.modules.volumetric_model import VolumetricModel
+    from thre3d_atom.rendering.volumetric.render_interface import Rays
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelSize
+    from thre3d_atom.utils.imaging_utils import CameraBounds
+
+    G, hw, B = 160, 400, 32768
+    dens, feat = random_grid(G)
+    vg = VoxelGrid(dens, feat, VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=100.0 / 3.0, tunable=True)
+    vm = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(S, CameraBounds(NEAR, FAR), white_bkgd=True),
+                         device=gh.DEV)
+    poses = np.stack([np.concatenate([_pose(i).rotation.numpy(), _pose(i).translation.numpy()], axis=-1) for i in range(8)])
+    subset = vo.random_subset(8 * hw * hw, B, 5, 0)
+    o, d = vo.cast_rays_indexed(hw, hw, focal_for(hw), poses, subset)
+    pix = np.random.default_rng(2).random((B, 3)).astype(np.float32)
+    rays = Rays(gh.t(o), gh.t(d))
+    # un-jittered so that the oracle can replay the two renders without knowing the product's RNG offsets
+    spec = vm.render_rays(rays, perturb_sampled_points=False).colour
+    diff = vm.render_rays(rays, perturb_sampled_points=False, render_diffuse=True).colour
+    loss = torch.nn.functional.l1_loss(spec, gh.t(pix)) + torch.nn.functional.l1_loss(diff, gh.t(pix))
+    loss.backward()
+    torch.cuda.synchronize()
+    grid = vo.Grid(dens.numpy(), feat.numpy(), AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    rd = rf = 0.0
+    ref_loss = 0.0
+    for colours, diffuse in ((spec, False), (diff, True)):
+        cfg = make_render_cfg(S, NEAR, FAR, white_bkgd=True, render_diffuse=diffuse)
+        ref = vo.render_fwd(grid, cfg, o, d)
+        np.testing.assert_allclose(gh.n(colours), ref["colour"], rtol=0, atol=FWD_ATOL)
+        ref_loss += float(np.abs(ref["colour"].astype(np.float64) - pix).mean())
+        # the sign pattern the product's autograd used (its own colours)
+        gc = (np.sign(gh.n(colours) - pix) / pix.size).astype(np.float32)
+        a, b = vo.render_bwd(grid, cfg, o, d, gc)
+        rd, rf = rd + a, rf + b
+    assert abs(float(loss) - ref_loss) < 1e-6
+    gd = gh.n(vm.thre3d_repr._densities.grad if hasattr(vm.thre3d_repr, "_densities") else vm.thre3d_repr.densities.grad)
+    gf = gh.n(vm.thre3d_repr._features.grad if hasattr(vm.thre3d_repr, "_features") else vm.thre3d_repr.features.grad)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+# ---- configs[4]: 256^3 grid, 800x800 cameras (one rank's camera of the 8-way job) ---------------------------------------
+@pytest.fixture(scope="module")
+def grid256():
+    return _grid(256, "random")
+
+
+def test_cfg5_256_grid_800x800_forward_vs_oracle(grid256):
+    o, d = _rays(800, i=17, n=200)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=9, rng_offset=4)
+    out = gh.hip_forward(grid256, cfg, o, d, rng=(9, 4), image_width=800)
+    _check_forward(out, vo.render_fwd(grid256, cfg, o, d))          # all 640 000 rays
+    sel = np.random.default_rng(3).choice(o.shape[0], 400, replace=False)
+    pr, po = gh.hip_probe(grid256, cfg, o[sel], d[sel], rng=(9, 4)), vo.sample_probe(grid256, cfg, o[sel], d[sel])
+    np.testing.assert_array_equal(pr["idx"], po["idx"])            # voxel indices and inside masks: bit exact
+    np.testing.assert_array_equal(pr["inside"], po["inside"])
+    np.testing.assert_array_equal(pr["z"], po["z"])                # sample depths incl. the in-kernel jitter stream
+
+
+def test_cfg5_256_grid_800x800_backward_vs_oracle(grid256):
+    o, d = _rays(800, i=101, n=200)
+    cfg = make_render_cfg(S, NEAR, FAR, white_bkgd=True)
+    gc = np.random.default_rng(6).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid256, cfg, o, d, gc, image_width=800)
+    rd, rf = vo.render_bwd(grid256, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+def test_cfg5_row_bands_of_8_ranks_sum_to_the_whole_image(grid256):
+    """the 8-way job shards an 800x800 camera into row bands (thre3d_atom/modules/parallel.py); the sum of the 8 band
+    gradients (what the all-reduce forms) equals the oracle's whole-image gradient"""
+    o, d = _rays(800, i=33, n=200)
+    cfg = make_render_cfg(S, NEAR, FAR, white_bkgd=True)
+    gc = np.random.default_rng(8).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd = gf = 0.0
+    for rank in range(8):
+        lo, hi = rank * 100 * 800, (rank + 1) * 100 * 800
+        a, b = gh.hip_backward(grid256, cfg, o[lo:hi], d[lo:hi], gc[lo:hi], image_width=800)
+        gd, gf = gd + a.astype(np.float64), gf + b.astype(np.float64)
+    rd, rf = vo.render_bwd(grid256, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL
+
+
+# ---- configs[3]: attention-grid render of the refinement loop, 160^3, 266x266 (800 / 3) ---------------------------------
+@pytest.mark.parametrize("hw,cam", [(266, 12), (400, 40)])
+def test_cfg4_attention_render_160_vs_oracle(hw, cam):
+    dens, _ = sphere_grid(160)
+    attn = (np.random.default_rng(4).standard_normal((160, 160, 160, 1)) - 1.0).astype(np.float32)
+    grid = vo.Grid(dens.numpy(), attn, AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_ATTN)
+    o, d = _rays(hw, cam)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=3, rng_offset=9)
+    out, ref = gh.hip_forward(grid, cfg, o, d, rng=(3, 9), image_width=hw), vo.render_fwd(grid, cfg, o, d)
+    _check_forward(out, ref)
+    ga = np.random.default_rng(5).standard_normal((o.shape[0], 1)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, ga, rng=(3, 9), image_width=hw)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, ga)
+    assert rel_l2(gf, rf) < GRAD_TOL, rel_l2(gf, rf)          # the attention grid: what the refinement loop optimises
+    assert rel_l2(gd, rd) < GRAD_TOL, rel_l2(gd, rd)
+
+
+# ---- the SHIPPED dispatch for small images (tests/conftest.py lowers VOXE_TILE_MIN_RAYS to 0 for everything else) -------
+@pytest.mark.parametrize("hw", [64, 100])
+def test_default_dispatch_small_images_vs_oracle(hw, monkeypatch):
+    """with the default threshold an image below 8192 rays takes the depth-segmented scatter backward and 100x100 the
+    LDS-window backward: run exactly what ships"""
+    monkeypatch.delenv("VOXE_TILE_MIN_RAYS", raising=False)
+    grid = _grid(160, "sphere")
+    o, d = _rays(hw, 21)
+    cfg = make_render_cfg(S, NEAR, FAR, white_bkgd=True)
+    gc = np.random.default_rng(hw).standard_normal((o.shape[0], 3)).astype(np.float32)
+    _check_forward(gh.hip_forward(grid, cfg, o, d, image_width=hw), vo.render_fwd(grid, cfg, o, d))
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, image_width=hw)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL
+    assert os.environ.get("VOXE_TILE_MIN_RAYS") is None

@@ -562,7 +562,8 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
 // combine in LDS): the depth-segmented line-dense scatter is faster there (64x64: 0.18 vs 0.40 ms; 100x100: 0.40 vs 0.31 ms).
 // VOXE_TILE_MIN_RAYS overrides the threshold (the parity tests set 0 so that small images exercise this kernel).
 bool tile_bwd_supported(const DevCfg& c, int deg) {
-  static const long long min_rays = [] { const char* e = getenv("VOXE_TILE_MIN_RAYS"); return e ? atoll(e) : 8192ll; }();
+  const char* e = getenv("VOXE_TILE_MIN_RAYS");   // read per launch: the tests flip it (default dispatch vs forced tile kernel)
+  const long long min_rays = e ? atoll(e) : 8192ll;
   (void)deg;   // every SH degree: view-dependent grids run their gradient channels as groups of 4 (sibling blocks)
   return c.image_width > 0 && c.R >= min_rays;
 }
