@@ -47,6 +47,20 @@ COMPAT_ONLY = [
 ]
 
 
+def edit_stage_intrinsics(checkpoint_intrinsics, dataset, data_downsample_factor: float):
+    """Camera intrinsics of the SDS edit and refinement stages.  The reference renders them at the DATASET's intrinsics,
+    built at --data_downsample_factor (edit_pretrained_relu_field.py:253-274, sds_trainer.py:152-156,270-277: default 3.0,
+    i.e. 266 x 266 for 800-pixel data), whatever resolution the checkpoint was trained at.  With a dataset: exactly
+    those.  Without one (this build allows editing from a checkpoint alone): the checkpoint's intrinsics -- the
+    training resolution, factor 1.0 with the reference's training defaults -- divided by the factor the way the
+    dataset class does it (height / width truncated, focal / factor)."""
+    if dataset is not None:
+        return dataset.camera_intrinsics
+    h, w, f = checkpoint_intrinsics
+    factor = float(data_downsample_factor)
+    return type(checkpoint_intrinsics)(max(int(h / factor), 1), max(int(w / factor), 1), f / factor)
+
+
 @click.command()
 @click.option("-i", "--ref_model_path", type=click.Path(file_okay=True, dir_okay=False), required=True, help="path to the pre-trained relu field model")
 @click.option("-o", "--output_path", type=click.Path(file_okay=False, dir_okay=True), required=True, help="path for training output")
@@ -117,13 +131,12 @@ def main(**kwargs) -> None:
     ref_vol_mod.render_config.white_bkgd = cfg.white_bkgd
     sds_vol_mod = copy.deepcopy(ref_vol_mod)
     dataset = None
-    if cfg.data_path is not None and (cfg.uncoupled_mode or cfg.data_pose_mode):
+    if cfg.data_path is not None:
         from thre3d_atom.data.datasets import PosedImagesDataset
 
         dataset = PosedImagesDataset(Path(cfg.data_path) / "train", Path(cfg.data_path) / "train_camera_params.json",
                                      downsample_factor=cfg.data_downsample_factor, rgba_white_bkgd=cfg.white_bkgd)
-    # the reference trains at the dataset's (down-sampled) resolution; the checkpoint stores those intrinsics
-    intrinsics = scale_camera_intrinsics(extra[CAMERA_INTRINSICS], 1.0)
+    intrinsics = edit_stage_intrinsics(extra[CAMERA_INTRINSICS], dataset, cfg.data_downsample_factor)
     train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
         sds_vol_mod=sds_vol_mod, pretrained_vol_mod=ref_vol_mod, train_dataset=dataset, image_dims=None,
         output_dir=output_path, num_iterations=cfg.num_iterations_edit, learning_rate=cfg.learning_rate,
@@ -134,7 +147,7 @@ def main(**kwargs) -> None:
         tv_features_weight=cfg.tv_features_weight, do_sds=cfg.do_sds, sds_t_freq=cfg.sds_t_freq,
         sds_t_start=cfg.sds_t_start, sds_t_gamma=cfg.sds_t_gamma, uncoupled_mode=cfg.uncoupled_mode,
         data_pose_mode=cfg.data_pose_mode, camera_intrinsics=intrinsics, camera_bounds=extra[CAMERA_BOUNDS],
-        hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311), uncoupled_l2_mode=cfg.uncoupled_l2_mode,
+        saved_hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311), uncoupled_l2_mode=cfg.uncoupled_l2_mode,
         l2_mode=cfg.l2_mode, l1_mode=cfg.l1_mode, log_wandb=cfg.log_wandb,
     )
     saved = output_path / "saved_models"
@@ -155,7 +168,7 @@ def main(**kwargs) -> None:
             min_num_edit_voxels=cfg.min_num_edit_voxels, top_k_edit_thresh=cfg.top_k_edit_thresh,
             top_k_obj_thresh=cfg.top_k_obj_thresh, data_pose_mode=cfg.data_pose_mode,
             downsample_refine_grid=cfg.downsample_refine_grid, camera_intrinsics=intrinsics,
-            camera_bounds=extra[CAMERA_BOUNDS], hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
+            camera_bounds=extra[CAMERA_BOUNDS], saved_hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
         )
         final_name = "model_final_refined.pth"
     if cfg.post_process_scc:

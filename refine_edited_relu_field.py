@@ -92,7 +92,7 @@ def main(**kwargs) -> None:
         attn_models.append(vm)
     vol_mod_edit, vol_mod_obj, sds_vol_mod = attn_models
     dataset = None
-    if cfg.data_path is not None and cfg.data_pose_mode:
+    if cfg.data_path is not None:   # (its intrinsics are the ones the refinement renders at, like the reference)
         from thre3d_atom.data.datasets import PosedImagesDataset
 
         dataset = PosedImagesDataset(Path(cfg.data_path) / "train", Path(cfg.data_path) / "train_camera_params.json",
@@ -108,7 +108,7 @@ def main(**kwargs) -> None:
         min_num_edit_voxels=cfg.min_num_edit_voxels, top_k_edit_thresh=cfg.top_k_edit_thresh,
         top_k_obj_thresh=cfg.top_k_obj_thresh, data_pose_mode=cfg.data_pose_mode,
         downsample_refine_grid=cfg.downsample_refine_grid, camera_intrinsics=extra[CAMERA_INTRINSICS],
-        camera_bounds=extra[CAMERA_BOUNDS], hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
+        camera_bounds=extra[CAMERA_BOUNDS], saved_hemispherical_radius=extra.get(HEMISPHERICAL_RADIUS, 4.0311),
         log_wandb=cfg.log_wandb,
     )
 

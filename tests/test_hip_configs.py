@@ -148,7 +148,7 @@ def test_cfg2_trainer_batch_through_the_model_api():
         gc = (np.sign(gh.n(colours) - pix) / pix.size).astype(np.float32)
         a, b = vo.render_bwd(grid, cfg, o, d, gc)
         rd, rf = rd + a, rf + b
-    assert abs(float(loss) - ref_loss) < 1e-6
+    assert abs(float(loss.detach()) - ref_loss) < 1e-6
     gd = gh.n(vm.thre3d_repr._densities.grad if hasattr(vm.thre3d_repr, "_densities") else vm.thre3d_repr.densities.grad)
     gf = gh.n(vm.thre3d_repr._features.grad if hasattr(vm.thre3d_repr, "_features") else vm.thre3d_repr.features.grad)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))

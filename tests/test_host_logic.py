@@ -197,7 +197,8 @@ def test_datasets_on_disk_format_and_downsampling(tmp_path):
     ds = PosedImagesDataset(img_dir, tmp_path / "train_camera_params.json", rgba_white_bkgd=True)
     assert len(ds) == 3 and ds.images.shape == (3, 3, 12, 16) and ds.poses.shape == (3, 3, 4)
     assert ds.camera_intrinsics == CameraIntrinsics(12, 16, 20.0)
-    assert ds.camera_bounds == CameraBounds(2.0 * 0.9, 6.0 * 1.1)           # datasets.py:275-276
+    # datasets.py:275-276, evaluated in float32 like the reference (np.float32 bounds array * python float)
+    assert ds.camera_bounds == CameraBounds(float(np.float32(2.0) * 0.9), float(np.float32(6.0) * 1.1))
     assert abs(ds.get_hemispherical_radius_estimate() - 4.0311) < 1e-3       # test_datasets.py:48-52
     assert 0.0 <= float(ds.images.min()) and float(ds.images.max()) <= 1.0
     img, pose, idx = ds[1]
@@ -216,6 +217,60 @@ def test_datasets_on_disk_format_and_downsampling(tmp_path):
     cam = PosedImagesDataset.extract_pose(dd.camera_parameters["r_1.png"])
     assert cam.rotation.shape == (3, 3) and cam.translation.shape == (3, 1)
     assert dd.get_config_dict()["rgba_white_bkgd"] is True and dd.get_config_dict()["downsample_factor"] == 1.0
+
+
+def test_dataset_bounds_scale_and_truncated_intrinsics_follow_the_reference(tmp_path):
+    """reference data/datasets.py: bounds = (min over ALL cameras' near) * 0.9, (max far) * 1.1 (:267-277); with
+    normalize_scene_scale every location and both bounds are divided by the distance of the FARTHEST camera (:218-249);
+    a downsample factor divides (height, width, focal) with height / width truncated (:288-306): 800 / 3 -> 266, f / 3"""
+    import json
+
+    from PIL import Image
+
+    from thre3d_atom.data.datasets import PosedImagesDataset
+    from thre3d_atom.utils.imaging_utils import CameraIntrinsics, pose_spherical
+
+    img_dir = tmp_path / "train"
+    img_dir.mkdir()
+    params = {}
+    radii, bounds = (3.0, 5.0, 4.0), ([2.0, 6.0], [1.5, 5.0], [2.5, 7.0])
+    for i in range(3):
+        pose = pose_spherical(50.0 * i, 25.0, radii[i])
+        Image.fromarray(np.full((80, 80, 3), 40 * i, np.uint8), "RGB").save(img_dir / f"r_{i}.png")
+        params[f"r_{i}.png"] = {
+            "extrinsic": {"rotation": pose.rotation.numpy().tolist(), "translation": pose.translation.numpy().tolist()},
+            "intrinsic": {"height": 80, "width": 80, "focal": 100.0, "bounds": bounds[i]},
+        }
+    (tmp_path / "p.json").write_text(json.dumps(params))
+    ds = PosedImagesDataset(img_dir, tmp_path / "p.json")
+    assert abs(ds.camera_bounds.near - 1.5 * 0.9) < 1e-6 and abs(ds.camera_bounds.far - 7.0 * 1.1) < 1e-6
+    dn = PosedImagesDataset(img_dir, tmp_path / "p.json", normalize_scene_scale=True)
+    norms = dn.poses[:, :, 3].norm(dim=-1)
+    assert abs(float(norms.max()) - 1.0) < 1e-6 and abs(float(norms.min()) - 3.0 / 5.0) < 1e-6
+    assert abs(dn.camera_bounds.near - 1.5 * 0.9 / 5.0) < 1e-6 and abs(dn.camera_bounds.far - 7.0 * 1.1 / 5.0) < 1e-6
+    d3 = PosedImagesDataset(img_dir, tmp_path / "p.json", downsample_factor=3.0)
+    assert d3.camera_intrinsics == CameraIntrinsics(26, 26, 100.0 / 3.0) and d3.images.shape[-2:] == (26, 26)
+
+
+def test_edit_stage_intrinsics_follow_the_dataset_or_the_downsample_factor():
+    """the SDS edit renders at the dataset's intrinsics (built at --data_downsample_factor, default 3.0), not
+    at the checkpoint's training resolution; in uncoupled_mode rendered and target pixel counts must agree"""
+    import importlib.util
+    import os
+    import types
+
+    from thre3d_atom.utils.imaging_utils import CameraIntrinsics
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("edit_cli", os.path.join(root, "edit_pretrained_relu_field.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ckpt = CameraIntrinsics(800, 800, 1111.111)
+    got = mod.edit_stage_intrinsics(ckpt, None, 3.0)
+    assert (got.height, got.width) == (266, 266) and abs(got.focal - 1111.111 / 3.0) < 1e-9
+    assert mod.edit_stage_intrinsics(ckpt, None, 1.0) == ckpt
+    ds = types.SimpleNamespace(camera_intrinsics=CameraIntrinsics(266, 266, 370.37))
+    assert mod.edit_stage_intrinsics(ckpt, ds, 3.0) is ds.camera_intrinsics   # rays and target pixels share these
 
 
 def test_product_never_imports_the_oracle():

@@ -43,13 +43,14 @@ class InMemoryPosedImages(Dataset):
         return float(self.poses[:, :, 3].norm(dim=-1).mean())
 
     def downsampled(self, factor: float) -> "InMemoryPosedImages":
-        """images resized by 1/factor (area filter), focal length scaled with them"""
+        """images resized by 1/factor (area filter); intrinsics as the reference derives them (datasets.py:288-306):
+        (height, width, focal) / factor with height and width TRUNCATED -- 800 px / 3.0 -> 266 px, focal / 3"""
         if factor == 1.0:
             return self
         h, w, f = self.camera_intrinsics
-        nh, nw = max(int(round(h / factor)), 1), max(int(round(w / factor)), 1)
+        nh, nw = max(int(h / factor), 1), max(int(w / factor), 1)
         images = F.interpolate(self.images, size=(nh, nw), mode="area")
-        return InMemoryPosedImages(images, self.poses, CameraIntrinsics(nh, nw, f * nw / w), self.camera_bounds)
+        return InMemoryPosedImages(images, self.poses, CameraIntrinsics(nh, nw, f / factor), self.camera_bounds)
 
     def to(self, device) -> "InMemoryPosedImages":
         return InMemoryPosedImages(self.images.to(device), self.poses.to(device), self.camera_intrinsics,
@@ -81,10 +82,12 @@ class PosedImagesDataset(InMemoryPosedImages):
         self._camera_parameters = params
         self.directions = [str(params[p.name][DIRECTION]) for p in files] if self.directional else None
         imgs, poses = [], []
+        # normalize_scene_scale: every camera location is divided by the distance of the FARTHEST camera from the origin
+        # (max norm over all entries of the camera-parameter file, datasets.py:218-249), and so are the bounds
         scale = 1.0
         if normalize_scene_scale:
-            radii = [np.linalg.norm(np.array(params[p.name][EXTRINSIC][TRANSLATION], dtype=np.float32)) for p in files]
-            scale = 1.0 / max(float(np.mean(radii)), 1e-8)
+            radii = [np.linalg.norm(np.array(entry[EXTRINSIC][TRANSLATION], dtype=np.float32)) for entry in params.values()]
+            scale = 1.0 / max(float(np.max(radii)), 1e-8)
         for p in files:
             entry = params[p.name]
             img = np.asarray(Image.open(p), dtype=np.float32) / 255.0
@@ -99,8 +102,9 @@ class PosedImagesDataset(InMemoryPosedImages):
             poses.append(torch.from_numpy(np.concatenate([rot, trans], axis=1)))
         first = params[files[0].name]
         intr = CameraIntrinsics(int(first[INTRINSIC][HEIGHT]), int(first[INTRINSIC][WIDTH]), float(first[INTRINSIC][FOCAL]))
-        near, far = (float(v) for v in first[INTRINSIC][BOUNDS])
-        bounds = CameraBounds(near * scale * 0.9, far * scale * 1.1)
+        # bounds over ALL cameras of the file: min(near) * 0.9, max(far) * 1.1 (datasets.py:267-277), then the scene scale
+        all_bounds = np.vstack([np.array(entry[INTRINSIC][BOUNDS]).astype(np.float32) for entry in params.values()])
+        bounds = CameraBounds(float(all_bounds.min() * 0.9) * scale, float(all_bounds.max() * 1.1) * scale)
         lo, hi = image_data_range
         images = torch.stack(imgs) * (hi - lo) + lo
         super().__init__(images, torch.stack(poses), intr, bounds)

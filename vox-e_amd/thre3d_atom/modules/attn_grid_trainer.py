@@ -129,7 +129,9 @@ def refine_edited_relu_field(
     attn_guidance: Any = None,           # object with get_num_tokens(prompt) / get_attn_map(prompt=, pred_rgb=, ...)
     camera_intrinsics: Optional[CameraIntrinsics] = None,
     camera_bounds: Optional[CameraBounds] = None,
-    hemispherical_radius: float = HEMISPHERICAL_RADIUS_CONSTANT,
+    hemispherical_radius: float = HEMISPHERICAL_RADIUS_CONSTANT,   # distance of the random cameras: the reference hard-codes
+    # 4.0311 (attn_grid_trainer.py:54,277); pass another value only as an explicit override
+    saved_hemispherical_radius: Optional[float] = None,            # radius estimate stored in the checkpoints (no dataset)
 ) -> VolumetricModel:
     """Optimise the attention grids of `vol_mod_edit` / `vol_mod_object` (copies of the SDS-edited field), cut the
     edit region and write the refined field into `vol_mod_output` (returned).  Checkpoints as in the reference:
@@ -140,11 +142,11 @@ def refine_edited_relu_field(
     if prompt == "none":
         raise AssertionError("sorry, you have to supply a text prompt to use SDS")
     if train_dataset is not None:
-        camera_intrinsics = camera_intrinsics or train_dataset.camera_intrinsics
+        camera_intrinsics = train_dataset.camera_intrinsics      # the dataset's, like the reference (:162-166)
         camera_bounds = camera_bounds or train_dataset.camera_bounds
         extra_radius = train_dataset.get_hemispherical_radius_estimate()
     else:
-        extra_radius = hemispherical_radius
+        extra_radius = hemispherical_radius if saved_hemispherical_radius is None else saved_hemispherical_radius
         if data_pose_mode:
             raise ValueError("data_pose_mode needs a dataset of posed images")
     if camera_intrinsics is None or camera_bounds is None:

@@ -120,7 +120,10 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
     guidance: Any = None,               # object with training_step(...) / get_current_max_step_ratio()
     camera_intrinsics: Optional[CameraIntrinsics] = None,
     camera_bounds: Optional[CameraBounds] = None,
-    hemispherical_radius: float = HEMISPHERICAL_RADIUS_CONSTANT,
+    hemispherical_radius: float = HEMISPHERICAL_RADIUS_CONSTANT,   # distance of the random SDS cameras; the reference
+    # hard-codes 4.0311 (sds_trainer.py:45,270) whatever the scene -- pass another value only as an explicit override
+    saved_hemispherical_radius: Optional[float] = None,            # radius estimate written into the checkpoints when
+    # there is no dataset to estimate it from (the reference stores train_dataset.get_hemispherical_radius_estimate())
 ) -> VolumetricModel:
     """Edit `sds_vol_mod` (a copy of `pretrained_vol_mod`) with score distillation.  Returns it."""
     for vm in (sds_vol_mod, pretrained_vol_mod):
@@ -130,11 +133,13 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
         if train_dataset is None:
             raise ValueError("uncoupled_mode / data_pose_mode need a dataset of posed images")
     if train_dataset is not None:
-        camera_intrinsics = camera_intrinsics or train_dataset.camera_intrinsics
+        # like the reference (sds_trainer.py:152-156): a dataset's intrinsics are the ones the rays AND the target pixels
+        # live at, so they win over a caller-supplied value (uncoupled_mode compares rendered and dataset pixels)
+        camera_intrinsics = train_dataset.camera_intrinsics
         camera_bounds = camera_bounds or train_dataset.camera_bounds
         extra_radius = train_dataset.get_hemispherical_radius_estimate()
     else:
-        extra_radius = hemispherical_radius
+        extra_radius = hemispherical_radius if saved_hemispherical_radius is None else saved_hemispherical_radius
     if camera_intrinsics is None or camera_bounds is None:
         raise ValueError("camera_intrinsics and camera_bounds are required without a dataset")
     im_h, im_w = (int(v) for v in (image_dims if image_dims is not None else camera_intrinsics[:2]))
@@ -152,7 +157,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
         from thre3d_atom.thre3d_reprs.sd import scoreDistillationLoss
 
         guidance = scoreDistillationLoss(device, sds_prompt, t_sched_start=sds_t_start, t_sched_freq=sds_t_freq,
-                                         t_sched_gamma=sds_t_gamma, directional=not uncoupled_mode)
+                                         t_sched_gamma=sds_t_gamma, directional=True)   # the reference's prompts are always '<prompt>, <dir> view'
 
     grid = sds_vol_mod.thre3d_repr
     # ---- ray-sharded data parallelism (one process per GPU; no-op for a single process) ---------------------
