@@ -308,49 +308,64 @@ def main():
         "step_alg_gbs_per_gpu": round(rays_per_s / world * (s_in_total / R * 384 + 72) / 1e9, 2),
     }
 
-    # ---- secondary line: the same step at 100x100 (BASELINE.json asks for both image sizes), N = 1 default run only ----
+    # ---- secondary lines: the same step at 100x100 (BASELINE.json asks for both image sizes), N = 1 default run only:
+    # one camera per step (what one SDS iteration at that size is) and a multi-view step of 8 cameras in ONE launch
+    # (VoxeRenderCfg::image_height: K images back to back, pixel tiles per camera) ----
     secondary = None
     if world == 1 and default_cfg and not args.no_secondary:
         hw2 = 100
-        ro2, rd2 = ops.cast_rays(hw2, hw2, focal_for(hw2), pose.rotation, pose.translation, dev)
-        R2 = ro2.shape[0]
-        p2 = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw2)
-        g2 = torch.randn((R2, 3), generator=torch.Generator().manual_seed(44)).to(dev)
-        out2 = [torch.empty((R2, n), dtype=torch.float32, device=dev) for n in (3, 1, 1, 1)]
-        ws2 = ops.Workspace()
-        inside2 = ops.sample_probe(spec, ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=hw2),
-                                   dens, feat, ro2, rd2, outputs=("inside",))["inside"]
-        s_in2 = int(inside2.sum().item())
 
-        def step2():
-            if fused:
-                return fused_step(p2, ro2, rd2, out2, g2, ws2)
-            step_no[0] += 1
-            rng = (42, step_no[0])
-            ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
-            ops.render_bwd_into(spec, p2, dens, feat, ro2, rd2, None, out2[0], out2[1], out2[2], g2, None, None,
-                                d_dens, d_feat, ws2, rng)
-            ops.adam_step_(flat_p, flat_g, exp_avg, exp_avg_sq, step_no[0], lr=1e-4)
+        def small_step_bench(K):
+            ros, rds = [], []
+            for i in range(K):
+                p_i = pose_spherical(*synth_pose_angles(args.camera + 11 * i, 100), RADIUS)
+                a, b = ops.cast_rays(hw2, hw2, focal_for(hw2), p_i.rotation, p_i.translation, dev)
+                ros.append(a)
+                rds.append(b)
+            ro2, rd2 = torch.cat(ros).contiguous(), torch.cat(rds).contiguous()
+            R2 = ro2.shape[0]
+            p2 = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw2,
+                                  image_height=hw2 if K > 1 else 0)
+            g2 = torch.randn((R2, 3), generator=torch.Generator().manual_seed(44)).to(dev)
+            out2 = [torch.empty((R2, n), dtype=torch.float32, device=dev) for n in (3, 1, 1, 1)]
+            ws2 = ops.Workspace()
+            probe2 = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=hw2,
+                                      image_height=hw2 if K > 1 else 0)
+            s_in2 = int(ops.sample_probe(spec, probe2, dens, feat, ro2, rd2, outputs=("inside",))["inside"].sum().item())
 
-        first[0] = True   # (another workspace: its gradient region starts uncleared)
-        for _ in range(args.warmup):
-            step2()
-        torch.cuda.synchronize()
-        ops.profile_enable(True)
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step2()
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t2
-        pr2 = ops.profile_read()
-        ops.profile_enable(False)
-        b2 = pr2["ms_bwd"] / max(pr2["n_bwd"], 1)
-        secondary = {
-            "workload": f"same grid and step, one {hw2}x{hw2} camera", "value": round(R2 * args.steps / e2, 1), "unit": "rays/s",
-            "ms_per_step": round(1e3 * e2 / args.steps, 4), "in_aabb_samples_per_ray": round(s_in2 / R2, 2),
-            "bwd_ms": round(b2, 4), "fwd_ms": round(pr2["ms_fwd"] / max(pr2["n_fwd"], 1), 4),
-            "roofline_frac_bwd": round((s_in2 * 256 + R2 * 56) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b2 > 0 else None,
-        }
+            def step2():
+                if fused:
+                    return fused_step(p2, ro2, rd2, out2, g2, ws2)
+                step_no[0] += 1
+                rng = (42, step_no[0])
+                ops.render_fwd_into(spec, p2, dens, feat, ro2, rd2, None, *out2, ws2, rng)
+                ops.render_bwd_into(spec, p2, dens, feat, ro2, rd2, None, out2[0], out2[1], out2[2], g2, None, None,
+                                    d_dens, d_feat, ws2, rng)
+                ops.adam_step_(flat_p, flat_g, exp_avg, exp_avg_sq, step_no[0], lr=1e-4)
+
+            first[0] = True   # (another workspace: its gradient region starts uncleared)
+            for _ in range(args.warmup):
+                step2()
+            torch.cuda.synchronize()
+            ops.profile_enable(True)
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step2()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t2
+            pr2 = ops.profile_read()
+            ops.profile_enable(False)
+            b2 = pr2["ms_bwd"] / max(pr2["n_bwd"], 1)
+            return {
+                "workload": f"same grid and step, {K} x {hw2}x{hw2} camera(s) in one launch", "cameras_per_step": K,
+                "value": round(R2 * args.steps / e2, 1), "unit": "rays/s",
+                "ms_per_step": round(1e3 * e2 / args.steps, 4), "in_aabb_samples_per_ray": round(s_in2 / R2, 2),
+                "bwd_ms": round(b2, 4), "fwd_ms": round(pr2["ms_fwd"] / max(pr2["n_fwd"], 1), 4),
+                "roofline_frac_bwd": round((s_in2 * 256 + R2 * 56) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b2 > 0 else None,
+            }
+
+        secondary = small_step_bench(1)
+        secondary["multi_view"] = small_step_bench(8)
 
     # ---- CPU baseline: the oracle (a C port of the reference path) on the host cores, bounded sample ----
     cpu_baseline = None

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 4
+#define VOXE_ABI_VERSION 5
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -90,6 +90,18 @@ typedef struct VoxeRenderCfg {
                                  on the same workspace (grid values unchanged)                    */
   int32_t image_width;        /* 0 = unknown. >0: rays are a row-major H x W image (ray r is
                                  pixel (r / W, r % W)); lets the kernels use 2-D pixel tiles      */
+  int32_t image_height;       /* 0 = one image (H = R / image_width).  >0 with image_width > 0: the rays are K =
+                                 R / (image_height * image_width) row-major images of the same size, one after
+                                 the other (ray r = (camera * H + y) * W + x): ONE launch renders a multi-view
+                                 batch; pixel tiles never straddle two cameras.  R must be a multiple of H * W.  */
+  int32_t deterministic;      /* backward only, test / race-check mode (SURVEY 8(b) `deterministic`).  1: the gradient
+                                 is accumulated in 64-bit FIXED POINT (integer adds are associative, so the result
+                                 does not depend on the order lanes, waves and blocks meet on a voxel): two calls on
+                                 the same inputs return identical bits.  Costs an extra measuring pass (per-call
+                                 power-of-two scales from max |contribution|) and 8 bytes per gradient value of
+                                 workspace (voxe_workspace_bytes accounts for it).  Image-ordered rays
+                                 (image_width > 0), SH degree 0 / render_diffuse / attention grids; other
+                                 configurations return VOXE_ERR_UNSUPPORTED.  0: float atomics (default).          */
   int32_t ray_state_valid;    /* backward only. 1: `workspace` still holds the per-ray depth-segment
                                  states (transmittance + partial sums every VOXE_SEGMENT_SAMPLES
                                  samples) written by voxe_render_fwd for EXACTLY these rays / cfg /

@@ -25,7 +25,7 @@ def params_of(cfg, **over) -> ops.RenderParams:
         num_samples=cfg.num_samples, near=float(cfg.near), far=float(cfg.far), perturb=bool(cfg.perturb),
         linear_disparity=bool(cfg.linear_disparity), aabb_clip=bool(cfg.aabb_clip),
         white_bkgd=bool(cfg.white_bkgd), sh_degree=cfg.sh_degree, render_diffuse=bool(cfg.render_diffuse),
-        term_eps=float(cfg.term_eps), image_width=cfg.image_width,
+        term_eps=float(cfg.term_eps), image_width=cfg.image_width, image_height=cfg.image_height, deterministic=bool(cfg.deterministic),
     )
     for k, v in over.items():
         setattr(p, k, v)

@@ -228,3 +228,101 @@ def test_default_dispatch_small_images_vs_oracle(hw, monkeypatch):
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL
     assert os.environ.get("VOXE_TILE_MIN_RAYS") is None
+
+
+# ---- multi-view launches: K cameras of the same size in ONE image-ordered launch (VoxeRenderCfg::image_height) ----------
+@pytest.mark.parametrize("hw,K,kind", [(100, 8, "sphere"), (36, 3, "random"), (200, 2, "random")])
+def test_multi_view_launch_vs_oracle(hw, K, kind):
+    """K cameras back to back, image_width = W, image_height = H (100 and 36 are no multiples of the 8-pixel tiles:
+    tiles must not straddle two cameras): forward and gradients equal the oracle on the concatenated rays, and the
+    forward equals K single-camera launches bit for bit"""
+    grid = _grid(160, kind)
+    rays = [_rays(hw, 5 + 9 * i) for i in range(K)]
+    o, d = np.concatenate([r[0] for r in rays]), np.concatenate([r[1] for r in rays])
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=8, rng_offset=2)
+    out = gh.hip_forward(grid, cfg, o, d, rng=(8, 2), image_width=hw, image_height=hw)
+    _check_forward(out, vo.render_fwd(grid, cfg, o, d))
+    flat = gh.hip_forward(grid, cfg, o, d, rng=(8, 2))                       # same rays as an unordered list
+    np.testing.assert_array_equal(out["colour"], flat["colour"])             # (the jitter stream is keyed by the ray index)
+    gc = np.random.default_rng(K).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(8, 2), image_width=hw, image_height=hw)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+def test_multi_view_bad_shapes_are_rejected():
+    from voxe_hip.runtime import VoxeError
+
+    grid = _grid(32, "random")
+    o, d = _rays(20, 1)
+    cfg = make_render_cfg(16, NEAR, FAR)
+    with pytest.raises(VoxeError):
+        gh.hip_forward(grid, cfg, o, d, image_width=20, image_height=15)      # 400 rays are no multiple of 15 * 20
+    with pytest.raises(VoxeError):
+        gh.hip_forward(grid, cfg, o, d, image_width=0, image_height=20)       # a height without a width
+
+
+def test_collated_cameras_render_as_one_launch():
+    """host side: collate_rays of flattened whole cameras keeps the image shape, render_rays renders the multi-view batch
+    in one launch and returns what the per-camera renders return"""
+    from thre3d_atom.modules.volumetric_model import VolumetricModel
+    from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, collate_rays, flatten_rays
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid, _render_params
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelSize
+    from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics
+
+    G, hw = 64, 60
+    dens, feat = sphere_grid(G)
+    vg = VoxelGrid(dens, feat, VoxelSize(3.0 / G, 3.0 / G, 3.0 / G), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=100.0 / 3.0, tunable=True)
+    vm = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(64, CameraBounds(NEAR, FAR), white_bkgd=True,
+                                                                        perturb_sampled_points=False), device=gh.DEV)
+    intr = CameraIntrinsics(hw, hw, focal_for(hw))
+    cams = [flatten_rays(cast_rays(intr, _pose(i), device=gh.DEV)) for i in (2, 30, 71)]
+    batch = collate_rays(cams)
+    assert batch.image_shape == (hw, hw)
+    params = _render_params(vm.thre3d_repr, batch, vm.render_config, attn=False)
+    assert (params.image_width, params.image_height) == (hw, hw)
+    assert _render_params(vm.thre3d_repr, cams[0], vm.render_config, attn=False).image_height == 0
+    with torch.no_grad():
+        whole = vm.render_rays(batch).colour
+        parts = torch.cat([vm.render_rays(c).colour for c in cams])
+    assert torch.equal(whole, parts)
+
+
+# ---- deterministic (ordered-accumulation) backward: SURVEY 8(b) `deterministic`, section 5 "race detection" -------------
+@pytest.mark.parametrize("hw,kind", [(400, "random"), (100, "sphere")])
+def test_deterministic_backward_is_bit_reproducible_and_matches_the_atomic_one(hw, kind):
+    """VoxeRenderCfg::deterministic = 1 accumulates in 64-bit fixed point (integer adds are associative): two launches
+    on the same inputs give IDENTICAL bits; the default float-atomic backward agrees with it to 1e-6 rel-L2 (a race in
+    the atomic path -- a lost or doubled deposit -- would show up here), and both agree with the oracle"""
+    grid = _grid(160, kind)
+    o, d = _rays(hw, 14)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=6, rng_offset=1)
+    gc = np.random.default_rng(9).standard_normal((o.shape[0], 3)).astype(np.float32)
+    det1 = gh.hip_backward(grid, cfg, o, d, gc, rng=(6, 1), image_width=hw, deterministic=True)
+    det2 = gh.hip_backward(grid, cfg, o, d, gc, rng=(6, 1), image_width=hw, deterministic=True)
+    np.testing.assert_array_equal(det1[0], det2[0])
+    np.testing.assert_array_equal(det1[1], det2[1])
+    atomic = gh.hip_backward(grid, cfg, o, d, gc, rng=(6, 1), image_width=hw)
+    assert rel_l2(atomic[0], det1[0]) < 1e-6 and rel_l2(atomic[1], det1[1]) < 1e-6, (rel_l2(atomic[0], det1[0]), rel_l2(atomic[1], det1[1]))
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(det1[0], rd) < GRAD_TOL and rel_l2(det1[1], rf) < GRAD_TOL
+
+
+def test_deterministic_backward_attention_grid_and_unsupported_cases():
+    from voxe_hip.runtime import VoxeError
+
+    dens, _ = sphere_grid(64)
+    attn = np.random.default_rng(4).standard_normal((64, 64, 64, 1)).astype(np.float32)
+    grid = vo.Grid(dens.numpy(), attn, AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_ATTN)
+    o, d = _rays(72, 3)
+    cfg = make_render_cfg(96, NEAR, FAR, white_bkgd=True)
+    ga = np.random.default_rng(5).standard_normal((o.shape[0], 1)).astype(np.float32)
+    a = gh.hip_backward(grid, cfg, o, d, ga, image_width=72, deterministic=True)
+    b = gh.hip_backward(grid, cfg, o, d, ga, image_width=72, deterministic=True)
+    np.testing.assert_array_equal(a[1], b[1])
+    rd, rf = vo.render_bwd(grid, cfg, o, d, ga)
+    assert rel_l2(a[1], rf) < GRAD_TOL and rel_l2(a[0], rd) < GRAD_TOL
+    with pytest.raises(VoxeError):      # unordered rays have no deterministic path
+        gh.hip_backward(grid, cfg, o, d, ga, deterministic=True)

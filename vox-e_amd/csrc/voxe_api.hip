@@ -76,6 +76,8 @@ int validate(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, Variant* 
     return VOXE_ERR_UNSUPPORTED;
   if (c->image_width < 0 || (c->image_width > 0 && R % c->image_width != 0))
     return VOXE_ERR_BAD_SHAPE;
+  if (c->image_height < 0 || (c->image_height > 0 && (c->image_width <= 0 || R % ((int64_t)c->image_height * c->image_width) != 0)))
+    return VOXE_ERR_BAD_SHAPE;
   return VOXE_OK;
 }
 
@@ -96,6 +98,7 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->key0 = (uint32_t)c->seed ^ ((uint32_t)c->rng_offset * 0x9E3779B1u);
   dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32) ^ 0x7F4A7C15u;
   dc->image_width = c->image_width;
+  dc->image_height = c->image_width > 0 ? (c->image_height > 0 ? c->image_height : (int)(R / c->image_width)) : 0;
   dc->map_mode = tile_map_mode(c->image_width);
   dc->R = R;
   dc->seg_len = seg_len_for(R);
@@ -105,7 +108,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, seg_off, src_off, fwd_total, total, total_with_src;
+  size_t packed_off, grad_off, state_off, seg_off, src_off, det_off, fwd_total, total, total_with_src;
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t nvox = (size_t)g->X * g->Y * g->Z;
@@ -128,8 +131,11 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   // per-sample gradient sources of the two-phase backward of view-dependent grids (optional: without it the channel
   // groups re-march the segment)
   l.src_off = l.total;
-  l.total_with_src = l.total + (c ? align_up(tile_src_bytes(R, c->image_width, c->num_samples, c->sh_degree, c->render_diffuse,
+  l.total_with_src = l.total + (c ? align_up(tile_src_bytes(R, c->image_width, c->image_height, c->num_samples, c->sh_degree, c->render_diffuse,
                                                            g->feature_kind == VOXE_FEAT_ATTN), 256) : 0);
+  // deterministic mode: the fixed-point gradient and its scales behind everything else
+  l.det_off = l.total_with_src;
+  if (c && c->deterministic) l.total_with_src += det_bytes((long long)nvox, g->F + 1);
   return l;
 }
 
@@ -309,7 +315,15 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
               want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
     if (tiled && l.total_with_src > l.total && workspace_bytes >= l.total_with_src && !two_phase_disabled())
       a.sample_src = (float*)((char*)workspace + l.src_off);
-    if ((tiled || packed_bwd) && !cfg->ray_state_valid) {
+    if (cfg->deterministic) {
+      if (!det_bwd_supported(dc, cfg->sh_degree, cfg->render_diffuse)) return VOXE_ERR_UNSUPPORTED;
+      if (workspace_bytes < l.total_with_src) return VOXE_ERR_WORKSPACE;
+      a.gdet = (unsigned long long*)((char*)workspace + l.det_off);
+      a.det_scale = (float*)((char*)workspace + l.det_off + det_bytes((long long)grid->X * grid->Y * grid->Z, grid->F + 1) - 256);
+      a.ray_state = state;
+    }
+    const bool det = cfg->deterministic != 0;
+    if ((tiled || packed_bwd || det) && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
@@ -317,7 +331,12 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
       launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, s);
     }
     PhaseTimer t(PH_BWD, s);
-    if (tiled)
+    if (det) {
+      // (the fixed-point region must start cleared: the finalize pass leaves it so, the first use clears it here)
+      if (hipMemsetAsync(a.gdet, 0, det_bytes((long long)grid->X * grid->Y * grid->Z, grid->F + 1), s) != hipSuccess)
+        return VOXE_ERR_LAUNCH;
+      launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
+    } else if (tiled)
       launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
     else if (packed_bwd) {
       launch_bwd_packed_scatter(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);

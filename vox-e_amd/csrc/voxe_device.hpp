@@ -34,6 +34,7 @@ struct DevCfg {
   float term_eps;
   uint32_t key0, key1;        // jitter stream keys (see jitter_base())
   int image_width;            // 0 = linear ray order
+  int image_height;           // rows of ONE image (image_width > 0); the launch holds R / (H * W) images back to back
   int map_mode;               // block -> tile mapping: 0 XCD bands, 1 linear, 2 tile rows interleaved over XCDs
   long long R;
   int seg_len;                // samples per depth segment of the segmented kernels (seg_len_for(R))

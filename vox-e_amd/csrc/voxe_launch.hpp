@@ -19,6 +19,10 @@ struct BwdArgs {
   bool want_d, want_f;
   const float* ray_state;  // states written by the forward for the same rays (tile backward only)
   float* sample_src = nullptr;   // scratch of the two-phase tile backward of view-dependent grids (tile_src_bytes())
+  // deterministic mode (VoxeRenderCfg::deterministic): 64-bit fixed-point gradient [voxels * C] + 4 floats
+  // (max |contribution| of features / density as float bits, then their power-of-two scales); see det_bytes()
+  unsigned long long* gdet = nullptr;
+  float* det_scale = nullptr;
 };
 struct ProbeArgs {
   const float *packed, *rays_o, *rays_d, *jitter;
@@ -50,8 +54,11 @@ void launch_query(const DevGrid& g, int C, const float* packed, const float* poi
 // voxe_render_tile.hip: LDS-window backward for image-ordered SH-0 / attention renders
 bool tile_bwd_supported(const DevCfg& c, int deg);
 // bytes of BwdArgs::sample_src for an image of R rays, width W, S samples (0: that render does not use it)
-size_t tile_src_bytes(long long R, int W, int S, int deg, int diffuse, int attn);
+size_t tile_src_bytes(long long R, int W, int H, int S, int deg, int diffuse, int attn);
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
+// deterministic (ordered-accumulation) backward: single-group image-ordered renders only
+bool det_bwd_supported(const DevCfg& c, int deg, int diffuse);
+size_t det_bytes(long long nvox, int C);   // [fixed-point gradient | 4 floats], 256-byte aligned parts
 
 // voxe_render_scatter.hip: line-dense scatter backward for unordered rays (SH-0 / attention)
 bool packed_scatter_supported(int deg);

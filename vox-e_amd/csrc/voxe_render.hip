@@ -417,14 +417,12 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
   {  // one wave = one 8x8 pixel tile (image order) or 64 consecutive rays
     const int lane = threadIdx.x;
     if (c.image_width > 0) {
-      const int W = c.image_width, H = (int)(c.R / W);
-      const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
+      const int W = c.image_width;
+      const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
       const int t = logical_tile_of(c, rb, nrb, ntx, nty);
       if (t < 0) return;
       const int ty = t / ntx, tx = t - ty * ntx;
-      const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
-      if (px >= W || py >= H) return;
-      r = (long long)py * W + px;
+      if (!tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r)) return;
     } else {
       const int nt = (int)((c.R + 63) / 64);
       const int t = logical_tile_of(c, rb, nrb, 1, nt);
@@ -768,8 +766,7 @@ void launch_query(const DevGrid& g, int C, const float* packed, const float* poi
 // ------------------------------------------------------------------------------------------------
 static inline int blocks_for(const DevCfg& c) {
   if (c.image_width > 0) {
-    const long long W = c.image_width, H = c.R / W;
-    return blocks_for_tiles(c.map_mode, (W + 15) / 16, (H + 15) / 16);
+    return blocks_for_tiles(c.map_mode, (c.image_width + 15) / 16, tile_rows_total(c, 16));
   }
   return blocks_for_tiles(c.map_mode, 1, (c.R + 255) / 256);
 }
@@ -818,7 +815,7 @@ static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hi
     if (env_fseg > 0) fseg = env_fseg;
     const int ncoarse = (nseg + fseg - 1) / fseg;
     const int nrb64 = c.image_width > 0
-                          ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, (c.R / c.image_width + 7) / 8)
+                          ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
                           : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64);
     render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
         g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);

@@ -61,23 +61,36 @@ static inline int blocks_for_tiles(int map_mode, long long ntx, long long nty) {
   return (int)((ntx * nty + 7) / 8 * 8);
 }
 
+// Image-ordered launches hold K = R / (H * W) images back to back (K = 1 unless VoxeRenderCfg::image_height says
+// otherwise).  Pixel tiles of `side` x `side` pixels are laid out per image -- a tile never straddles two cameras --
+// and numbered row-major over a virtual image of K * ceil(H / side) tile rows.
+__host__ __device__ inline long long tile_rows_total(const DevCfg& c, int side) {
+  const long long per = (c.image_height + side - 1) / side;
+  const long long nimg = c.image_height > 0 ? c.R / ((long long)c.image_width * c.image_height) : 0;
+  return per * (nimg > 0 ? nimg : 1);
+}
+// ray of pixel (px, row `py_in_tile` of tile row `ty`): false when the pixel is outside its image
+__device__ __forceinline__ bool tile_pixel_ray(const DevCfg& c, int ty, int py_in_tile, int px, int side, long long& r) {
+  const int per = (c.image_height + side - 1) / side;       // tile rows of one image
+  const int img = ty / per, tyi = ty - img * per;
+  const int py = tyi * side + py_in_tile;
+  r = ((long long)img * c.image_height + py) * c.image_width + px;
+  return px < c.image_width && py < c.image_height;
+}
+
 // b / nblocks: this block's index among the `nblocks` ray blocks of the launch (a kernel that runs several
 // blocks per ray block, e.g. one per depth segment, passes blockIdx.x / n and gridDim.x / n).
 __device__ __forceinline__ bool map_ray_block(const DevCfg& c, int b, int nblocks, long long& r) {
   const int tid = threadIdx.x;
   if (c.image_width > 0) {
     const int W = c.image_width;
-    const int H = (int)(c.R / W);
-    const int ntx = (W + 15) >> 4, nty = (H + 15) >> 4;
+    const int ntx = (W + 15) >> 4, nty = (int)tile_rows_total(c, 16);
     const int logical = logical_tile_of(c, b, nblocks, ntx, nty);
     if (logical < 0) return false;
     const int ty = logical / ntx, tx = logical - ty * ntx;
     const int wave = tid >> 6, lane = tid & 63;
     const int px = (tx << 4) + ((wave & 1) << 3) + (lane & 7);
-    const int py = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
-    if (px >= W || py >= H) return false;
-    r = (long long)py * W + px;
-    return true;
+    return tile_pixel_ray(c, ty, ((wave >> 1) << 3) + (lane >> 3), px, 16, r);
   }
   const int nt = (int)((c.R + 255) / 256);
   const int logical = logical_tile_of(c, b, nblocks, 1, nt);

@@ -110,9 +110,12 @@ struct Window {
 };
 // WC = channels held by the window, CM = channels of a packed texel, memch = texel channel of THIS lane's window
 // channel (lane % WC)
-template <int WC, int KL>
+// DET (deterministic mode, test / race-check only): the window holds 64-bit FIXED-POINT sums (integer adds are
+// associative: any order gives the same bits) and is flushed with 64-bit integer atomics into `gdet`.
+template <int WC, int KL, bool DET = false>
 __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __restrict__ gpacked,
-                                            const Window& w, int key, int lane, int CM, int memch) {
+                                            const Window& w, int key, int lane, int CM, int memch,
+                                            unsigned long long* __restrict__ gdet = nullptr) {
   constexpr int C = WC;
   constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots, kPlane = Lat<KL>::kPlane;
   const int im = w.sgn * key;
@@ -125,6 +128,16 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
     if (kLayerSlots % kPerInstr != 0 && ab >= kLayerSlots) continue;
     const int ch = lane % C;
     const int idx = ch * kPlane + lbase + Lat<KL>::pos(key, ab);
+    if constexpr (DET) {
+      const unsigned long long q = reinterpret_cast<unsigned long long*>(win)[idx];
+      if (q != 0ull) {
+        reinterpret_cast<unsigned long long*>(win)[idx] = 0ull;
+        const int iu = ab / kLat + offu, iv = ab % kLat + offv;
+        const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+        atomicAdd(gdet + vox * CM + memch, q);
+      }
+      continue;
+    }
     const double val = win[idx];
     if (val != 0.0) {
       win[idx] = 0.0;
@@ -145,7 +158,11 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
 // (full gather, all the math) and stores the 4 per-sample gradient sources (d rad_0..2, d v); MODE 2 (one block per
 // group) recomputes only the footprints, loads the sources and deposits its 4 channels.  MODE 0 does both in one kernel
 // (every single-group render; view-dependent grids without the scratch buffer).
-template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE, int KL>
+// fixed-point image of a float contribution (DET): the value was pre-multiplied by a power of two (exact), so the
+// rounding to an integer is the only step that differs from the float path; two's-complement wrap makes signed sums work
+__device__ __forceinline__ unsigned long long det_quant(float x) { return (unsigned long long)__double2ll_rn((double)x); }
+
+template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE, int KL, bool DET = false>
 // launch bounds swept: (64, 3) best; 2 and 4..6 are 6-9 % slower (register budget vs the LDS-bound residency)
 #ifndef VOXE_TILE_LB
 #define VOXE_TILE_LB 3
@@ -157,7 +174,11 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
     const float* __restrict__ acc, const float* __restrict__ d_colour,
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
     const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit, const int grp_begin,
-    const int ngrp, float4* __restrict__ sample_src) {
+    const int ngrp, float4* __restrict__ sample_src, unsigned long long* __restrict__ gdet = nullptr,
+    float* __restrict__ det_scale = nullptr, const int det_phase = 0) {
+  // DET: det_phase 0 measures max |contribution| per channel class into det_scale[0..1] (features, density) as
+  // float bits (atomicMax: order independent); det_phase 1 deposits with the power-of-two scales det_scale[2..3].
+  static_assert(!DET || MODE == 0, "the deterministic mode is the single-kernel backward");
   constexpr int CM = COUT * NCM + 1;          // channels of a packed texel
   constexpr int NG = COUT * NCU + 1;          // channels that receive a gradient (the used coefficients + density)
   constexpr int C = NG < 4 ? NG : 4;          // channels held by the LDS window
@@ -170,8 +191,8 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   for (int i = lane; i < kWinDoubles; i += 64) win[i] = 0.0;
 
   // ---- tile -> ray (XCD-banded like map_ray) ----------------------------------------------------
-  const int W = c.image_width, H = (int)(c.R / W);
-  const int ntx = (W + 7) >> 3, nty = (H + 7) >> 3;
+  const int W = c.image_width;
+  const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);   // (all cameras of a multi-view launch)
   // a block = (pixel tile, depth segment[, part]).  qsplit == 4 (small images that leave the chip under-filled): the
   // parts of a tile run as sibling blocks instead of one after the other.
   // Block order: (part, SEGMENT)-major, tile minor -- all tiles at depth segment 0, then all at segment 1, ...  The
@@ -195,9 +216,9 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   // two-phase backward: slot of (tile, segment, sample k, lane) in the source buffer
   const long long src_base = ((long long)tile * nseg + seg) * c.seg_len * 64 + lane - (long long)ks * 64;
   const int ty = tile / ntx, tx = tile - ty * ntx;
-  const int px = (tx << 3) + (lane & 7), py = (ty << 3) + (lane >> 3);
-  const bool alive = (px < W) && (py < H);
-  const long long r = alive ? (long long)py * W + px : 0;
+  long long r_px;
+  const bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  const long long r = alive ? r_px : 0;
 
   RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
@@ -326,6 +347,16 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
         mult[s] = b;
       }
     }
+    float dscale[C];            // DET: power-of-two scale of every window channel; det_max: largest |contribution| seen
+    float det_max_f = 0.0f, det_max_d = 0.0f;
+  #pragma unroll
+    for (int s = 0; s < C; ++s) dscale[s] = 1.0f;
+    if constexpr (DET) {
+      if (det_phase == 1) {
+  #pragma unroll
+        for (int s = 0; s < C; ++s) dscale[s] = (chsel[s] == COUT) ? det_scale[3] : det_scale[2];
+      }
+    }
     int my_memch = memch[0];    // texel channel of window channel lane % C (flush)
   #pragma unroll
     for (int s = 1; s < C; ++s) my_memch = (lane % C == s) ? memch[s] : my_memch;
@@ -412,6 +443,19 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
             any = any || (gch[s] != 0.0f);
           }
           if constexpr (MODE == 1) any = false;   // the source pass deposits nothing
+          if constexpr (DET) {
+            if (det_phase == 0) {   // measuring pass: weights are <= 1, so |gch| bounds every contribution
+  #pragma unroll
+              for (int s = 0; s < C; ++s) {
+                if (chsel[s] == COUT) det_max_d = fmaxf(det_max_d, fabsf(gch[s]));
+                else det_max_f = fmaxf(det_max_f, fabsf(gch[s]));
+              }
+              any = false;
+            } else {
+  #pragma unroll
+              for (int s = 0; s < C; ++s) gch[s] *= dscale[s];   // exact (power of two)
+            }
+          }
 
           if (MODE != 1 && any) {
             // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
@@ -473,9 +517,14 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
                 const int idx = (bm ? lofB : lofA) + Lat<KL>::wrap(abu[bm + 2 * bu] + (bv ? vB : vA));
   #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
-                  if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
-                    __hip_atomic_fetch_add(&win[poff[ch] + idx], (double)(gr[ch] * wgt), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                  if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D)) {
+                    if constexpr (DET)
+                      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(win) + (poff[ch] + idx),
+                                             det_quant(gr[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                      __hip_atomic_fetch_add(&win[poff[ch] + idx], (double)(gr[ch] * wgt), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                  }
                 }
               }
             } else {  // some corner outside the window: per-corner test, global scatter for the outsiders (rare)
@@ -493,16 +542,23 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
                     const int idx = ring_slot(key) * kLayerSlots + Lat<KL>::pos(key, a * kLat + b);
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
-                      if (NGRP > 1 || (ch < COUT && WANT_F) || (ch == COUT && WANT_D))
-                        __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                      if (NGRP > 1 || (ch < COUT && WANT_F) || (ch == COUT && WANT_D)) {
+                        if constexpr (DET)
+                          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(win) + (ch * kPlane + idx),
+                                                 det_quant(gch[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else
+                          __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+                      }
                     }
                   } else {
                     const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
-                      if (NGRP > 1 ? (chsel[ch] >= 0) : ((ch < COUT && WANT_F) || (ch == COUT && WANT_D)))
-                        atomicAdd(gpacked + vox * CM + memch[ch], gch[ch] * wgt);
+                      if (NGRP > 1 ? (chsel[ch] >= 0) : ((ch < COUT && WANT_F) || (ch == COUT && WANT_D))) {
+                        if constexpr (DET) atomicAdd(gdet + vox * CM + memch[ch], det_quant(gch[ch] * wgt));
+                        else atomicAdd(gpacked + vox * CM + memch[ch], gch[ch] * wgt);
+                      }
                     }
                   }
                 }
@@ -526,7 +582,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
         __syncthreads();
         const long long adv = (long long)newbase - (long long)w.base;
         const int nflush = adv < kRing ? (int)adv : kRing;
-        for (int i = 0; i < nflush; ++i) flush_layer<C, KL>(win, gpacked, w, w.base + i, lane, CM, my_memch);
+        for (int i = 0; i < nflush; ++i) flush_layer<C, KL, DET>(win, gpacked, w, w.base + i, lane, CM, my_memch, gdet);
         w.base = newbase;
         __syncthreads();
       }
@@ -534,7 +590,17 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
     __syncthreads();
     if constexpr (MODE != 1) {
       if (w.base != INT_MAX) {
-        for (int i = 0; i < kRing; ++i) flush_layer<C, KL>(win, gpacked, w, w.base + i, lane, CM, my_memch);
+        for (int i = 0; i < kRing; ++i) flush_layer<C, KL, DET>(win, gpacked, w, w.base + i, lane, CM, my_memch, gdet);
+      }
+    }
+    if constexpr (DET) {
+      if (det_phase == 0) {   // non-negative floats order like their bit patterns: atomicMax on the bits
+        const unsigned mf = (unsigned)wave_max_i32((int)__float_as_uint(det_max_f));
+        const unsigned md = (unsigned)wave_max_i32((int)__float_as_uint(det_max_d));
+        if (lane == 0) {
+          atomicMax(reinterpret_cast<unsigned*>(det_scale), mf);
+          atomicMax(reinterpret_cast<unsigned*>(det_scale) + 1, md);
+        }
       }
     }
 
@@ -568,9 +634,37 @@ bool tile_bwd_supported(const DevCfg& c, int deg) {
   return c.image_width > 0 && c.R >= min_rays;
 }
 
+// ---- deterministic mode: scales from the measured maxima, fixed-point -> float ---------------------------------------
+__global__ void det_scale_kernel(float* __restrict__ det_scale) {
+  // det_scale[0..1]: max |contribution| (features, density); -> det_scale[2..3]: 2^(38 - e) with max < 2^e, so that a
+  // scaled contribution is below 2^38 and 2^24 of them still fit the 64-bit sum
+  for (int i = 0; i < 2; ++i) {
+    int e = 0;
+    const float m = det_scale[i];
+    if (m > 0.0f && m < 3.0e38f) (void)frexpf(m, &e);
+    det_scale[2 + i] = ldexpf(1.0f, 38 - e);
+  }
+}
+__global__ __launch_bounds__(256) void det_finalize_kernel(unsigned long long* __restrict__ gdet, float* __restrict__ gpacked,
+                                                           long long n, int CM, const float* __restrict__ det_scale) {
+  const double inv_f = 1.0 / (double)det_scale[2], inv_d = 1.0 / (double)det_scale[3];   // exact (powers of two)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long long q = (long long)gdet[i];
+    if (q != 0) {
+      gpacked[i] += (float)((double)q * ((int)(i % CM) == CM - 1 ? inv_d : inv_f));
+      gdet[i] = 0ull;   // ready for the next call
+    }
+  }
+}
+size_t det_bytes(long long nvox, int C) { return (((size_t)nvox * C * 8 + 255) / 256 + 1) * 256; }
+bool det_bwd_supported(const DevCfg& c, int deg, int diffuse) {
+  return c.image_width > 0 && (c.attn || deg == 0 || diffuse);   // one channel group, image-ordered rays
+}
+
 template <int COUT, int NCM, int NCU>
 static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
-  const long long W = c.image_width, H = c.R / W;
+  const long long ntx8 = (c.image_width + 7) / 8, nty8 = tile_rows_total(c, 8);
   // The parts (halves / quadrants) of a tile run as sibling blocks instead of consecutive passes while the launch is
   // small enough for the extra blocks to pay off (LDS bounds residency at 9 blocks per CU, 2304 on the chip; siblings
   // of a tile that fits the window whole retire at once); measured cross-over on MI355X with the segment-major block
@@ -579,13 +673,27 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   constexpr int NG = COUT * NCU + 1, WC = NG < 4 ? NG : 4, NGRP = (NG + WC - 1) / WC;
   // channel groups: all of them for a feature gradient; only the one holding the density channel (the last) otherwise
   const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
-  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * num_segments(c.S, c.seg_len) * ngrp;
+  const long long tiles = ntx8 * nty8 * num_segments(c.S, c.seg_len) * ngrp;
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
-  const int nb = blocks_for_tiles(c.map_mode, (W + 7) / 8, (H + 7) / 8) * num_segments(c.S, c.seg_len) * qsplit * ngrp;
+  const int nb = blocks_for_tiles(c.map_mode, ntx8, nty8) * num_segments(c.S, c.seg_len) * qsplit * ngrp;
 #define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
   render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE, KL><<<NB, 64, 0, st>>>(                    \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
       a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src))
+  if constexpr (NGRP == 1) {
+    if (a.gdet) {   // deterministic mode: measure the maxima, derive the scales, deposit in fixed point, convert
+      const long long n = (long long)g.X * g.Y * g.Z * (COUT * NCM + 1);
+      (void)hipMemsetAsync(a.det_scale, 0, 4 * sizeof(float), st);
+      for (int phase = 0; phase < 2; ++phase) {
+        render_bwd_tile_kernel<COUT, NCM, NCU, true, true, 0, 8, true><<<nb, 64, 0, st>>>(
+            g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc,
+            a.ray_state, a.gpacked, qsplit, 0, 1, nullptr, a.gdet, a.det_scale, phase);
+        if (phase == 0) det_scale_kernel<<<1, 1, 0, st>>>(a.det_scale);
+      }
+      det_finalize_kernel<<<4096, 256, 0, st>>>(a.gdet, a.gpacked, n, COUT * NCM + 1, a.det_scale);
+      return;
+    }
+  }
   if constexpr (NGRP > 1) {
     if (a.sample_src && a.want_f) {   // two-phase: march once for the per-sample sources, then one deposit block per group
       if (a.want_d) VOXE_TBWD(true, true, 1, 8, nb / ngrp, 0, 1);
@@ -605,7 +713,7 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
     const char* env_kl_s = getenv("VOXE_TILE_KL");     // 8 | 10 overrides the choice (read per launch: the tests flip it)
     const int env_kl = env_kl_s ? atoi(env_kl_s) : 0;
     const int side = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
-    const int kl = env_kl ? env_kl : ((float)side >= 0.75f * (float)W ? 10 : 8);
+    const int kl = env_kl ? env_kl : ((float)side >= 0.75f * (float)c.image_width ? 10 : 8);
 #define VOXE_TBWD_KL(KL)                                                       \
     do {                                                                       \
       if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, KL, nb, 0, 1);         \
@@ -619,9 +727,10 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
 #undef VOXE_TBWD
 }
 
-size_t tile_src_bytes(long long R, int W, int S, int deg, int diffuse, int attn) {
+size_t tile_src_bytes(long long R, int W, int H1, int S, int deg, int diffuse, int attn) {
   if (W <= 0 || R <= 0 || deg <= 0 || diffuse || attn) return 0;   // single-group renders do not use it
-  const long long H = R / W, tiles = ((W + 7) / 8) * ((H + 7) / 8);
+  const long long H = H1 > 0 ? H1 : R / W, nimg = R / (H * W);
+  const long long tiles = ((W + 7) / 8) * ((H + 7) / 8) * (nimg > 0 ? nimg : 1);
   const int seg = seg_len_for(R);
   const size_t bytes = (size_t)tiles * num_segments(S, seg) * seg * 64 * sizeof(float4);
   return bytes <= ((size_t)4 << 30) ? bytes : 0;   // above 4 GB the single-kernel groups run instead

@@ -36,9 +36,16 @@ def flatten_rays(rays: Rays) -> Rays:
 
 
 def collate_rays(rays_list: Sequence[Rays]) -> Rays:
+    """Concatenation of flat ray batches (misc.py:60-70).  When every batch is one whole image of the same shape the
+    result keeps that `image_shape`: the renderer then runs the K cameras as ONE image-ordered launch."""
+    shapes = {r.image_shape for r in rays_list}
+    shape = shapes.pop() if len(shapes) == 1 else None
+    if shape is not None and any(r.origins.dim() != 2 or r.origins.shape[0] != shape[0] * shape[1] for r in rays_list):
+        shape = None
     return Rays(
         origins=torch.cat([r.origins for r in rays_list], dim=0),
         directions=torch.cat([r.directions for r in rays_list], dim=0),
+        image_shape=shape,
     )
 
 

@@ -70,9 +70,14 @@ def _render_params(voxel_grid: VoxelGrid, rays: Rays, cfg: SHVoxGridRenderConfig
     if cfg.stochastic_density_noise_std != 0.0:
         raise VoxeError("stochastic_density_noise_std != 0 is not supported by the HIP renderer")
     num_rays = rays.origins.shape[0]
-    width = 0
-    if rays.image_shape is not None and rays.image_shape[0] * rays.image_shape[1] == num_rays:
-        width = int(rays.image_shape[1])
+    # image-ordered rays: one image (R == H * W) or a multi-view batch of K images of that shape, one after the other
+    # (collate_rays of flattened cameras that all carry the same image_shape): ONE launch, 2-D pixel tiles per camera
+    width = height = 0
+    if rays.image_shape is not None and num_rays > 0:
+        per_image = int(rays.image_shape[0]) * int(rays.image_shape[1])
+        if per_image > 0 and num_rays % per_image == 0:
+            width = int(rays.image_shape[1])
+            height = int(rays.image_shape[0]) if num_rays != per_image else 0
     return _ops.RenderParams(
         num_samples=int(cfg.num_samples_per_ray),
         near=float(cfg.camera_bounds[0]),
@@ -86,6 +91,7 @@ def _render_params(voxel_grid: VoxelGrid, rays: Rays, cfg: SHVoxGridRenderConfig
         render_diffuse=bool(cfg.render_diffuse),
         term_eps=_TERM_EPS,
         image_width=width,
+        image_height=height,
     )
 
 

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # VoxeStatus
 OK = 0
@@ -66,6 +66,8 @@ class VoxeRenderCfg(C.Structure):
         ("rng_offset", C.c_uint64),
         ("reuse_packed_grid", C.c_int32),
         ("image_width", C.c_int32),
+        ("image_height", C.c_int32),
+        ("deterministic", C.c_int32),
         ("ray_state_valid", C.c_int32),
     ]
 

@@ -68,6 +68,8 @@ def make_render_cfg(
     reuse_packed_grid: bool = False,
     image_width: Optional[int] = None,
     ray_state_valid: bool = False,
+    image_height: Optional[int] = None,
+    deterministic: bool = False,
 ) -> abi.VoxeRenderCfg:
     c = abi.VoxeRenderCfg()
     c.num_samples = int(num_samples)
@@ -84,5 +86,7 @@ def make_render_cfg(
     c.rng_offset = int(rng_offset) & 0xFFFFFFFFFFFFFFFF
     c.reuse_packed_grid = int(bool(reuse_packed_grid))
     c.image_width = int(image_width or 0)
+    c.image_height = int(image_height or 0)
+    c.deterministic = int(bool(deterministic))
     c.ray_state_valid = int(bool(ray_state_valid))
     return c

@@ -36,6 +36,8 @@ class RenderParams:
     render_diffuse: bool = False
     term_eps: float = 0.0
     image_width: int = 0
+    image_height: int = 0     # > 0 (with image_width): the rays are K = R / (H * W) images, one after the other
+    deterministic: bool = False   # backward in 64-bit fixed point: bit-reproducible (test / race-check mode)
 
 
 class Workspace:
@@ -88,7 +90,8 @@ def _descs(spec: GridSpec, params: RenderParams, densities, features, seed, rng_
                        spec.density_scale, spec.density_pre_act, spec.density_post_act, spec.feature_kind)
     c = make_render_cfg(params.num_samples, params.near, params.far, params.perturb,
                         params.linear_disparity, params.aabb_clip, params.white_bkgd, params.sh_degree,
-                        params.render_diffuse, params.term_eps, seed, rng_offset, reuse, params.image_width)
+                        params.render_diffuse, params.term_eps, seed, rng_offset, reuse, params.image_width,
+                        image_height=params.image_height, deterministic=params.deterministic)
     return g, c
 
 
