@@ -581,6 +581,59 @@ def g15_attention_maps():
     save("attention_maps.npz", **out)
 
 
+def g16_sds_boundary():
+    """SDS boundary a19: the REFERENCE's thre3d_atom/thre3d_reprs/sd.py (scoreDistillationLoss.training_step :365-385 ->
+    StableDiffusion.train_step :174-234 -> SpecifyGradient :20-34) executed on the tiny stand-in SD stack of
+    tests/sds_standins.py (diffusers / weights are absent here).  Recorded per step: the rendered colours handed in, the
+    direction word, every random draw (timestep, VAE sample noise, diffusion noise), the returned loss, the gradient that
+    reaches the colours, the max-step ratio after the schedule.  tests/test_sds_boundary.py replays the draws through
+    the build's sd.py."""
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), ""))      # tests/
+    import sds_standins as st  # noqa: E402
+
+    h, w = 20, 28
+    out = {"hw": np.array([h, w])}
+    with st.installed():
+        from thre3d_atom.thre3d_reprs import sd as ref_sd  # noqa: E402
+
+        torch.manual_seed(16)
+        guide = ref_sd.scoreDistillationLoss(torch.device("cpu"), "a yarn doll", t_sched_start=2, t_sched_freq=2,
+                                             t_sched_gamma=0.5, directional=True)
+        plain = ref_sd.scoreDistillationLoss(torch.device("cpu"), "a yarn doll", directional=False)
+        directions = ["front", "side", "overhead", "back", "side", "front"]   # (step 6: the 0.22 floor of the ratio)
+        n_steps = len(directions)
+        for step in range(1, n_steps + 1):
+            colour = torch.sigmoid(torch.randn(h * w, 3)).requires_grad_(True)
+            with st.RandomTape(record=True) as tape:
+                loss = guide.training_step(colour, h, w, directions=[directions[step - 1]], global_step=step)
+                loss.backward()
+            out[f"s{step}_colour"] = np_(colour)
+            out[f"s{step}_grad"] = np_(colour.grad)
+            out[f"s{step}_loss"] = np_(loss)
+            out[f"s{step}_ratio"] = np.array(guide.get_current_max_step_ratio())
+            out[f"s{step}_max_step"] = np.array(guide.sd_model.max_step)
+            for i, d in enumerate(tape.draws):
+                out[f"s{step}_draw{i}"] = d.numpy()
+            out[f"s{step}_ndraws"] = np.array(len(tape.draws))
+        # non-directional guidance with a per-call log-variance (sd.py:226-227).  (One image per call: train_step pairs the
+        # [uncond, text] embeddings with cat([latents] * 2), so the reference itself only works for a batch of one.)
+        colour = torch.sigmoid(torch.randn(h * w, 3)).requires_grad_(True)
+        logvar = torch.tensor(0.3)
+        with st.RandomTape(record=True) as tape:
+            loss = plain.training_step(colour, h, w, global_step=7, logvars=logvar)
+            loss.backward()
+        out["b_colour"], out["b_grad"], out["b_logvar"] = np_(colour), np_(colour.grad), np_(logvar)
+        for i, d in enumerate(tape.draws):
+            out[f"b_draw{i}"] = d.numpy()
+        out["b_ndraws"] = np.array(len(tape.draws))
+        out["directions"] = np.array(directions)
+        out["steps"] = np.array(n_steps)
+        out["num_tokens"] = np.array(guide.sd_model.get_num_tokens("a yarn doll"))
+        out["text_front"] = np_(guide.text_encodings["front"])
+        out["alphas"] = np_(guide.sd_model.alphas)
+    save("sds_boundary.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -597,3 +650,4 @@ if __name__ == "__main__":
     g13_refinement()
     g14_edit_trajectory()
     g15_attention_maps()
+    g16_sds_boundary()
