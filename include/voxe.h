@@ -102,6 +102,10 @@ typedef struct VoxeRenderCfg {
                                  workspace (voxe_workspace_bytes accounts for it).  Image-ordered rays
                                  (image_width > 0), SH degree 0 / render_diffuse / attention grids; other
                                  configurations return VOXE_ERR_UNSUPPORTED.  0: float atomics (default).          */
+  int32_t linear_grad;        /* voxe_render_bwd_acc(_into) only.  1: the gradient region is written in
+                                 VOXE_GRAD_LINEAR whatever backward kernel runs (the line-dense scatter of small
+                                 unordered batches otherwise prefers VOXE_GRAD_BRICKED, -7 % on that kernel): lets a
+                                 caller accumulate ANY mix of renders into one optimiser step.                     */
   int32_t ray_state_valid;    /* backward only. 1: `workspace` still holds the per-ray depth-segment
                                  states (transmittance + partial sums every VOXE_SEGMENT_SAMPLES
                                  samples) written by voxe_render_fwd for EXACTLY these rays / cfg /
@@ -274,6 +278,21 @@ int voxe_render_bwd_acc(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                         const float* d_colour, const float* d_depth, const float* d_acc,
                         int32_t want_densities, int32_t want_features, int32_t zero_first, int32_t* grad_layout,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the gradient region of ANOTHER workspace of the same grid as the destination (grad_workspace; NULL =
+ * `workspace` itself): two renders of one optimiser step that run in different workspaces -- each keeps its own
+ * packed grid and per-ray states, e.g. the specular and the diffuse render of a reconstruction iteration
+ * (modules/trainers.py:316,333) -- then sum into ONE gradient region that voxe_grid_adam_step consumes.            */
+int voxe_render_bwd_acc_into(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
+                             const float* rays_o, const float* rays_d, int64_t R, const float* jitter,
+                             const float* colour, const float* depth, const float* acc,
+                             const float* d_colour, const float* d_depth, const float* d_acc,
+                             int32_t want_densities, int32_t want_features, int32_t zero_first, int32_t* grad_layout,
+                             void* workspace, size_t workspace_bytes, void* grad_workspace, size_t grad_workspace_bytes,
+                             void* stream);
+/* layout the backward of (grid, cfg, R) would write: VOXE_GRAD_LINEAR / VOXE_GRAD_BRICKED (VOXE_GRAD_ANY for R == 0), or
+ * a negative VOXE_ERR_* below -1 for invalid arguments -- lets a caller that accumulates several renders into one step
+ * check that they agree BEFORE running one                                                                          */
+int voxe_render_bwd_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R);
 size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid);  /* byte offset / size of the gradient region, e.g. */
 size_t voxe_workspace_grad_bytes(const VoxeGridDesc* grid);   /* for the multi-GPU all-reduce between the two calls */
 int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x_begin, int32_t x_end,

@@ -169,9 +169,13 @@ def _sharded_worker(rank, world, port, results):
 
     assert parallel.slab_of(8, 1, 2) == (4, 8) and parallel.slab_of(8, 0, 2, 2) == (0, 4)
     assert parallel.slab_of(6, 0, 2, 2) is None and parallel.slab_of(5, 0, 2) is None
+    assert parallel.slabs_of(5, 2) == [(0, 3), (3, 5)] and parallel.slabs_of(6, 2, 2) == [(0, 4), (4, 6)]
     modes = {}
-    for name, (X, Y, Z, F, layout) in {"linear": (6, 5, 3, 3, 0), "bricked": (8, 5, 3, 3, 1), "bricked_odd_x": (6, 4, 4, 1, 1),
-                                       "indivisible": (5, 4, 3, 3, 0)}.items():
+    cases = {"linear": (6, 5, 3, 3, 0), "bricked": (8, 5, 3, 3, 1), "bricked_odd_x": (6, 4, 4, 1, 1), "indivisible": (5, 4, 3, 3, 0)}
+    if world > 2:   # (the 8-rank run: planes that do not divide, fewer planes than ranks, an odd bricked extent)
+        cases = {"linear": (16, 3, 2, 3, 0), "indivisible": (10, 3, 2, 3, 0), "fewer_planes_than_ranks": (5, 4, 3, 1, 0),
+                 "bricked": (16, 4, 2, 3, 1), "bricked_odd_x": (13, 3, 3, 3, 1)}
+    for name, (X, Y, Z, F, layout) in cases.items():
         C = F + 1
         gen = torch.Generator().manual_seed(3)
         dens0, feat0 = torch.randn(X, Y, Z, 1, generator=gen), torch.randn(X, Y, Z, F, generator=gen)
@@ -183,7 +187,14 @@ def _sharded_worker(rank, world, port, results):
             _CpuOps.store_gradient(rws, sum(per_rank[1:], per_rank[0]), layout)
             _CpuOps.grid_adam_step_(None, rd, rf, layout, rws, k + 1, 0.05, rm[0], rm[1])
         # this rank of the sharded job: every exchange must give the single-process result (2 ranks: a + b is exact in
-        # any order), and so must whatever autotune() picks
+        # any order; more ranks: the gradients are small integers, exact in any order), and so must whatever autotune() picks
+        if world > 2:
+            grads = [[torch.randint(-8, 9, (X, Y, Z, C), generator=gen).float() for _ in range(world)] for _ in range(3)]
+            rd, rf, rws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
+            rm = ((torch.zeros_like(rd), torch.zeros_like(rd)), (torch.zeros_like(rf), torch.zeros_like(rf)))
+            for k, per_rank in enumerate(grads):
+                _CpuOps.store_gradient(rws, sum(per_rank[1:], per_rank[0]), layout)
+                _CpuOps.grid_adam_step_(None, rd, rf, layout, rws, k + 1, 0.05, rm[0], rm[1])
         for exchange in ("reduce-scatter", "all-to-all", "all-reduce", "auto"):
             d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
             opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps,
@@ -206,7 +217,10 @@ def _sharded_worker(rank, world, port, results):
             opt.gather_parameters()
             assert torch.equal(d, rd) and torch.equal(f, rf), (name, exchange)
             if exchange == "all-to-all" and name in ("linear", "bricked"):
-                assert opt.mode.startswith("all-to-all")
+                assert opt.mode.startswith("all-to-all +")
+            if exchange in ("all-to-all", "reduce-scatter") and name not in ("linear", "bricked"):
+                assert opt.mode.startswith("all-to-all (uneven slabs)")      # no fall-back to a replicated step
+            assert opt.exchange_steps == len(grads) and opt.read_exchange_ms() == 0.0      # (CPU tensors: no device timing)
             if exchange == "all-reduce":
                 assert opt.mode.startswith("all-reduce")
         d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
@@ -220,23 +234,25 @@ def _sharded_worker(rank, world, port, results):
             assert float(ws.grad.abs().max()) == 0.0
         modes[name] = opt.mode
         assert torch.equal(ws.packed, rws.packed), name
-        x0, x1 = parallel.slab_of(X, rank, world, 2 if layout == 1 else 1) or (0, X)
+        x0, x1 = parallel.slabs_of(X, world, 2 if layout == 1 else 1)[rank]
         assert torch.equal(d[x0:x1], rd[x0:x1]) and torch.equal(f[x0:x1], rf[x0:x1]), name
-        if opt.mode.startswith("reduce-scatter") and world > 1:
+        if world > 1:
             other = slice(0, x0) if x0 > 0 else slice(x1, X)
             assert torch.equal(d[other], dens0[other]), "a rank must not touch the raw parameters outside its slab"
         opt.gather_parameters()
         assert torch.equal(d, rd) and torch.equal(f, rf), name
     assert modes["linear"].startswith("reduce-scatter") and modes["bricked"].startswith("reduce-scatter")
-    assert modes["bricked_odd_x"].startswith("all-reduce")       # 6 x-planes = 3 brick pairs: not divisible by 2 ranks
-    assert modes["indivisible"].startswith("all-reduce")
+    assert modes["bricked_odd_x"].startswith("all-to-all (uneven slabs)")    # e.g. 6 x-planes = 3 brick pairs on 2 ranks
+    assert modes["indivisible"].startswith("all-to-all (uneven slabs)")
+    assert opt.probe_exchanges() == {"reduce-scatter": True, "all-to-all": True, "all-reduce": True}
     results[rank] = True
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_rank_sharded_grid_adam():
-    world = 2
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_grid_adam_ranks(world):
+    """world 2 and world 8 (the driver's N = 8 job: x-planes that do not divide, fewer planes than ranks)"""
     port = _free_port()
     ctx = mp.get_context("spawn")
     with ctx.Manager() as manager:
@@ -245,6 +261,6 @@ def test_two_rank_sharded_grid_adam():
         for p in procs:
             p.start()
         for p in procs:
-            p.join(100)
+            p.join(200)
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         assert len(results) == world

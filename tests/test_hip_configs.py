@@ -326,3 +326,72 @@ def test_deterministic_backward_attention_grid_and_unsupported_cases():
     assert rel_l2(a[1], rf) < GRAD_TOL and rel_l2(a[0], rd) < GRAD_TOL
     with pytest.raises(VoxeError):      # unordered rays have no deterministic path
         gh.hip_backward(grid, cfg, o, d, ga, deterministic=True)
+
+
+# ---- space-binned backward (voxe_render_region.hip) forced onto small cases: every variant against the oracle ---------------
+def _region_env(monkeypatch, image_too=False):
+    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
+    if image_too:
+        monkeypatch.setenv("VOXE_REGION_IMAGE_RATIO", "0")
+
+
+@pytest.mark.parametrize("case", ["sh0_jitter", "sh0_clip_lindisp", "attn", "diffuse_sh1", "tiny_grid", "image_ordered",
+                                  "density_only", "features_only", "jitter_tensor"])
+def test_region_backward_variants_vs_oracle(case, monkeypatch):
+    _region_env(monkeypatch, image_too=(case == "image_ordered"))
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    dims = (5, 6, 7) if case == "tiny_grid" else (40, 33, 48)
+    nfeat = 12 if case == "diffuse_sh1" else (1 if case == "attn" else 3)
+    dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
+    feat = rng.uniform(-1, 1, (*dims, nfeat)).astype(np.float32)
+    grid = vo.Grid(dens, feat, [(-1.5, 1.5), (-1.2, 1.3), (-1.5, 1.4)], 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS,
+                   abi.FEAT_ATTN if case == "attn" else abi.FEAT_SH)
+    hw = 44
+    o, d = _rays(hw, 7)
+    if case != "image_ordered":
+        perm = rng.permutation(o.shape[0])[:1500]
+        o, d = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm])
+    kw = dict(white_bkgd=True)
+    jit = None
+    if case in ("sh0_jitter", "attn", "image_ordered"):
+        kw.update(perturb=True, seed=5, rng_offset=9)
+    if case == "sh0_clip_lindisp":
+        kw.update(aabb_clip=True)
+    if case == "diffuse_sh1":
+        kw.update(sh_degree=1, render_diffuse=True)
+    if case == "jitter_tensor":
+        kw.update(perturb=True)
+        jit = rng.random((o.shape[0], 70)).astype(np.float32)
+    cfg = make_render_cfg(70, NEAR, FAR, **kw)
+    cout = 1 if case == "attn" else 3
+    gc = rng.standard_normal((o.shape[0], cout)).astype(np.float32)
+    gdep = (0.2 * rng.standard_normal(o.shape[0])).astype(np.float32)
+    over = dict(image_width=hw) if case == "image_ordered" else {}
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, jitter=jit, rng=(5, 9), **over)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, jitter=jit)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (case, rel_l2(gd, rd), rel_l2(gf, rf))
+    if case in ("density_only", "features_only"):
+        # one tensor frozen: the other's gradient is unchanged
+        from voxe_hip import ops
+        dt, ft = gh.t(grid.densities, case == "density_only"), gh.t(grid.features, case == "features_only")
+        c, dep, _, _ = ops.render(gh.spec_of(grid), gh.params_of(cfg), dt, ft, gh.t(o), gh.t(d), None, rng=(5, 9))
+        ((c * gh.t(gc)).sum() + (dep[:, 0] * gh.t(gdep)).sum()).backward()
+        got, ref = (gh.n(dt.grad), rd) if case == "density_only" else (gh.n(ft.grad), rf)
+        assert rel_l2(got, ref) < GRAD_TOL
+
+
+def test_region_backward_equals_scatter_backward_on_a_random_batch(monkeypatch):
+    """same rays through the space-binned backward and through the line-dense scatter it replaces for large batches"""
+    grid = _grid(96, "random")
+    o, d = _rays(300, 9)
+    sel = np.random.default_rng(2).permutation(o.shape[0])[:20000]
+    o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
+    cfg = make_render_cfg(128, NEAR, FAR, perturb=True, white_bkgd=True, seed=1, rng_offset=1)
+    gc = np.random.default_rng(3).standard_normal((o.shape[0], 3)).astype(np.float32)
+    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
+    a = gh.hip_backward(grid, cfg, o, d, gc, rng=(1, 1))
+    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
+    b = gh.hip_backward(grid, cfg, o, d, gc, rng=(1, 1))
+    assert rel_l2(a[0], b[0]) < 2e-5 and rel_l2(a[1], b[1]) < 2e-6, (rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(b[0], rd) < GRAD_TOL and rel_l2(b[1], rf) < GRAD_TOL

@@ -283,7 +283,8 @@ def test_holdout_evaluation_psnr():
     assert good["psnr"] > 30.0 and bad["psnr"] < 25.0 and good["psnr"] > bad["psnr"] + 10.0, (good, bad)
 
 
-def test_edit_trajectory_matches_reference_run():
+@pytest.mark.parametrize("optimizer", ["voxe_adam", "fused_grid_adam"])
+def test_edit_trajectory_matches_reference_run(optimizer):
     """The reference's own 12-step edit run (render_rays -> tint loss -> torch Adam; tests/golden/edit_trajectory.npz)
     repeated through the product API (HIP forward / backward / Adam): same losses, and the edited frames agree far
     inside BASELINE.json's bar (1e-3 L2, PSNR >= 40 dB)."""
@@ -302,7 +303,12 @@ def test_edit_trajectory_matches_reference_run():
     cams = [flatten_rays(cast_rays(intr, CameraPose(torch.from_numpy(z["rot"][i]), torch.from_numpy(z["trans"][i])),
                                    device=DEV)) for i in range(3)]
     tint = torch.from_numpy(z["tint"]).to(DEV)
-    opt = VoxeAdam([{"params": vm.thre3d_repr.parameters(), "lr": float(z["lr"])}], betas=(0.9, 0.999))
+    if optimizer == "fused_grid_adam":   # deferred-gradient mode: the render gradient never leaves the kernels' workspace
+        from thre3d_atom.modules.optim import FusedGridAdam
+
+        opt = FusedGridAdam(vm.thre3d_repr, lr=float(z["lr"]), betas=(0.9, 0.999))
+    else:
+        opt = VoxeAdam([{"params": vm.thre3d_repr.parameters(), "lr": float(z["lr"])}], betas=(0.9, 0.999))
     for step in range(int(z["steps"])):
         col = vm.render_rays(cams[step % 3]).colour
         loss = ((col - tint) ** 2).mean()
@@ -310,6 +316,8 @@ def test_edit_trajectory_matches_reference_run():
         loss.backward()
         opt.step()
         assert abs(float(loss.detach()) - float(z["losses"][step])) < 1e-6, step
+        if optimizer == "fused_grid_adam":
+            assert vm.thre3d_repr.densities.grad is None and vm.thre3d_repr.features.grad is None
     with torch.no_grad():
         for i in range(3):
             frame = vm.render_rays(cams[i]).colour.reshape(intr.height, intr.width, 3).cpu().numpy()
@@ -345,3 +353,57 @@ def test_selected_pixel_rays_equal_cast_collate_select():
     assert torch.equal(got_rays.origins, want_rays.origins)
     assert torch.equal(got_rays.directions, want_rays.directions)
     assert torch.equal(got_pix, want_pix)
+
+
+def test_fused_grid_adam_equals_voxe_adam_on_a_trainer_shaped_loop():
+    """two renders per iteration (specular + diffuse of one random-ray batch, the second in the sibling workspace) + a TV
+    regulariser through autograd + an LR schedule: FusedGridAdam (gradient left in the workspace, one fused pass) lands
+    on the parameters of the ordinary path (.grad tensors + VoxeAdam per tensor); also an image-ordered render per
+    iteration whose backward writes the OTHER gradient layout (falls back to .grad and is added by the same pass)"""
+    from thre3d_atom.modules.optim import FusedGridAdam
+    from thre3d_atom.modules.sds_trainer import _tv_loss_on_grid
+    from thre3d_atom.rendering.volumetric.render_interface import Rays
+    from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+
+    def run(fused):
+        torch.manual_seed(0)
+        g = torch.Generator().manual_seed(3)
+        dens = torch.empty(24, 24, 24, 1).uniform_(-1, 1, generator=g)
+        feat = torch.empty(24, 24, 24, 3).uniform_(-1, 1, generator=g)
+        vg = VoxelGrid(dens, feat, VoxelSize(3.0 / 24, 3.0 / 24, 3.0 / 24), density_preactivation=torch.nn.Identity(),
+                       density_postactivation=torch.nn.Softplus(), expected_density_scale=4.0, tunable=True)
+        vm = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(48, CameraBounds(1.8, 6.6), white_bkgd=True,
+                                                                            perturb_sampled_points=False), device=DEV)
+        grid = vm.thre3d_repr
+        opt = FusedGridAdam(grid, lr=0.02) if fused else VoxeAdam([{"params": grid.parameters(), "lr": 0.02}])
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.5)
+        intr = CameraIntrinsics(40, 40, 55.0)
+        losses = []
+        for it in range(6):
+            rays = flatten_rays(cast_rays(intr, pose_spherical(40.0 * it, 30.0, 4.0311), device=DEV))
+            pick = torch.randperm(1600, generator=g)[:700].to(DEV)
+            batch = Rays(rays.origins[pick].contiguous(), rays.directions[pick].contiguous())
+            target = torch.rand(700, 3, generator=g).to(DEV)
+            loss = torch.nn.functional.l1_loss(vm.render_rays(batch).colour, target)
+            loss = loss + torch.nn.functional.l1_loss(vm.render_rays(batch, render_diffuse=True).colour, target)
+            loss = loss + 0.1 * _tv_loss_on_grid(torch.relu(grid.densities)) + 0.05 * _tv_loss_on_grid(grid.features)
+            if it % 2 == 1:   # an image-ordered render on top (LDS-window backward: the linear gradient layout)
+                loss = loss + vm.render_rays(rays).colour.mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if it == 2:
+                sched.step()
+            losses.append(float(loss.detach()))
+        if fused:
+            opt.detach()
+            assert grid.voxe_workspace("sh").deferred is None
+        return losses, grid.densities.detach().cpu().numpy(), grid.features.detach().cpu().numpy()
+
+    l_ref, d_ref, f_ref = run(False)
+    l_fus, d_fus, f_fus = run(True)
+    np.testing.assert_allclose(l_fus, l_ref, rtol=0, atol=2e-6)
+    # 6 Adam steps of 0.02 / 0.01: voxels with rounding-noise gradients may differ by a fraction of a step
+    assert np.linalg.norm(f_fus - f_ref) / np.linalg.norm(f_ref) < 2e-4
+    assert np.linalg.norm(d_fus - d_ref) / np.linalg.norm(d_ref) < 2e-3

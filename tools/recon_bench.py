@@ -10,7 +10,7 @@ sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), RO
 
 import torch  # noqa: E402
 from synth import FAR, NEAR, RADIUS, focal_for, random_grid, synth_pose_angles  # noqa: E402
-from thre3d_atom.modules.optim import VoxeAdam  # noqa: E402
+from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam  # noqa: E402
 from thre3d_atom.modules.volumetric_model import VolumetricModel  # noqa: E402
 from thre3d_atom.rendering.volumetric.utils.misc import (  # noqa: E402
     cast_rays,
@@ -41,7 +41,10 @@ def main():
         poses.append(torch.cat([p.rotation, p.translation], dim=-1))
     poses = torch.stack(poses).to(dev)
     images = torch.rand(NV, 3, HW, HW, device=dev)
-    opt = VoxeAdam([{"params": vm.thre3d_repr.parameters(), "lr": 0.03}])
+    if os.environ.get("RECON_SPLIT_ADAM"):   # the ordinary path: .grad tensors (un-pack) + one Adam kernel per tensor
+        opt = VoxeAdam([{"params": vm.thre3d_repr.parameters(), "lr": 0.03}])
+    else:                                    # what the trainer uses: gradient left in the workspace + one fused pass
+        opt = FusedGridAdam(vm.thre3d_repr, lr=0.03)
     gen = torch.Generator().manual_seed(0)
     marks = {}
 

@@ -101,6 +101,7 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->image_height = c->image_width > 0 ? (c->image_height > 0 ? c->image_height : (int)(R / c->image_width)) : 0;
   dc->map_mode = tile_map_mode(c->image_width);
   dc->R = R;
+  dc->linear_grad = c->linear_grad;
   dc->seg_len = seg_len_for(R);
 }
 
@@ -108,7 +109,8 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, seg_off, src_off, det_off, fwd_total, total, total_with_src;
+  size_t packed_off, grad_off, state_off, seg_off, src_off, det_off, region_off, fwd_total, total, total_with_src;
+  bool region;   // the space-binned backward applies to (grid, cfg, R): its scratch is part of the workspace
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t nvox = (size_t)g->X * g->Y * g->Z;
@@ -136,6 +138,19 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   // deterministic mode: the fixed-point gradient and its scales behind everything else
   l.det_off = l.total_with_src;
   if (c && c->deterministic) l.total_with_src += det_bytes((long long)nvox, g->F + 1);
+  // space-binned backward (voxe_render_region.hip): per-sample sources + segment tables
+  l.region_off = l.total_with_src;
+  l.region = false;
+  if (c && R > 0 && !c->deterministic && !force_no_tile_bwd()) {
+    Variant v;
+    if (validate(g, c, R, &v) == VOXE_OK) {
+      DevGrid dg; DevCfg dc;
+      make_dev(g, c, R, v, &dg, &dc);
+      const bool tiled = tile_bwd_supported(dc, c->sh_degree);
+      l.region = region_bwd_supported(dg, dc, c->sh_degree, c->render_diffuse, tiled);
+      if (l.region) l.total_with_src += region_scratch_bytes(g->X, g->Y, g->Z, R, c->num_samples);
+    }
+  }
   return l;
 }
 
@@ -294,11 +309,12 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
                       const float* rays_d, int64_t R, const float* jitter, const float* colour, const float* depth,
                       const float* acc, const float* d_colour, const float* d_depth, const float* d_acc, bool want_d,
                       bool want_f, bool zero_first, bool* bricked, void* workspace, size_t workspace_bytes,
-                      hipStream_t s) {
+                      hipStream_t s, void* grad_workspace = nullptr, size_t grad_workspace_bytes = 0) {
   const WsLayout l = ws_layout(grid, cfg, R);
   if (!workspace || workspace_bytes < l.total) return VOXE_ERR_WORKSPACE;
+  if (grad_workspace && grad_workspace_bytes < l.state_off) return VOXE_ERR_WORKSPACE;   // (packed grid + gradient region)
   float* packed = (float*)((char*)workspace + l.packed_off);
-  float* gpacked = (float*)((char*)workspace + l.grad_off);
+  float* gpacked = (float*)((char*)(grad_workspace ? grad_workspace : workspace) + l.grad_off);
   float* state = (float*)((char*)workspace + l.state_off);
   if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
   if (zero_first) {
@@ -323,6 +339,7 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
       a.ray_state = state;
     }
     const bool det = cfg->deterministic != 0;
+    const bool region = l.region && !det && workspace_bytes >= l.total_with_src;
     if ((tiled || packed_bwd || det) && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
@@ -336,11 +353,14 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
       if (hipMemsetAsync(a.gdet, 0, det_bytes((long long)grid->X * grid->Y * grid->Z, grid->F + 1), s) != hipSuccess)
         return VOXE_ERR_LAUNCH;
       launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
+    } else if (region) {
+      a.ray_state = state;
+      launch_bwd_region(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, (char*)workspace + l.region_off, s);
     } else if (tiled)
       launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
     else if (packed_bwd) {
       launch_bwd_packed_scatter(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
-      *bricked = true;  // that kernel accumulates into the bricked layout
+      *bricked = !cfg->linear_grad;  // that kernel accumulates into the bricked layout unless asked otherwise
     } else
       launch_bwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
   }
@@ -393,6 +413,39 @@ int voxe_render_bwd_acc(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, cons
   if (rc) return rc;
   *grad_layout = R > 0 ? (bricked ? VOXE_GRAD_BRICKED : VOXE_GRAD_LINEAR) : VOXE_GRAD_ANY;
   return finish();
+}
+
+int voxe_render_bwd_acc_into(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o, const float* rays_d,
+                             int64_t R, const float* jitter, const float* colour, const float* depth, const float* acc,
+                             const float* d_colour, const float* d_depth, const float* d_acc, int32_t want_densities,
+                             int32_t want_features, int32_t zero_first, int32_t* grad_layout, void* workspace,
+                             size_t workspace_bytes, void* grad_workspace, size_t grad_workspace_bytes, void* stream) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  if (!grad_layout || (R > 0 && (!rays_o || !rays_d || !colour || !depth || !acc || !d_colour)))
+    return VOXE_ERR_NULL_POINTER;
+  bool bricked = false;
+  const int rc = render_bwd_common(grid, cfg, v, rays_o, rays_d, R, jitter, colour, depth, acc, d_colour, d_depth, d_acc,
+                                   want_densities != 0, want_features != 0, zero_first != 0, &bricked, workspace,
+                                   workspace_bytes, (hipStream_t)stream, grad_workspace, grad_workspace_bytes);
+  if (rc) return rc;
+  *grad_layout = R > 0 ? (bricked ? VOXE_GRAD_BRICKED : VOXE_GRAD_LINEAR) : VOXE_GRAD_ANY;
+  return finish();
+}
+
+int voxe_render_bwd_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st < -1 ? st : VOXE_ERR_BAD_SHAPE;
+  if (R == 0) return VOXE_GRAD_ANY;
+  DevGrid dg; DevCfg dc;
+  make_dev(grid, cfg, R, v, &dg, &dc);
+  if (cfg->deterministic) return VOXE_GRAD_LINEAR;
+  const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
+  const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
+  if (ws_layout(grid, cfg, R).region) return VOXE_GRAD_LINEAR;   // (given the workspace voxe_workspace_bytes asks for)
+  return (packed_bwd && !cfg->linear_grad) ? VOXE_GRAD_BRICKED : VOXE_GRAD_LINEAR;
 }
 
 size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid) {

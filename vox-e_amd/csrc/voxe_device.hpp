@@ -37,6 +37,7 @@ struct DevCfg {
   int image_height;           // rows of ONE image (image_width > 0); the launch holds R / (H * W) images back to back
   int map_mode;               // block -> tile mapping: 0 XCD bands, 1 linear, 2 tile rows interleaved over XCDs
   long long R;
+  int linear_grad;            // the scatter backward writes the linear gradient layout (VoxeRenderCfg::linear_grad)
   int seg_len;                // samples per depth segment of the segmented kernels (seg_len_for(R))
 };
 

@@ -34,6 +34,11 @@ namespace voxe {
 #ifndef VOXE_SCATTER_PEND
 #define VOXE_SCATTER_PEND 1
 #endif
+// slot of voxel (x, y, z) in the gradient region: 2x2x2 bricks by default, the linear [X,Y,Z] order on request
+__device__ __forceinline__ long long grad_slot(const DevCfg& c, int x, int y, int z, int Y, int Z) {
+  return c.linear_grad ? ((long long)x * Y + y) * Z + z : brick_slot(x, y, z, Y, Z);
+}
+
 template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F>
 __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
           if (gv != 0.0f) {
             const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
             const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
-            atomicAdd(gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM + mem, gv);
+            atomicAdd(gpacked + grad_slot(c, x, y, z, g.Y, g.Z) * CM + mem, gv);
           }
         }
       }
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
             // (a size-1 axis has both corners on the same voxel; make_cell gives the second one weight 0)
             const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
             const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
-            atomicAdd(gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM + mem, gv * w);
+            atomicAdd(gpacked + grad_slot(c, x, y, z, g.Y, g.Z) * CM + mem, gv * w);
           }
         }
       }
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
         const float w = kPend ? 1.0f : s_w[j][s];   // (pending footprints carry their weights already)
         const int x = min(b + (j & 1), g.X - 1), y = min(s_cell[1][s] + ((j >> 1) & 1), g.Y - 1);
         const int z = min(s_cell[2][s] + (j >> 2), g.Z - 1);
-        float* __restrict__ texel = gpacked + brick_slot(x, y, z, g.Y, g.Z) * CM;
+        float* __restrict__ texel = gpacked + grad_slot(c, x, y, z, g.Y, g.Z) * CM;
 #pragma unroll
         for (int chunk = 0; chunk < (NG + 7) / 8; ++chunk) {
           const int q = chunk * 8 + cc;             // gradient channel: (colour ch, coefficient jj) or, last, the density

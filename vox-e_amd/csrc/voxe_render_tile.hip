@@ -60,6 +60,12 @@ __device__ __forceinline__ int ring_slot(int key) {
 #ifndef VOXE_TILE_CROT
 #define VOXE_TILE_CROT(lane) (lane)
 #endif
+#ifndef VOXE_TILE_SLOTINC
+#define VOXE_TILE_SLOTINC 0
+#endif
+#ifndef VOXE_TILE_F64MUL
+#define VOXE_TILE_F64MUL 0
+#endif
 // LDS mapping constants, swept on hardware with tools/variants.py + tools/ab_variants.sh (three cameras): channel
 // rotation by lane & 3 instead of (lane >> 1) & 3: backward -6.5 %; layer rotation 9 / 17 / 25 ~ equal, 21 +0.4 %;
 // plane padding 6 ~ 10 < 2 < 4 << 8 (+35 %: bank aliasing)
@@ -458,6 +464,9 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
           }
 
           if (MODE != 1 && any) {
+#if VOXE_TILE_SLOTINC
+            const int base_slot = ring_slot(w.base);   // wave-uniform (scalar unit)
+#endif
             // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
             const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
             float wm[2], wu[2], wv[2];
@@ -474,10 +483,19 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
             for (int s = 0; s < 2; ++s) {
               const int im = pm + s, key = w.sgn * im;
               const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
-              fits = fits && ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
+              const int dk = key - w.base;
+              fits = fits && ((unsigned)dk < (unsigned)kRing) && ((unsigned)a0 < (unsigned)(kLat - 1)) &&
                      ((unsigned)b0 < (unsigned)(kLat - 1));
-              lofs[s] = ring_slot(key) * kLayerSlots;
-              ab0[s] = a0 * kLat + b0 + Lat<KL>::rot_of(key);  // + the per-layer rotation of Lat::pos()
+#if VOXE_TILE_SLOTINC
+              // ring slot of a live layer = slot of the window base (wave-uniform) + its distance, wrapped once: no
+              // per-lane modulo (keys outside the ring give garbage here and take the `!fits` path, which recomputes)
+              int sl = base_slot + dk;
+              sl = sl >= kRing ? sl - kRing : sl;
+#else
+              const int sl = ring_slot(key);
+#endif
+              lofs[s] = sl * kLayerSlots;
+              ab0[s] = a0 * kLat + b0 + (KL == 8 ? VOXE_TILE_ROT * sl : 0);  // + the per-layer rotation of Lat::pos()
             }
             if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
               // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
@@ -510,14 +528,29 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   #pragma unroll
                 for (int j = 0; j < C; ++j) { gr[j] = gch[j]; poff[j] = j * kPlane; }
               }
+#if VOXE_TILE_F64MUL
+              double grd[C];   // products in double: 4 + 8 conversions per sample instead of 32 (one per product)
+  #pragma unroll
+              for (int ch = 0; ch < C; ++ch) grd[ch] = (double)gr[ch];
+#endif
   #pragma unroll
               for (int cc = 0; cc < 8; ++cc) {
                 const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;  // compile-time bits of this instruction
                 const float wgt = wmu[bm + 2 * bu] * (bv ? wvB : wvA);
                 const int idx = (bm ? lofB : lofA) + Lat<KL>::wrap(abu[bm + 2 * bu] + (bv ? vB : vA));
+#if VOXE_TILE_F64MUL
+                const double wgtd = (double)wgt;
+#endif
   #pragma unroll
                 for (int ch = 0; ch < C; ++ch) {
                   if (kAllCh || (ch < COUT && WANT_F) || (ch == COUT && WANT_D)) {
+#if VOXE_TILE_F64MUL
+                    if constexpr (!DET) {
+                      __hip_atomic_fetch_add(&win[poff[ch] + idx], grd[ch] * wgtd, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                      continue;
+                    }
+#endif
                     if constexpr (DET)
                       __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(win) + (poff[ch] + idx),
                                              det_quant(gr[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

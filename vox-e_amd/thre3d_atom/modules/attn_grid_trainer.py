@@ -17,7 +17,7 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from thre3d_atom.modules.optim import VoxeAdam
+from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam
 from thre3d_atom.modules.refinement_functions import calc_loss_on_attn_grid, get_edit_region
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
@@ -132,6 +132,7 @@ def refine_edited_relu_field(
     hemispherical_radius: float = HEMISPHERICAL_RADIUS_CONSTANT,   # distance of the random cameras: the reference hard-codes
     # 4.0311 (attn_grid_trainer.py:54,277); pass another value only as an explicit override
     saved_hemispherical_radius: Optional[float] = None,            # radius estimate stored in the checkpoints (no dataset)
+    fused_grid_step: bool = True,        # FusedGridAdam on the attention grids (gradient stays in the kernels' workspace)
 ) -> VolumetricModel:
     """Optimise the attention grids of `vol_mod_edit` / `vol_mod_object` (copies of the SDS-edited field), cut the
     edit region and write the refined field into `vol_mod_output` (returned).  Checkpoints as in the reference:
@@ -168,8 +169,12 @@ def refine_edited_relu_field(
     extra_info = {CAMERA_BOUNDS: camera_bounds, CAMERA_INTRINSICS: camera_intrinsics, HEMISPHERICAL_RADIUS: extra_radius}
 
     edit_grid, object_grid = vol_mod_edit.thre3d_repr, vol_mod_object.thre3d_repr
-    optimizer_edit = VoxeAdam([{"params": [edit_grid.attn], "lr": learning_rate}], betas=(0.9, 0.999))
-    optimizer_object = VoxeAdam([{"params": [object_grid.attn], "lr": learning_rate}], betas=(0.9, 0.999))
+    if fused_grid_step:
+        optimizer_edit = FusedGridAdam(edit_grid, lr=learning_rate, betas=(0.9, 0.999), kind="attn")
+        optimizer_object = FusedGridAdam(object_grid, lr=learning_rate, betas=(0.9, 0.999), kind="attn")
+    else:
+        optimizer_edit = VoxeAdam([{"params": [edit_grid.attn], "lr": learning_rate}], betas=(0.9, 0.999))
+        optimizer_object = VoxeAdam([{"params": [object_grid.attn], "lr": learning_rate}], betas=(0.9, 0.999))
     lr_scheduler_edit = torch.optim.lr_scheduler.ExponentialLR(optimizer_edit, gamma=lr_decay_gamma_per_stage)
 
     log.info(f"voxel grid resolution: {edit_grid.grid_dims} training images resolution: [{im_h} x {im_w}]")
@@ -228,6 +233,9 @@ def refine_edited_relu_field(
                 torch.save(vol_mod_object.get_save_info(extra_info=extra_info), model_dir / f"model_object_iter_{global_step}.pth")
         last = time.perf_counter()
 
+    if fused_grid_step:
+        optimizer_edit.detach()
+        optimizer_object.detach()
     # ---- graph cut and splice ----------------------------------------------------------------------------
     log.info("Starting Grid Refinement!")
     t0 = time.perf_counter()

@@ -40,3 +40,99 @@ class VoxeAdam(torch.optim.Optimizer):
                                 lr=group["lr"], beta1=beta1, beta2=beta2, eps=group["eps"])
                 torch.autograd.graph.increment_version(p)
         return loss
+
+
+class FusedGridAdam(torch.optim.Optimizer):
+    """`torch.optim.Adam` for the tensors of ONE VoxelGrid on top of the fused grid step (voxe_render_bwd_acc_into +
+    voxe_grid_adam_step): while it is attached, the backward of every render through the grid LEAVES the grid gradient in
+    the grid's workspace (kernel layout) and `step()` applies, in ONE streaming pass, the chain rule of the density
+    pre-activation, Adam on both tensors, the re-pack of the grid for the next render and the clearing of the gradient
+    (bit-identical parameters to un-pack + VoxeAdam per tensor: tests/test_hip_fused_step.py).  Gradients that reach the
+    parameters through autograd instead (regularisers: DCL, TV; renders whose kernel writes another gradient layout) sit
+    in `.grad` as usual and are added by the same pass.
+
+    The same arithmetic, schedulers and `state_dict` layout (`step`, `exp_avg`, `exp_avg_sq` per parameter) as the
+    reference's `torch.optim.Adam(params=[{"params": grid.parameters(), "lr": lr}], betas=(0.9, 0.999))`
+    (modules/trainers.py:247-255, modules/sds_trainer.py:200-203, modules/attn_grid_trainer.py:243-247).
+    `kind`: "sh" optimises (densities, features), "attn" the attention grid alone (densities frozen)."""
+
+    def __init__(self, voxel_grid, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, kind: str = "sh"):
+        if kind not in ("sh", "attn"):
+            raise ValueError("kind must be 'sh' or 'attn'")
+        self.grid, self.kind = voxel_grid, kind
+        if kind == "sh":
+            self._dens, self._feat = voxel_grid.densities, voxel_grid.features
+            params = [p for p in (self._dens, self._feat) if isinstance(p, torch.nn.Parameter) and p.requires_grad]
+        else:
+            self._dens, self._feat = voxel_grid.densities, voxel_grid.attn
+            params = [self._feat]
+        if not params:
+            raise ValueError("FusedGridAdam: the grid has no trainable tensors")
+        super().__init__([{"params": params}], dict(lr=lr, betas=betas, eps=eps))
+        self.spec = voxel_grid.voxe_grid_spec(attn=(kind == "attn"))
+        self.workspace = voxel_grid.voxe_workspace(kind)
+        train_d = any(p is self._dens for p in params)
+        train_f = any(p is self._feat for p in params)
+        self.workspace.deferred = _ops.DeferredGrad(want_densities=train_d, want_features=train_f)
+        self._train = (train_d, train_f)
+
+    def detach(self) -> None:
+        """leave the deferred-gradient mode (renders return ordinary .grad tensors again)"""
+        if self.workspace.deferred is not None and self.workspace.deferred.dirty:
+            self.workspace.invalidate()   # (an unconsumed gradient would otherwise leak into a later fused step)
+            _ops.workspace_grad_view(self.spec, self._dens, self._feat, self.workspace).zero_()
+        self.workspace.deferred = None
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        super().zero_grad(set_to_none=True)
+        d = self.workspace.deferred
+        if d is not None and d.dirty:          # a gradient nobody stepped on: clear the region
+            _ops.workspace_grad_view(self.spec, self._dens, self._feat, self.workspace).zero_()
+            d.dirty, d.layout = False, _ops.abi.GRAD_ANY
+
+    def _state_of(self, p):
+        state = self.state[p]
+        if not state:
+            state["step"] = 0
+            state["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return state
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        group = self.param_groups[0]
+        beta1, beta2 = group["betas"]
+        d = self.workspace.deferred
+        train_d, train_f = self._train
+        have_render_grad = d is not None and d.dirty and self.workspace.buf is not None
+        if not have_render_grad:
+            # no render gradient in the workspace this iteration (e.g. a regulariser-only step): per-tensor Adam
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self._state_of(p)
+                st["step"] += 1
+                _ops.adam_step_(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], st["step"], lr=group["lr"],
+                                beta1=beta1, beta2=beta2, eps=group["eps"])
+                torch.autograd.graph.increment_version(p)
+            return loss
+        st_d = self._state_of(self._dens) if train_d else None
+        st_f = self._state_of(self._feat) if train_f else None
+        step_no = 0
+        for st in (st_d, st_f):
+            if st is not None:
+                st["step"] += 1
+                step_no = st["step"]
+        extra_d = self._dens.grad.contiguous() if (train_d and self._dens.grad is not None) else None
+        extra_f = self._feat.grad.contiguous() if (train_f and self._feat.grad is not None) else None
+        _ops.grid_adam_step_(self.spec, self._dens, self._feat, d.layout, self.workspace, step_no, group["lr"],
+                             state_densities=None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
+                             state_features=None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]),
+                             extra_d_densities=extra_d, extra_d_features=extra_f, beta1=beta1, beta2=beta2,
+                             eps=group["eps"])
+        d.dirty, d.layout = False, _ops.abi.GRAD_ANY
+        return loss

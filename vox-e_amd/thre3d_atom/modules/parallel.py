@@ -118,12 +118,26 @@ def all_gather_rows(local: torch.Tensor, height: int, align: int = 8) -> torch.T
 
 
 def slab_of(extent: int, rank: int, world: int, align: int = 1):
-    """[begin, end) of rank's equal share of `extent` x-planes in multiples of `align`, or None when it does not
-    divide (collectives over slabs need equal sizes; the caller then falls back to the replicated step)."""
+    """[begin, end) of rank's EQUAL share of `extent` x-planes in multiples of `align`, or None when it does not divide
+    (reduce_scatter_tensor / all_gather_into_tensor need equal sizes; see slabs_of for the general split)."""
     if world < 1 or extent % (world * align) != 0:
         return None
     per = extent // world
     return rank * per, (rank + 1) * per
+
+
+def slabs_of(extent: int, world: int, align: int = 1) -> List[Tuple[int, int]]:
+    """[begin, end) of EVERY rank's share of `extent` x-planes, in units of `align` planes, as even as possible (the
+    first `units % world` ranks get one unit more; ranks beyond the number of units get an empty slab).  Equal to
+    slab_of() whenever that is defined."""
+    units = (extent + align - 1) // align
+    base, rem = divmod(units, world)
+    out, u = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((min(u * align, extent), min((u + n) * align, extent)))
+        u += n
+    return out
 
 
 class ShardedGridAdam:
@@ -137,11 +151,14 @@ class ShardedGridAdam:
           Same wire bytes as one all-reduce; the optimiser's HBM pass shrinks by `world`.
       "all-to-all"  the same with both collectives spelled as direct transfers: ONE all-to-all of the gradient slabs
           (point-to-point over every xGMI link at once instead of the library's ring) + a local sum over the `world`
-          received slabs, and the packed slabs sent to every peer as one batch of point-to-point operations.
-      "all-reduce"  all-reduce of the whole gradient region + the replicated full step (also the fallback whenever X is
-          not divisible by the world size).
-    `autotune()` times the three on the job's own ranks and links (dry steps before training: zero gradient + zero
-    moments leave every parameter bit-unchanged) and keeps the fastest -- the same choice on every rank.
+          received slabs, and the packed slabs sent to every peer as one batch of point-to-point operations.  Slabs may
+          be UNEVEN: when X is not divisible by the world size (5 planes on 2 ranks, 160 on 7, the odd plane pair of a
+          bricked gradient) "reduce-scatter" runs as this exchange too -- no fall-back to a replicated step.
+      "all-reduce"  all-reduce of the whole gradient region + the replicated full step.
+    `autotune()` times the exchanges this job's backend supports (probed once, on all ranks together) on the job's own
+    ranks and links (dry steps before training: zero gradient + zero moments leave every parameter bit-unchanged) and
+    keeps the fastest -- the same choice on every rank.  `exchange_ms` accumulates the device time of the exchange
+    part of every step (events on the launch stream), `exchange_steps` counts them.
     `gather_parameters()` makes the raw tensors whole again on every rank (checkpoints, upsampling between stages).
 
     `backend` is voxe_hip.ops; tests substitute a CPU stand-in with the same four functions."""
@@ -150,6 +167,7 @@ class ShardedGridAdam:
     _MODE_NAMES = {
         "reduce-scatter": "reduce-scatter + sharded step + all-gather of the packed grid",
         "all-to-all": "all-to-all + local sum + sharded step + point-to-point all-gather of the packed grid",
+        "all-to-all-uneven": "all-to-all (uneven slabs) + local sum + sharded step + point-to-point all-gather of the packed grid",
         "all-reduce": "all-reduce + replicated step",
     }
 
@@ -168,23 +186,35 @@ class ShardedGridAdam:
         self.exercise_collectives = exercise_collectives   # run the collectives even in a 1-rank group (bring-up)
         self.exchange = exchange
         self.tuned_ms = None        # autotune(): {exchange: milliseconds per dry step, max over ranks}
+        self.supported = None       # probe_exchanges(): which exchanges this backend runs (same answer on all ranks)
         self._shard = None
         self._recv = None
         self.mode = "single"
         self._sharded_ran = False
+        self._last_slabs = None
+        self.exchange_ms, self.exchange_steps = 0.0, 0
+        self._events = []           # (start, stop) pairs not read back yet
 
-    def _slab(self, grad_layout: int):
-        """(x_begin, x_end, floats per slab in the gradient region, floats per slab in the packed grid) or None"""
-        rank, world = world_info()
+    # ---- geometry ------------------------------------------------------------------------------------------------
+    def _dims(self):
         X, Y, Z = (int(v) for v in self.densities.shape[:3])
-        C = int(self.features.shape[-1]) + 1
+        return X, Y, Z, int(self.features.shape[-1]) + 1
+
+    def _slab_table(self, grad_layout: int):
+        """per rank: (x_begin, x_end, first float / float count in the gradient region, first / count in the packed grid)"""
+        _, world = world_info()
+        X, Y, Z, C = self._dims()
         bricked = grad_layout == 1   # VOXE_GRAD_BRICKED
-        xr = slab_of(X, rank, world, 2 if bricked else 1)
-        if xr is None:
-            return None
-        planes = xr[1] - xr[0]
-        g_per = (planes // 2) * ((Y + 1) // 2) * ((Z + 1) // 2) * 8 * C if bricked else planes * Y * Z * C
-        return xr[0], xr[1], g_per, planes * Y * Z * C
+        align = 2 if bricked else 1
+        table = []
+        for x0, x1 in slabs_of(X, world, align):
+            if bricked:
+                per_pair = ((Y + 1) // 2) * ((Z + 1) // 2) * 8 * C
+                g0, g1 = ((x0 + 1) // 2) * per_pair, ((x1 + 1) // 2) * per_pair   # (x0 is even, or == X for an empty slab)
+            else:
+                g0, g1 = x0 * Y * Z * C, x1 * Y * Z * C
+            table.append((x0, x1, g0, g1 - g0, x0 * Y * Z * C, (x1 - x0) * Y * Z * C))
+        return table
 
     def _collective(self) -> bool:
         _, world = world_info()
@@ -199,7 +229,24 @@ class ShardedGridAdam:
         if self._host_staged():
             torch.cuda.synchronize(self.densities.device)
 
-    def _run(self, workspace, grad_layout: int, exchange: str, step_no: int) -> str:
+    def _mark(self):
+        if not self.densities.is_cuda:
+            return None
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.densities.device))
+        return ev
+
+    def read_exchange_ms(self) -> float:
+        """mean device milliseconds per step spent between the end of the backward and the start of the next render that
+        is NOT the local optimiser kernel: gradient exchange + packed-grid exchange (0 for a single process)"""
+        for a, b, c, d in self._events:
+            d.synchronize()
+            self.exchange_ms += a.elapsed_time(b) + c.elapsed_time(d)
+        self._events = []
+        return self.exchange_ms / max(self.exchange_steps, 1)
+
+    # ---- one exchange + step -------------------------------------------------------------------------------------
+    def _run(self, workspace, grad_layout: int, exchange: str, step_no: int, timed: bool = False) -> str:
         """one exchange + optimiser step; returns the name of what ran"""
         rank, world = world_info()
         kw = dict(state_densities=self.state_densities, state_features=self.state_features, beta1=self.betas[0],
@@ -209,57 +256,118 @@ class ShardedGridAdam:
             self.ops.grid_adam_step_(*args, **kw)
             return "single"
         region = self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace)
-        slab = self._slab(grad_layout)
-        if slab is None or exchange == "all-reduce":
+        table = self._slab_table(grad_layout)
+        even = len({t[3] for t in table}) == 1 and len({t[5] for t in table}) == 1 and table[0][3] > 0
+        e0 = self._mark() if timed else None
+        if exchange == "all-reduce":
             self._fence()
             dist.all_reduce(region)
             self._fence()
+            e1 = self._mark() if timed else None
             self.ops.grid_adam_step_(*args, **kw)
+            if timed and e0 is not None:
+                self._events.append((e0, e1, e1, e1))
             return self._MODE_NAMES["all-reduce"]
-        x0, x1, g_per, p_per = slab
-        mine = region[rank * g_per: (rank + 1) * g_per]
+        x0, x1, g0, gn, p0, pn = table[rank]
+        mine = region[g0: g0 + gn]
         self._fence()
-        if exchange == "all-to-all":
-            if self._recv is None or self._recv.numel() != world * g_per:
-                self._recv = torch.empty(world * g_per, dtype=region.dtype, device=region.device)
-            dist.all_to_all_single(self._recv, region[: world * g_per])      # slab j of every rank -> rank j
-            torch.sum(self._recv.view(world, g_per), dim=0, out=mine)
+        direct = exchange == "all-to-all" or not even
+        if direct:
+            # slab j of every rank -> rank j (point-to-point over all links at once); sizes may differ between ranks
+            if self._recv is None or self._recv.numel() != world * gn:
+                self._recv = torch.empty(world * gn, dtype=region.dtype, device=region.device)
+            span = table[-1][2] + table[-1][3]
+            dist.all_to_all_single(self._recv, region[:span], output_split_sizes=[gn] * world,
+                                   input_split_sizes=[t[3] for t in table])
+            if gn > 0:
+                torch.sum(self._recv.view(world, gn), dim=0, out=mine)
         else:
-            if self._shard is None or self._shard.numel() != g_per:
-                self._shard = torch.empty(g_per, dtype=region.dtype, device=region.device)
-            dist.reduce_scatter_tensor(self._shard, region[: world * g_per])
+            if self._shard is None or self._shard.numel() != gn:
+                self._shard = torch.empty(gn, dtype=region.dtype, device=region.device)
+            dist.reduce_scatter_tensor(self._shard, region[: world * gn])
             mine.copy_(self._shard)
         self._fence()
+        e1 = self._mark() if timed else None
         # the step reads (and clears) the gradient in place: the summed slab is where the kernel expects it; clear what
         # this rank's own backward left in the other slabs
-        region[: rank * g_per].zero_()
-        region[(rank + 1) * g_per:].zero_()
-        self.ops.grid_adam_step_(*args, x_range=(x0, x1), **kw)
+        region[:g0].zero_()
+        region[g0 + gn:].zero_()
+        if x1 > x0:
+            self.ops.grid_adam_step_(*args, x_range=(x0, x1), **kw)
         packed = self.ops.workspace_packed_view(self.spec, self.densities, self.features, workspace)
         self._fence()
-        if exchange == "all-to-all":
+        e2 = self._mark() if timed else None
+        if direct:
             # the all-gather as direct sends too: this rank's packed slab to every peer, theirs into place
             if world > 1:
-                sends = [dist.P2POp(dist.isend, packed[rank * p_per: (rank + 1) * p_per], peer)
-                         for peer in range(world) if peer != rank]
-                recvs = [dist.P2POp(dist.irecv, packed[peer * p_per: (peer + 1) * p_per], peer)
-                         for peer in range(world) if peer != rank]
-                for req in dist.batch_isend_irecv(sends + recvs):
-                    req.wait()
+                ops_ = []
+                for peer in range(world):
+                    if peer == rank:
+                        continue
+                    if pn > 0:
+                        ops_.append(dist.P2POp(dist.isend, packed[p0: p0 + pn], peer))
+                    if table[peer][5] > 0:
+                        ops_.append(dist.P2POp(dist.irecv, packed[table[peer][4]: table[peer][4] + table[peer][5]], peer))
+                if ops_:
+                    for req in dist.batch_isend_irecv(ops_):
+                        req.wait()
         else:
-            dist.all_gather_into_tensor(packed, packed[rank * p_per: (rank + 1) * p_per])
+            dist.all_gather_into_tensor(packed, packed[p0: p0 + pn])
         self._fence()
+        if timed and e0 is not None:
+            self._events.append((e0, e1, e2, self._mark()))
         self._sharded_ran = True
-        return self._MODE_NAMES[exchange]
+        self._last_slabs = [(t[0], t[1]) for t in table]
+        if direct and not even:
+            return self._MODE_NAMES["all-to-all-uneven"]
+        return self._MODE_NAMES["all-to-all" if direct else "reduce-scatter"]
 
     @torch.no_grad()
     def step(self, workspace, grad_layout: int) -> None:
         self.steps += 1
-        self.mode = self._run(workspace, grad_layout, self.exchange, self.steps)
+        self.mode = self._run(workspace, grad_layout, self.exchange, self.steps, timed=True)
+        self.exchange_steps += 1
+        if len(self._events) > 256:
+            self.read_exchange_ms()
+
+    @torch.no_grad()
+    def probe_exchanges(self):
+        """which collectives this job's backend runs, decided ONCE and identically on every rank: each rank tries the tiny
+        collective on its own (an unsupported one raises before anything is posted) and the verdicts are combined with a
+        MIN all-reduce -- so no rank can later sit in a collective its peers skipped."""
+        if self.supported is not None:
+            return self.supported
+        if not self._collective():
+            self.supported = {e: True for e in self.EXCHANGES}
+            return self.supported
+        _, world = world_info()
+        dev = self.densities.device
+        probe = torch.zeros(world * 4, dtype=torch.float32, device=dev)
+        verdict = []
+        for name, call in (
+            ("reduce-scatter", lambda: (dist.reduce_scatter_tensor(torch.empty(4, device=dev), probe),
+                                        dist.all_gather_into_tensor(probe, probe[:4].clone()))),
+            ("all-to-all", lambda: dist.all_to_all_single(torch.empty_like(probe), probe)),
+            ("all-reduce", lambda: dist.all_reduce(probe)),
+        ):
+            try:
+                call()
+                verdict.append(1)
+            except (RuntimeError, NotImplementedError):     # the backend lacks it: raised locally, nothing was posted
+                verdict.append(0)
+        self._fence()
+        v = torch.tensor(verdict, dtype=torch.int32, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        self.supported = {e: bool(x) for e, x in zip(self.EXCHANGES, v.tolist())}
+        if not self.supported["all-reduce"]:
+            raise RuntimeError("the process group cannot even all-reduce")
+        if not self.supported[self.exchange]:
+            self.exchange = "all-reduce"
+        return self.supported
 
     @torch.no_grad()
     def autotune(self, workspace, grad_layout: int, iters: int = 5, sync=None) -> str:
-        """Time every exchange with `iters` dry steps and keep the fastest (max over ranks, so all ranks agree).
+        """Time every SUPPORTED exchange with `iters` dry steps and keep the fastest (max over ranks, so all ranks agree).
         Call before the first real step, with the workspace holding a packed grid: the gradient region is cleared here,
         and with zero gradient and zero moments a step changes no parameter bit.  `sync`: device synchronisation around
         the timed loops (default: torch.cuda.synchronize when the grid lives on a GPU)."""
@@ -271,24 +379,25 @@ class ShardedGridAdam:
             return self.exchange
         if sync is None:
             sync = torch.cuda.synchronize if self.densities.is_cuda else (lambda: None)
+        supported = self.probe_exchanges()
         self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace).zero_()
         times = []
         for exchange in self.EXCHANGES:
-            try:
-                self._run(workspace, grad_layout, exchange, 1)          # buffers, communicator warm-up
-                sync()
-                dist.barrier()
-                t0 = time.perf_counter()
-                for _ in range(iters):
-                    self._run(workspace, grad_layout, exchange, 1)
-                sync()
-                times.append((time.perf_counter() - t0) / iters * 1e3)
-            except RuntimeError:       # a backend without this collective: never pick it (MAX over ranks below)
+            if not supported[exchange]:        # the same skip on every rank (probe_exchanges)
                 times.append(float("inf"))
+                continue
+            self._run(workspace, grad_layout, exchange, 1)          # buffers, communicator warm-up
+            sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                self._run(workspace, grad_layout, exchange, 1)
+            sync()
+            times.append((time.perf_counter() - t0) / iters * 1e3)
         t = torch.tensor(times, dtype=torch.float64, device=self.densities.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        self.tuned_ms = {e: round(float(v), 4) for e, v in zip(self.EXCHANGES, t.tolist())}
-        self.exchange = min(self.tuned_ms, key=self.tuned_ms.get)
+        self.tuned_ms = {e: (round(float(v), 4) if v != float("inf") else None) for e, v in zip(self.EXCHANGES, t.tolist())}
+        self.exchange = min((e for e in self.EXCHANGES if self.tuned_ms[e] is not None), key=lambda e: self.tuned_ms[e])
         self._sharded_ran = False      # (dry steps changed nothing: the raw tensors are still whole)
         return self.exchange
 
@@ -298,9 +407,17 @@ class ShardedGridAdam:
         rank, world = world_info()
         if not self._sharded_ran:
             return
+        slabs = self._last_slabs
+        equal = len({b - a for a, b in slabs}) == 1
         for t in (self.densities, self.features):
             flat = t.view(-1)
-            per = flat.numel() // world
-            dist.all_gather_into_tensor(flat, flat[rank * per: (rank + 1) * per].clone())
+            per_plane = flat.numel() // int(t.shape[0])
+            if equal:
+                per = flat.numel() // world
+                dist.all_gather_into_tensor(flat, flat[rank * per: (rank + 1) * per].clone())
+            else:       # uneven slabs: one broadcast per owner (rare: checkpoints, stage changes)
+                for owner, (a, b) in enumerate(slabs):
+                    if b > a:
+                        dist.broadcast(flat[a * per_plane: b * per_plane], src=owner)
             torch.autograd.graph.increment_version(t)
         self._sharded_ran = False

@@ -17,7 +17,7 @@ import torch
 from torch import Tensor
 
 from thre3d_atom.modules import parallel
-from thre3d_atom.modules.optim import VoxeAdam
+from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
 from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid
@@ -122,6 +122,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
     camera_bounds: Optional[CameraBounds] = None,
     hemispherical_radius: float = HEMISPHERICAL_RADIUS_CONSTANT,   # distance of the random SDS cameras; the reference
     # hard-codes 4.0311 (sds_trainer.py:45,270) whatever the scene -- pass another value only as an explicit override
+    fused_grid_step: bool = True,       # FusedGridAdam (single process): the render gradient stays in the workspace
     saved_hemispherical_radius: Optional[float] = None,            # radius estimate written into the checkpoints when
     # there is no dataset to estimate it from (the reference stores train_dataset.get_hemispherical_radius_estimate())
 ) -> VolumetricModel:
@@ -175,7 +176,10 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
         torch.manual_seed(int(seed.item()))
         np.random.seed(int(seed.item()))
     row_lo, row_hi = parallel.shard_rows(im_h, rank, world)
-    optimizer = VoxeAdam([{"params": grid.parameters(), "lr": learning_rate}], betas=(0.9, 0.999))
+    if fused_grid_step and flat is None:
+        optimizer = FusedGridAdam(grid, lr=learning_rate, betas=(0.9, 0.999))
+    else:   # (data-parallel runs exchange the flat .grad buffer: ordinary gradients)
+        optimizer = VoxeAdam([{"params": grid.parameters(), "lr": learning_rate}], betas=(0.9, 0.999))
     lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_gamma)
     extra_info = {CAMERA_BOUNDS: camera_bounds, CAMERA_INTRINSICS: camera_intrinsics, HEMISPHERICAL_RADIUS: extra_radius}
 
@@ -253,6 +257,8 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
             torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / f"model_iter_{global_step}.pth")
         last = time.perf_counter()
 
+    if isinstance(optimizer, FusedGridAdam):
+        optimizer.detach()
     if rank == 0:
         torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / "model_final.pth")
     log.info("Training complete")

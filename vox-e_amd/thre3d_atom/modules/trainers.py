@@ -14,7 +14,7 @@ from typing import Any, Callable, Optional
 import torch
 from torch import Tensor
 
-from thre3d_atom.modules.optim import VoxeAdam
+from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam
 from thre3d_atom.modules.testers import test_sh_vox_grid_vol_mod_with_posed_images
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import sample_random_rays_and_pixels_from_cameras
@@ -52,6 +52,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     verbose_rendering: bool = True,
     fast_debug_mode: bool = False,
     lpips_weight: float = 0.0,
+    fused_grid_step: bool = True,      # addition of this build: FusedGridAdam (gradient stays in the kernels' workspace)
 ) -> VolumetricModel:
     if not isinstance(vol_mod.thre3d_repr, VoxelGrid) or vol_mod.render_procedure != render_sh_voxel_grid:
         raise AssertionError("this train procedure needs an SH-based VoxelGrid volumetric model")
@@ -95,7 +96,10 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         data = stage_datasets[stage - 1]
         intr = data.camera_intrinsics
         lr = learning_rate * (stagewise_lr_decay_gamma ** (stage - 1))
-        optimizer = VoxeAdam([{"params": vol_mod.thre3d_repr.parameters(), "lr": lr}], betas=(0.9, 0.999))
+        if fused_grid_step:
+            optimizer = FusedGridAdam(vol_mod.thre3d_repr, lr=lr, betas=(0.9, 0.999))
+        else:
+            optimizer = VoxeAdam([{"params": vol_mod.thre3d_repr.parameters(), "lr": lr}], betas=(0.9, 0.999))
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_decay_gamma_per_stage)
         log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
         for it in range(1, num_iterations_per_stage + 1):
@@ -131,6 +135,8 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
                                                            global_step=global_step)
             if it % save_freq == 0 and not fast_debug_mode:
                 torch.save(vol_mod.get_save_info(extra_info), model_dir / f"model_stage_{stage}_iter_{it}.pth")
+        if fused_grid_step:
+            optimizer.detach()
         if stage != num_stages:
             with torch.no_grad():
                 vol_mod.thre3d_repr = scale_voxel_grid_with_required_output_size(vol_mod.thre3d_repr, grid_sizes[stage])

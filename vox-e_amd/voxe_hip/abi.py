@@ -68,6 +68,7 @@ class VoxeRenderCfg(C.Structure):
         ("image_width", C.c_int32),
         ("image_height", C.c_int32),
         ("deterministic", C.c_int32),
+        ("linear_grad", C.c_int32),
         ("ray_state_valid", C.c_int32),
     ]
 
@@ -124,6 +125,9 @@ HIP_ONLY = {
     # fused optimiser step of a grid (gradient stays in the workspace between the two calls)
     "render_bwd_acc": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                  C.POINTER(C.c_int32), _P, C.c_size_t, _P]),
+    "render_bwd_acc_into": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                      C.POINTER(C.c_int32), _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "render_bwd_layout": (C.c_int, [_GD, _RC, C.c_int64]),
     "workspace_grad_offset": (C.c_size_t, [_GD]),
     "workspace_grad_bytes": (C.c_size_t, [_GD]),
     "grid_adam_step": (C.c_int, [_GD, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -70,6 +70,7 @@ def make_render_cfg(
     ray_state_valid: bool = False,
     image_height: Optional[int] = None,
     deterministic: bool = False,
+    linear_grad: bool = False,
 ) -> abi.VoxeRenderCfg:
     c = abi.VoxeRenderCfg()
     c.num_samples = int(num_samples)
@@ -88,5 +89,6 @@ def make_render_cfg(
     c.image_width = int(image_width or 0)
     c.image_height = int(image_height or 0)
     c.deterministic = int(bool(deterministic))
+    c.linear_grad = int(bool(linear_grad))
     c.ray_state_valid = int(bool(ray_state_valid))
     return c

@@ -2,6 +2,7 @@
 the whole-grid passes.  Tensors are plumbing (device memory + streams); all compute is in the HIP
 library.  Nothing here falls back to torch ops or to the CPU oracle."""
 import ctypes as C
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -38,6 +39,18 @@ class RenderParams:
     image_width: int = 0
     image_height: int = 0     # > 0 (with image_width): the rays are K = R / (H * W) images, one after the other
     deterministic: bool = False   # backward in 64-bit fixed point: bit-reproducible (test / race-check mode)
+    linear_grad: bool = False     # render_bwd_acc: write VOXE_GRAD_LINEAR whatever kernel runs (deferred-gradient mode)
+
+
+@dataclass
+class DeferredGrad:
+    """state of the deferred-gradient mode of one grid: which layout the accumulated gradient has and whether the region
+    holds anything since the last optimiser step"""
+    layout: int = abi.GRAD_ANY
+    dirty: bool = False
+    want_densities: bool = True
+    want_features: bool = True
+    clean_ptr: int = 0        # data_ptr of the workspace buffer whose gradient region is known to be cleared / in use
 
 
 class Workspace:
@@ -52,19 +65,38 @@ class Workspace:
         # forward arrives before that backward (two renders in one loss: specular + diffuse), it runs in `sibling`
         # (own buffers) instead of overwriting the states -- otherwise the first backward must re-march its rays.
         self.pending = False
+        self.pending_version = None   # (densities._version, features._version) of the forward that set `pending`
         self.sibling: Optional["Workspace"] = None
+        # deferred-gradient mode (FusedGridAdam): backward passes of renders through this workspace (or its sibling)
+        # LEAVE the grid gradient in this workspace's gradient region instead of returning .grad tensors
+        self.deferred: Optional["DeferredGrad"] = None
 
-    def for_differentiable_forward(self) -> "Workspace":
+    def for_differentiable_forward(self, version=None) -> "Workspace":
+        """the workspace a differentiable forward should run in.  A pending forward whose backward never came (the caller
+        dropped the graph: the parameters have moved on since) no longer blocks this workspace."""
+        if self.pending and version is not None and self.pending_version != version:
+            self.pending = False
         if not self.pending:
             return self
         if self.sibling is None:
             self.sibling = Workspace()
+        if self.sibling.pending and version is not None and self.sibling.pending_version != version:
+            self.sibling.pending = False
         return self.sibling if not self.sibling.pending else self
 
     def ensure(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            old = self.buf
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self.key = None
+            keep = (old is not None and self.deferred is not None and self.deferred.dirty
+                    and old.device == self.buf.device)
+            if keep:
+                # deferred-gradient mode: an accumulated gradient (and the packed grid in front of it) lives at fixed
+                # offsets from the start of the buffer -- a render that needs a bigger workspace must not lose it
+                self.buf[: old.numel()].copy_(old)
+                self.deferred.clean_ptr = self.buf.data_ptr()
+            else:
+                self.key = None
             self.state_key = None
         return self.buf
 
@@ -80,7 +112,8 @@ def _pack_key(spec: GridSpec, densities: torch.Tensor, features: torch.Tensor):
 
 def _state_key(pack_key, params: RenderParams, rays_o, rays_d, jitter, rng):
     """identity of a forward call: the backward may consume the ray states only of exactly this call"""
-    return (pack_key, tuple(vars(params).items()), rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0],
+    fwd = tuple((k, v) for k, v in vars(params).items() if k not in ("linear_grad", "deterministic"))   # backward-only knobs
+    return (pack_key, fwd, rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0],
             None if jitter is None else jitter.data_ptr(), tuple(rng))
 
 
@@ -91,7 +124,8 @@ def _descs(spec: GridSpec, params: RenderParams, densities, features, seed, rng_
     c = make_render_cfg(params.num_samples, params.near, params.far, params.perturb,
                         params.linear_disparity, params.aabb_clip, params.white_bkgd, params.sh_degree,
                         params.render_diffuse, params.term_eps, seed, rng_offset, reuse, params.image_width,
-                        image_height=params.image_height, deterministic=params.deterministic)
+                        image_height=params.image_height, deterministic=params.deterministic,
+                        linear_grad=params.linear_grad)
     return g, c
 
 
@@ -170,9 +204,11 @@ class _RenderFn(torch.autograd.Function):
         depth = torch.empty((R, 1), dtype=torch.float32, device=device)
         acc = torch.empty((R, 1), dtype=torch.float32, device=device)
         disp = torch.empty((R, 1), dtype=torch.float32, device=device)
+        ctx.main_workspace = workspace
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:  # (grad mode itself is off inside Function.forward)
-            workspace = workspace.for_differentiable_forward()
-            workspace.pending = True
+            version = (densities._version, features._version)
+            workspace = workspace.for_differentiable_forward(version)
+            workspace.pending, workspace.pending_version = True, version
         render_fwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, disp, workspace, rng)
         ctx.spec, ctx.params, ctx.workspace, ctx.rng = spec, params, workspace, rng
         ctx.save_for_backward(densities, features, ro, rd, jit, colour, depth, acc)
@@ -204,6 +240,36 @@ class _RenderFn(torch.autograd.Function):
         g_depth = None if g_depth is None else f32c(g_depth)
         g_acc = None if g_acc is None else f32c(g_acc)
         dens, feat = f32c(densities.detach()), f32c(features.detach())
+        main = ctx.main_workspace
+        deferred = main.deferred
+        if deferred is not None and main.buf is not None and dens.data_ptr() == densities.data_ptr() \
+                and feat.data_ptr() == features.data_ptr():
+            # deferred-gradient mode: the gradient stays in the MAIN workspace's gradient region (kernel layout) for the
+            # fused grid step; autograd sees no gradient for the two grid tensors
+            # (the region of a buffer this mode has not written yet holds whatever torch.empty returned)
+            fresh = (not deferred.dirty) and deferred.clean_ptr != main.buf.data_ptr()
+            if not params.linear_grad:   # every render of the step writes the SAME (linear) gradient layout
+                params = dataclasses.replace(params, linear_grad=True)
+            layout = render_bwd_acc(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, g_colour, g_depth, g_acc,
+                                    workspace, ctx.rng, zero_first=fresh,
+                                    want_densities=bool(need_d and deferred.want_densities),
+                                    want_features=bool(need_f and deferred.want_features),
+                                    grad_workspace=(main if workspace is not main else None),
+                                    expect_layout=deferred.layout if deferred.dirty else abi.GRAD_ANY)
+            if layout is not None:
+                deferred.clean_ptr = main.buf.data_ptr()
+                if layout != abi.GRAD_ANY:
+                    deferred.layout = layout
+                    deferred.dirty = True
+                workspace.pending = False
+                return (None,) * 9
+            # (the kernel that fits this render writes another gradient layout than what the region holds -- cannot happen
+            #  with linear_grad -- : ordinary path; its un-pack leaves a gradient in ITS workspace's region)
+            if workspace is main:
+                if deferred.dirty:
+                    raise VoxeError("deferred-gradient mode: a render with another gradient layout would overwrite the "
+                                    "accumulated gradient")
+                deferred.clean_ptr = 0
         d_dens = torch.empty_like(dens) if need_d else None
         d_feat = torch.empty_like(feat) if need_f else None
         render_bwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, g_colour, g_depth, g_acc,
@@ -463,25 +529,38 @@ def adam_step_(param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, e
 
 def render_bwd_acc(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
                    colour, depth, acc, g_colour, g_depth, g_acc, workspace: Workspace, rng=(0, 0),
-                   zero_first: bool = True, want_densities: bool = True, want_features: bool = True) -> int:
-    """voxe_render_bwd_acc: the backward of one render, its gradient LEFT in the workspace (kernel layout) for
-    `grid_adam_step_`.  Returns the layout (abi.GRAD_*); renders accumulated into one step must agree on it."""
+                   zero_first: bool = True, want_densities: bool = True, want_features: bool = True,
+                   grad_workspace: Optional[Workspace] = None, expect_layout: int = abi.GRAD_ANY) -> Optional[int]:
+    """voxe_render_bwd_acc(_into): the backward of one render, its gradient LEFT in the workspace (kernel layout) for
+    `grid_adam_step_` -- in `grad_workspace`'s gradient region when given (a second render of the same step that ran in
+    its own workspace).  Returns the layout (abi.GRAD_*); renders accumulated into one step must agree on it:
+    with `expect_layout` set, a render whose kernel writes the other layout is NOT run and None is returned."""
     device = densities.device
     L = lib()
     R = rays_o.shape[0]
     key = _pack_key(spec, densities, features)
     g, c = _descs(spec, params, densities, features, rng[0], rng[1], workspace.key == key)
     layout = C.c_int32(abi.GRAD_ANY)
+    if expect_layout != abi.GRAD_ANY and R > 0 and expect_layout != predicted_grad_layout(spec, params, densities, features, R):
+        return None
     with torch.cuda.device(device):
         ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
         c.reuse_packed_grid = int(workspace.key == key)
         c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng))
-        check(L.voxe_render_bwd_acc(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
-                                    ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
-                                    int(want_densities), int(want_features), int(zero_first), C.byref(layout),
-                                    ptr(ws), ws.numel(), stream_ptr(device)), "voxe_render_bwd_acc")
+        gws = None if grad_workspace is None else grad_workspace.buf
+        check(L.voxe_render_bwd_acc_into(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
+                                         ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
+                                         int(want_densities), int(want_features), int(zero_first), C.byref(layout),
+                                         ptr(ws), ws.numel(), ptr(gws), 0 if gws is None else gws.numel(),
+                                         stream_ptr(device)), "voxe_render_bwd_acc_into")
     workspace.key = key
     return int(layout.value)
+
+
+def predicted_grad_layout(spec: GridSpec, params: RenderParams, densities, features, R: int) -> int:
+    """which gradient layout the backward of this render writes (voxe_render_bwd_layout)"""
+    g, c = _descs(spec, params, densities, features, 0, 0, False)
+    return int(lib().voxe_render_bwd_layout(C.byref(g), C.byref(c), int(R)))
 
 
 def workspace_grad_view(spec: GridSpec, densities, features, workspace: Workspace) -> torch.Tensor:
