@@ -200,12 +200,16 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if fused:   # exchange timing of the timed region only (events on the launch stream; 0 for one process)
+        opt.read_exchange_ms()
+        opt.exchange_ms, opt.exchange_steps = 0.0, 0
     ops.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    exchange_ms = opt.read_exchange_ms() if fused else None
     prof = ops.profile_read()
     ops.profile_enable(False)
 
@@ -419,6 +423,10 @@ def main():
                 "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
                 "replicas_consistent": replicas_consistent, "backend": (backend if dist is not None else None),
                 "exchange_autotune_ms": (opt.tuned_ms if fused else None),
+                # device time per step between the backward and the next render that is NOT the local optimiser kernel:
+                # gradient reduce-scatter / all-to-all + all-gather of the packed grid (nothing overlaps it: the backward
+                # produces the whole gradient, the next forward consumes the whole grid -- DESIGN.md section 6)
+                "exchange_ms_per_step": (round(exchange_ms, 4) if exchange_ms is not None else None),
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
                 "untimed_steps_before_timing": PRE_WARM_STEPS + args.warmup,
             },

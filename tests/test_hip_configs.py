@@ -235,15 +235,16 @@ def test_default_dispatch_small_images_vs_oracle(hw, monkeypatch):
 def test_multi_view_launch_vs_oracle(hw, K, kind):
     """K cameras back to back, image_width = W, image_height = H (100 and 36 are no multiples of the 8-pixel tiles:
     tiles must not straddle two cameras): forward and gradients equal the oracle on the concatenated rays, and the
-    forward equals K single-camera launches bit for bit"""
+    forward equals the same rays rendered as an unordered list"""
     grid = _grid(160, kind)
     rays = [_rays(hw, 5 + 9 * i) for i in range(K)]
     o, d = np.concatenate([r[0] for r in rays]), np.concatenate([r[1] for r in rays])
     cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=8, rng_offset=2)
     out = gh.hip_forward(grid, cfg, o, d, rng=(8, 2), image_width=hw, image_height=hw)
     _check_forward(out, vo.render_fwd(grid, cfg, o, d))
-    flat = gh.hip_forward(grid, cfg, o, d, rng=(8, 2))                       # same rays as an unordered list
-    np.testing.assert_array_equal(out["colour"], flat["colour"])             # (the jitter stream is keyed by the ray index)
+    flat = gh.hip_forward(grid, cfg, o, d, rng=(8, 2))                       # same rays as an unordered list: the same
+    # samples (the jitter stream is keyed by the ray index); the two launches may composite in different segment orders
+    np.testing.assert_allclose(out["colour"], flat["colour"], rtol=0, atol=2e-6)
     gc = np.random.default_rng(K).standard_normal((o.shape[0], 3)).astype(np.float32)
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(8, 2), image_width=hw, image_height=hw)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
@@ -328,7 +329,7 @@ def test_deterministic_backward_attention_grid_and_unsupported_cases():
         gh.hip_backward(grid, cfg, o, d, ga, deterministic=True)
 
 
-# ---- space-binned backward (voxe_render_region.hip) forced onto small cases: every variant against the oracle ---------------
+# ---- space-binned render (voxe_render_region.hip: forward AND backward) forced onto small cases, every variant vs the oracle --
 def _region_env(monkeypatch, image_too=False):
     monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
     if image_too:
@@ -367,6 +368,9 @@ def test_region_backward_variants_vs_oracle(case, monkeypatch):
     gc = rng.standard_normal((o.shape[0], cout)).astype(np.float32)
     gdep = (0.2 * rng.standard_normal(o.shape[0])).astype(np.float32)
     over = dict(image_width=hw) if case == "image_ordered" else {}
+    out, ref = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(5, 9), **over), vo.render_fwd(grid, cfg, o, d, jitter=jit)
+    _check_forward(out, ref)
+    np.testing.assert_array_equal(np.isnan(out["disparity"]), np.isnan(ref["disparity"]))
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, jitter=jit, rng=(5, 9), **over)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, jitter=jit)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (case, rel_l2(gd, rd), rel_l2(gf, rf))
@@ -392,6 +396,6 @@ def test_region_backward_equals_scatter_backward_on_a_random_batch(monkeypatch):
     a = gh.hip_backward(grid, cfg, o, d, gc, rng=(1, 1))
     monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
     b = gh.hip_backward(grid, cfg, o, d, gc, rng=(1, 1))
-    assert rel_l2(a[0], b[0]) < 2e-5 and rel_l2(a[1], b[1]) < 2e-6, (rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
+    assert rel_l2(a[0], b[0]) < 5e-5 and rel_l2(a[1], b[1]) < 2e-6, (rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(b[0], rd) < GRAD_TOL and rel_l2(b[1], rf) < GRAD_TOL

@@ -297,6 +297,13 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   if ((tiled || packed_bwd) && workspace_bytes >= l.total) state = (float*)((char*)workspace + l.state_off);
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
+  if (l.region && workspace_bytes >= l.total_with_src) {
+    // space-binned path (unordered / sparse rays): forward through the region kernels; the segment tables and per-segment
+    // states stay in the workspace for the backward of the same call (cfg->ray_state_valid)
+    PhaseTimer t(PH_FWD, s);
+    launch_fwd_region(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, (char*)workspace + l.region_off, s);
+    return finish();
+  }
   { PhaseTimer t(PH_FWD, s); launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s); }
   return finish();
 }
@@ -340,7 +347,12 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     }
     const bool det = cfg->deterministic != 0;
     const bool region = l.region && !det && workspace_bytes >= l.total_with_src;
-    if ((tiled || packed_bwd || det) && !cfg->ray_state_valid) {
+    if (region && !cfg->ray_state_valid) {
+      // the caller's workspace does not hold this call's segment tables / states: rebuild them (no outputs)
+      PhaseTimer t(PH_FWD, s);
+      FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      launch_fwd_region(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, (char*)workspace + l.region_off, s);
+    } else if ((tiled || packed_bwd || det) && !cfg->ray_state_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
@@ -354,7 +366,6 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
         return VOXE_ERR_LAUNCH;
       launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);
     } else if (region) {
-      a.ray_state = state;
       launch_bwd_region(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, (char*)workspace + l.region_off, s);
     } else if (tiled)
       launch_bwd_tile(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);

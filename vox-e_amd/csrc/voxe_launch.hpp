@@ -64,11 +64,14 @@ size_t det_bytes(long long nvox, int C);   // [fixed-point gradient | 4 floats],
 bool packed_scatter_supported(int deg);
 void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
 
-// voxe_render_region.hip: space-binned backward (segments of rays grouped by 8x8x8-cell region, LDS window per region)
+// voxe_render_region.hip: space-binned render (segments of rays grouped by 8x8x8-cell region; texels and the gradient
+// window of a region live in LDS)
 bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffuse, bool tiled);
 size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S);
+void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
+                       hipStream_t st);   // segment tables + forward; leaves the per-segment states in `scratch`
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
-                       hipStream_t st);
+                       hipStream_t st);   // needs the tables / states of launch_fwd_region for the same rays
 
 // voxe_grid_ops.hip
 void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,

@@ -1,26 +1,33 @@
-// voxe_render_region.hip -- backward render for rays that share no voxels with their NEIGHBOURS IN THE LAUNCH (random
-// training batches of the reconstruction loop, modules/trainers.py:288-351; low-resolution images whose pixels are more
-// than a voxel apart): the deposit is binned by SPACE instead of by ray.
+// voxe_render_region.hip -- SPACE-BINNED render (forward + backward) for rays that share no voxels with their neighbours
+// in the launch: random training batches of the reconstruction loop (modules/trainers.py:288-351), low-resolution /
+// multi-view images whose pixels are more than a voxel apart.
 //
-// Why: such rays still meet -- 32768 rays x 144 in-AABB samples x 8 corners = 38 M deposits land on 4 M voxels -- but
-// not inside a wave, so the LDS window of render_bwd_tile_kernel has nothing to combine and the line-dense scatter
-// (render_bwd_packed_scatter_kernel) stays bound by the ~20 G atomic cache-line requests/s of the memory side
-// (profiles/r01_microbench_atomics.md: 3.6 requests per sample).  Here
+// Why: such rays still meet -- 32768 rays x 144 in-AABB samples x 8 corners = 38 M texel fetches and 38 M gradient
+// deposits land on 4 M voxels -- but not inside a wave.  The ray-ordered kernels then pay for it twice: the forward
+// gather pulls ~4.5 cache lines per sample through L2 (5x slower per ray than an image-ordered render), and the backward
+// has nothing to combine in LDS, so it is a scatter bound by the ~20 G atomic cache-line requests/s of the memory side
+// (profiles/r01_microbench_atomics.md).  Here the work is binned by SPACE instead of by ray:
 //
-//   1. render_bwd_src_kernel      one lane = one ray (x depth segment, like the scatter kernel): the full march (gather,
-//                                 compositing, gradient math) WITHOUT any deposit; it stores the 4 gradient sources of
-//                                 every sample (d rad_0..2 x C0, d v: 16 B) and cuts the ray into SEGMENTS of consecutive
-//                                 samples whose 2x2x2 footprint starts in the same 8x8x8-cell REGION of the grid;
-//   2. region_scan / region_fill  counting sort of the segments by region (no host round trip, no global cursor:
-//                                 every (ray, depth segment) owns its slots of the segment table);
-//   3. render_bwd_region_kernel   one block per region: lanes = segments; footprints are recomputed (index math only, no
-//                                 gather), sources loaded, and the 8 corners x C channels go into a 9x9x9-voxel LDS
-//                                 window of doubles (ds_add_f64, as in the tile kernel); ONE dense flush per region.
+//   1. region_seg_kernel      index math only (depths, footprints; no gather): every ray is cut into SEGMENTS of consecutive
+//                             samples whose 2x2x2 footprint starts in the same 8x8x8-cell REGION of the grid; each
+//                             (ray, depth segment) lane owns its slots of the segment table -- no global cursor -- and
+//                             takes the segment's rank inside its region from one returning atomic per segment;
+//   2. region_scan / fill     counting sort of the segments by region (no host round trip);
+//   3. region_fwd_kernel      one block per region: the region's 9x9x9 texels are staged in LDS ONCE (coalesced rows),
+//                             lanes = segments, trilinear gathers come from LDS; every segment composites with a LOCAL
+//                             transmittance starting at 1 (compositing is associative: the depth-segmented forward of
+//                             voxe_render.hip does the same with fixed 32-sample segments);
+//   4. region_combine_kernel  one lane per ray folds its segments front to back -> colour / depth / acc / disparity, and
+//                             leaves the state BEFORE every segment for the backward;
+//   5. region_bwd_kernel      one block per region again: texels in LDS, lanes = segments starting from their saved
+//                             state; the 8 corners x C channels of every sample go into a 9x9x9-voxel LDS window of
+//                             doubles (ds_add_f64, as in the tile kernel); ONE dense flush per region.
 //
-// Global atomics drop from ~3.6 requests per sample to ~160 per region (x 8000 regions at 160^3), the deposit runs at
-// LDS speed, and the gathers of pass 1 are the only incoherent memory traffic left.
-// Per-sample math: identical to render_bwd_kernel / render_bwd_packed_scatter_kernel (same device functions).
-// Reference: autograd through thre3d_atom/rendering/volumetric/{sample,process,accumulate}.py, thre3d_reprs/voxels.py.
+// Global memory sees each region's texels once per pass and ~160 atomic requests per region instead of ~3.6 per sample.
+// A lane whose (ray, depth segment) needs more segment slots than it owns (a ray zig-zagging through region corners)
+// puts the rest of its samples into the GENERIC bin: same kernels, texels from global memory, global atomics.
+// Per-sample math: identical to render_fwd_seg_kernel / render_bwd_packed_scatter_kernel (same device functions).
+// Reference: thre3d_atom/rendering/volumetric/{sample,process,accumulate}.py, thre3d_reprs/voxels.py (+ autograd).
 #include <limits.h>
 #include <stdlib.h>
 
@@ -33,38 +40,60 @@ namespace voxe {
 constexpr int kRB = 8;             // region edge in cells (low-corner indices)
 constexpr int kRW = kRB + 1;       // window edge in voxels
 constexpr int kRWin = kRW * kRW * kRW;      // 729 voxels
-constexpr int kRPlane = kRWin + 7;          // channel plane (doubles), padded off the bank period
+constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient window (doubles), padded off the bank period
 #ifndef VOXE_REGION_CHUNK
-#define VOXE_REGION_CHUNK 16       // longest segment (samples).  Swept on MI355X (recon batch, backward of an iteration): 4 / 6 / 8 / 16 -> 1.36 / 1.33 / 1.31 / 1.31 ms
+#define VOXE_REGION_CHUNK 16       // longest segment (samples): bounds the lane divergence of the region kernels
 #endif
 #ifndef VOXE_REGION_BLOCK
-#define VOXE_REGION_BLOCK 256      // threads of a region block (its waves share the LDS window): 64 / 128 / 256 -> 1.46 / 1.33 / 1.28 ms
+#define VOXE_REGION_BLOCK 256      // threads of a region block (its waves share the LDS windows)
 #endif
-constexpr int kSlotsPerLane = 16;  // segment slots of one (ray, depth segment); beyond: direct global atomics (rare)
+constexpr int kSlotsPerLane = 16;  // segment slots of one (ray, depth segment)
 constexpr unsigned kNoRegion = 0xFFFFFFFFu;
 
 __host__ __device__ inline int regions_along(int N) { return ((N > 1 ? N - 1 : 1) + kRB - 1) / kRB; }
 
-struct RegionScratch {
-  float4* src;            // [R * S]   gradient sources per sample (features already x C0, density last used slot)
-  unsigned* slot_region;  // [R * nseg * 16] region of every segment slot (kNoRegion: empty)
-  uint2* slot_seg;        // [R * nseg * 16] (ray, k0 | k1 << 16)
-  uint2* sorted;          // [R * nseg * 16] segments grouped by region
-  unsigned* count;        // [nreg] segments per region
-  unsigned* start;        // [nreg] first position of the region in `sorted`
-  unsigned* fill;         // [nreg] cursor of region_fill_kernel
+struct BinScratch {
+  unsigned* slot_region;  // [nslots] region of every USED segment slot (nreg: the generic bin); slot j of a lane is used iff j < lane_n
+  unsigned* slot_pos;     // [nslots] rank inside the region (seg kernel), then position in `sorted` (fill kernel)
+  uint2* slot_seg;        // [nslots] (ray, k0 | k1 << 16)
+  uint2* sorted;          // [nslots] (ray, k0 | k1 << 16) grouped by region
+  float4* part;           // [nslots][2] by position: forward partials of the segment (Tseg, csum[0..2] | asum, dsum)
+  float4* state;          // [nslots][2] by position: compositing state BEFORE the segment (T, csum[0..2] | asum, dsum)
+  unsigned* lane_n;       // [R * nseg] segments of every (ray, depth segment) lane
+  float4* dpart;          // [R * nseg][2] fold of a lane's segments (local transmittance / partial sums)
+  unsigned* count;        // [nreg + 1] segments per region (+ generic bin)
+  unsigned* start;        // [nreg + 1] first position of the region in `sorted`
 };
 
-// ---- pass 1: march, sources, segments ------------------------------------------------------------------------------------
-template <int COUT, int NCM>
-__global__ __launch_bounds__(64) void render_bwd_src_kernel(
-    DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
-    const float* __restrict__ rays_d, const float* __restrict__ jitter, const float* __restrict__ colour,
-    const float* __restrict__ depth, const float* __restrict__ acc, const float* __restrict__ d_colour,
-    const float* __restrict__ d_depth, const float* __restrict__ d_acc, const float* __restrict__ ray_state,
-    float* __restrict__ gpacked, const int want_d, const int want_f, RegionScratch rs) {
-  constexpr int C = COUT + 1;
-  constexpr int CM = COUT * NCM + 1;
+// ---- ray context of a segment lane: origin, direction, depth generator (no sample range, no SH basis) ----------------------
+struct SegRay {
+  float o[3], d[3], dnorm;
+  DepthGen dg;
+  __device__ __forceinline__ void init(const DevGrid& g, const DevCfg& c, long long r, const float* __restrict__ rays_o,
+                                       const float* __restrict__ rays_d, const float* __restrict__ jitter) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { o[a] = rays_o[3 * r + a]; d[a] = rays_d[3 * r + a]; }
+    dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    dg.near = c.near; dg.far = c.far;
+    dg.lindisp = c.lindisp != 0;
+    if (c.aabb_clip) { ray_aabb_bounds(g, o, d, dg.near, dg.far); dg.lindisp = false; }
+    dg.S = c.S; dg.half = c.S >> 1;
+    dg.step = 1.0f / (float)(c.S - 1);
+    dg.perturb = c.perturb != 0;
+    dg.jit = jitter ? jitter + r * c.S : nullptr;
+    dg.base = jitter_base(c.key0, c.key1, r);
+    dg.kc = INT_MIN;
+  }
+  __device__ __forceinline__ void point(float z, float (&p)[3]) const {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { const float dz = d[a] * z; p[a] = o[a] + dz; }
+  }
+};
+
+// ---- pass 1: segments (index math only) ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, const float* __restrict__ jitter,
+                                                        BinScratch bs, const int nreg) {
   const int lane = threadIdx.x;
   const int nt = (int)((c.R + 63) / 64);
   const int nseg = num_segments(c.S, c.seg_len);
@@ -72,140 +101,54 @@ __global__ __launch_bounds__(64) void render_bwd_src_kernel(
   const int seg = blockIdx.x / nrb;
   const int logical = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, 1, nt);
   if (logical < 0) return;
-  const long long r0 = (long long)logical * 64 + lane;
-  if (r0 >= c.R) return;
-  const long long r = r0;
-
-  RayCtx<COUT, NCM, 1> rc;
+  const long long r = (long long)logical * 64 + lane;
+  if (r >= c.R) return;
+  RayCtx<3, 1, 1> rc;   // (origin, direction, depth generator, conservative in-AABB sample range)
   rc.init(g, c, r, rays_o, rays_d, jitter);
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
   const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
   if (k_lo > k_hi) return;
-  float T = 1.0f, pre_c[COUT], pre_a = 0.0f, pre_d = 0.0f;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = 0.0f;
-  if (seg > 0) {
-    constexpr int NC = COUT + 3;
-    T = ray_state[ray_state_index(seg, 0, NC, c.R, r)];
-#pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
-    pre_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
-    pre_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
-  }
-  float gc[COUT], gsum = 0.0f;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
-  const float gdep = d_depth ? d_depth[r] : 0.0f;
-  const float gacc = d_acc ? d_acc[r] : 0.0f;
-  const bool white = c.white && !c.attn;
-  const float asum = acc[r];
-  float total = gdep * depth[r] + gacc * asum;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) {
-    const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
-    total += gc[ch] * csum;
-  }
-  if (white) total -= gsum * asum;
-  float prefix = gdep * pre_d + gacc * pre_a;
-#pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
-  if (white) prefix -= gsum * pre_a;
-
   const int nry = regions_along(g.Y), nrz = regions_along(g.Z);
   const long long slot0 = (r * nseg + seg) * kSlotsPerLane;
   int nslots = 0;
-  unsigned cur_region = kNoRegion;
-  int seg_k0 = 0;
-  // close the open segment [seg_k0, k_end] (if any) into the next slot of this (ray, depth segment)
+  unsigned cur = kNoRegion;
+  int k0 = 0, k_prev = 0;
   auto emit = [&](int k_end) {
-    if (cur_region == kNoRegion) return;
-    rs.slot_region[slot0 + nslots] = cur_region;
-    rs.slot_seg[slot0 + nslots] = make_uint2((unsigned)r, (unsigned)seg_k0 | ((unsigned)k_end << 16));
-    atomicAdd(rs.count + cur_region, 1u);
+    if (cur == kNoRegion) return;
+    bs.slot_region[slot0 + nslots] = cur;
+    bs.slot_seg[slot0 + nslots] = make_uint2((unsigned)r, (unsigned)k0 | ((unsigned)k_end << 16));
+    bs.slot_pos[slot0 + nslots] = atomicAdd(bs.count + cur, 1u);   // rank of this segment inside its region
     ++nslots;
   };
-  float z_next = rc.dg.z(k_lo);
   for (int k = k_lo; k <= k_hi; ++k) {
-    const float z = z_next;
-    const bool last = (k == c.S - 1);
-    if (!last) z_next = rc.dg.z(k + 1);
+    const float z = rc.dg.z(k);
     float p[3];
     rc.point(z, p);
     Footprint fp;
     footprint(g, p, fp);
-    float gch[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (fp.inside) {
-      Cell cell;
-      make_cell_fast(g, fp, cell);
-      float v, rad[COUT];
-      gather<COUT, NCM, 1>(g, packed, cell, rc.basis, v, rad);
-      float sigma, dpost;
-      post_activate_vg(g.post_act, v, sigma, dpost);
-      const float dl = last ? kInfinity : (z_next - z);
-      const float delta = dl * rc.dnorm;
-      const float e = fast_exp(-(sigma * delta));
-      const float alpha = 1.0f - e;
-      const float om = 1.0f - alpha;
-      const float wk = alpha * T;
-      float col[COUT], dldw = fmaf(gdep, z, gacc);
-#pragma unroll
-      for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
-      if (white) dldw -= gsum;
-      prefix = fmaf(dldw, wk, prefix);
-      const float suffix = last ? 0.0f : (total - prefix);
-      const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
-      const float dsig = (delta * e) * fmaf(T, dldw, -tail);
-      bool any = false;
-#pragma unroll
-      for (int ch = 0; ch < COUT; ++ch) {
-        gch[ch] = want_f ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
-        any = any || (gch[ch] != 0.0f);
-      }
-      gch[COUT] = want_d ? dsig * dpost : 0.0f;
-      any = any || (gch[COUT] != 0.0f);
-      T = T * om;
-      if (any) {
-        const unsigned region =
-            (unsigned)(((cell.i[0] / kRB) * nry + cell.i[1] / kRB) * nrz + cell.i[2] / kRB);
-        const bool full = (k - seg_k0 + 1 > VOXE_REGION_CHUNK);
-        if (region != cur_region || full) {
-          emit(k - 1);
-          if (nslots < kSlotsPerLane) {
-            cur_region = region;
-            seg_k0 = k;
-          } else {
-            // (segment table of this lane exhausted -- a ray that zig-zags through region corners: deposit directly)
-            cur_region = kNoRegion;
-            const CellAddr ad = cell_addr(g, cell);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float w = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
-              if (w == 0.0f) continue;
-              float* __restrict__ texel =
-                  gpacked + (long long)(ad.base + (j & 1) * ad.sx + ((j >> 1) & 1) * ad.sy + (j >> 2) * ad.sz) * CM;
-#pragma unroll
-              for (int ch = 0; ch < C; ++ch)
-                if (gch[ch] != 0.0f) atomicAdd(texel + (ch == COUT ? CM - 1 : ch * NCM), gch[ch] * w);
-            }
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) gch[ch] = 0.0f;   // (nothing left for the deposit kernel)
-          }
-        }
-      }
+    if (!fp.inside) continue;          // contributes nothing (process.py:83): not part of any segment
+    Cell cell;
+    make_cell(g, fp, cell);
+    unsigned region = (unsigned)(((cell.i[0] / kRB) * nry + cell.i[1] / kRB) * nrz + cell.i[2] / kRB);
+    if (cur == (unsigned)nreg) region = cur;              // the generic bin keeps the rest of this lane's samples
+    if (region != cur || (cur != (unsigned)nreg && k - k0 + 1 > VOXE_REGION_CHUNK)) {
+      emit(k_prev);
+      cur = (nslots == kSlotsPerLane - 1) ? (unsigned)nreg : region;   // last slot of the lane: generic bin
+      k0 = k;
     }
-    rs.src[r * c.S + k] = make_float4(gch[0], gch[1], gch[2], gch[3]);
+    k_prev = k;
   }
-  emit(k_hi);
+  emit(k_prev);
+  bs.lane_n[r * nseg + seg] = (unsigned)nslots;
 }
 
 // ---- pass 2: counting sort of the segments by region ---------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void region_scan_kernel(const unsigned* __restrict__ count, unsigned* __restrict__ start,
-                                                           int nreg) {
-  // exclusive prefix sum of `count` (one block; nreg is a few thousand .. 32768)
-  __shared__ unsigned partial[1024];
+                                                           int n) {
+  __shared__ unsigned partial[1024];   // exclusive prefix sum of `count` (one block; n is a few thousand .. 32769)
   const int tid = threadIdx.x;
-  const int per = (nreg + 1023) / 1024;
-  const int lo = tid * per, hi = min(nreg, lo + per);
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = min(n, lo + per);
   unsigned sum = 0;
   for (int i = lo; i < hi; ++i) sum += count[i];
   partial[tid] = sum;
@@ -220,98 +163,375 @@ __global__ __launch_bounds__(1024) void region_scan_kernel(const unsigned* __res
   for (int i = lo; i < hi; ++i) { start[i] = run; run += count[i]; }
 }
 
-__global__ __launch_bounds__(256) void region_fill_kernel(RegionScratch rs, long long nslots) {
+__global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long long nslots) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nslots) return;
-  const unsigned region = rs.slot_region[i];
-  if (region == kNoRegion) return;
-  const unsigned pos = rs.start[region] + atomicAdd(rs.fill + region, 1u);
-  rs.sorted[pos] = rs.slot_seg[i];
+  if ((unsigned)(i % kSlotsPerLane) >= bs.lane_n[i / kSlotsPerLane]) return;   // unused slot
+  const unsigned region = bs.slot_region[i];
+  const unsigned pos = bs.start[region] + bs.slot_pos[i];
+  bs.slot_pos[i] = pos;
+  bs.sorted[pos] = bs.slot_seg[i];
 }
 
-// ---- pass 3: one block per region, LDS window, one dense flush -------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(VOXE_REGION_BLOCK) void render_bwd_region_kernel(DevGrid g, DevCfg c, const float* __restrict__ rays_o,
-                                                                const float* __restrict__ rays_d,
-                                                                const float* __restrict__ jitter,
-                                                                float* __restrict__ gpacked, const int cout, const int ncm,
-                                                                const int chmask, RegionScratch rs) {
+// ---- the region's texels in LDS ----------------------------------------------------------------------------------------------
+// tex[voxel of the 9x9x9 window][C] floats, C = COUT + 1: (coefficient 0 of every colour, pre-activated density) -- all a
+// single-group render (SH-0 / diffuse / attention) reads.  Voxels beyond the grid's far faces are zero (their weights are).
+template <int COUT, int NCM>
+__device__ __forceinline__ void load_window(const DevGrid& g, const float* __restrict__ packed, float* __restrict__ tex,
+                                            int ox, int oy, int oz, int tid) {
+  constexpr int C = COUT + 1, CM = COUT * NCM + 1;
+  for (int v = tid; v < kRWin; v += VOXE_REGION_BLOCK) {
+    const int x = ox + v / (kRW * kRW), y = oy + (v / kRW) % kRW, z = oz + v % kRW;
+    const bool in = x < g.X && y < g.Y && z < g.Z;
+    const long long vox = ((long long)x * g.Y + y) * g.Z + z;
+    if constexpr (CM == 4) {
+      const float4 t = in ? reinterpret_cast<const float4*>(packed)[vox] : make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(tex)[v] = t;
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) tex[v * C + ch] = in ? packed[vox * CM + (ch == COUT ? CM - 1 : ch * NCM)] : 0.0f;
+    }
+  }
+}
+
+// trilinear gather from the LDS window: same products / FMA order as gather<>() of voxe_render_common.hpp for C == 4 / 2
+template <int COUT>
+__device__ __forceinline__ void gather_lds(const float* __restrict__ tex, int idx0, const Cell& cell, float& v,
+                                           float (&rad)[COUT]) {
+  constexpr int C = COUT + 1;
+  float wxy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wxy[k] = cell.w[0][k & 1] * cell.w[1][k >> 1];
+  if constexpr (C == 4) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float4 t = reinterpret_cast<const float4*>(tex)[idx0 + (k & 1) * (kRW * kRW) + ((k >> 1) & 1) * kRW + (k >> 2)];
+      const float w = wxy[k & 3] * cell.w[2][k >> 2];
+      const v2f ww = {w, w};
+      const v2f a = {t.x, t.y}, b = {t.z, t.w};
+      rg = __builtin_elementwise_fma(a, ww, rg);
+      bs = __builtin_elementwise_fma(b, ww, bs);
+    }
+    rad[0] = kC0 * rg.x; rad[1] = kC0 * rg.y; rad[2] = kC0 * bs.x; v = bs.y;
+  } else {
+    float f = 0.0f;
+    v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float2 t = reinterpret_cast<const float2*>(tex)[idx0 + (k & 1) * (kRW * kRW) + ((k >> 1) & 1) * kRW + (k >> 2)];
+      const float w = wxy[k & 3] * cell.w[2][k >> 2];
+      f = fmaf(t.x, w, f);
+      v = fmaf(t.y, w, v);
+    }
+    rad[0] = kC0 * f;
+  }
+}
+
+struct RegionBlock {
+  int ox, oy, oz;   // window origin (voxels)
+  bool generic;     // the generic bin: texels from global memory, global atomics
+};
+__device__ __forceinline__ RegionBlock region_block(const DevGrid& g, unsigned region, int nreg) {
+  RegionBlock b;
+  b.generic = region == (unsigned)nreg;
+  const int nry = regions_along(g.Y), nrz = regions_along(g.Z);
+  b.oz = (int)(region % (unsigned)nrz) * kRB;
+  b.oy = (int)((region / (unsigned)nrz) % (unsigned)nry) * kRB;
+  b.ox = (int)(region / (unsigned)(nrz * nry)) * kRB;
+  return b;
+}
+
+// ---- pass 3: forward, one block per region -----------------------------------------------------------------------------------
+template <int COUT, int NCM>
+__global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
+                                                                       const float* __restrict__ rays_o,
+                                                                       const float* __restrict__ rays_d,
+                                                                       const float* __restrict__ jitter, BinScratch bs,
+                                                                       const int nreg) {
+  constexpr int C = COUT + 1;
+  __shared__ float tex[kRWin * C];
+  const int tid = threadIdx.x;
+  const unsigned region = blockIdx.x;
+  const unsigned n = bs.count[region];
+  if (n == 0) return;                       // block-uniform
+  const unsigned first = bs.start[region];
+  const RegionBlock rb = region_block(g, region, nreg);
+  if (!rb.generic) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+  __syncthreads();
+  const float basis0[1] = {kC0};
+  for (unsigned i = tid; i < n; i += VOXE_REGION_BLOCK) {
+    const uint2 rec = bs.sorted[first + i];
+    const long long r = rec.x;
+    const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
+    SegRay ray;
+    ray.init(g, c, r, rays_o, rays_d, jitter);
+    float csum[3] = {0.0f, 0.0f, 0.0f};
+    float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+    float z_next = ray.dg.z(k0);
+    for (int k = k0; k <= k1; ++k) {
+      const float z = z_next;
+      const bool last = (k == c.S - 1);
+      if (!last) z_next = ray.dg.z(k + 1);
+      float p[3];
+      ray.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      if (!fp.inside) continue;
+      Cell cell;
+      make_cell(g, fp, cell);
+      float v, rad[COUT];
+      if (rb.generic) {
+        gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
+      } else {
+        const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
+        if ((unsigned)lx >= (unsigned)kRB || (unsigned)ly >= (unsigned)kRB || (unsigned)lz >= (unsigned)kRB) continue;
+        gather_lds<COUT>(tex, (lx * kRW + ly) * kRW + lz, cell, v, rad);
+      }
+      const float sigma = post_activate(g.post_act, v);
+      const float dl = last ? kInfinity : (z_next - z);
+      const float delta = dl * ray.dnorm;
+      const float e = fast_exp(-(sigma * delta));
+      const float alpha = 1.0f - e;
+      const float om = 1.0f - alpha;
+      const float w = alpha * T;
+      T = T * om;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), w, csum[ch]);
+      asum = asum + w;
+      dsum = fmaf(z, w, dsum);
+    }
+    bs.part[2 * (size_t)(first + i)] = make_float4(T, csum[0], csum[1], csum[2]);
+    bs.part[2 * (size_t)(first + i) + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
+  }
+}
+
+// ---- pass 4: fold the segments of every ray front to back (two levels: inside a depth-segment lane, then across lanes) ----
+// level 1, one thread per (ray, depth segment): fold the lane's <= 16 segments with a transmittance starting at 1; leaves the
+// state before every segment RELATIVE to the lane start and the lane's own fold in dpart.
+__global__ __launch_bounds__(256) void region_fold_lane_kernel(DevCfg c, BinScratch bs) {
+  const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nseg = num_segments(c.S, c.seg_len);
+  if (lane >= c.R * nseg) return;
+  const unsigned n = bs.lane_n[lane];
+  float cs[3] = {0.0f, 0.0f, 0.0f};
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  for (unsigned j = 0; j < n; ++j) {
+    const size_t pos = bs.slot_pos[lane * kSlotsPerLane + j];
+    bs.state[2 * pos] = make_float4(T, cs[0], cs[1], cs[2]);
+    bs.state[2 * pos + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
+    const float4 a = bs.part[2 * pos], b = bs.part[2 * pos + 1];
+    cs[0] = fmaf(T, a.y, cs[0]);
+    cs[1] = fmaf(T, a.z, cs[1]);
+    cs[2] = fmaf(T, a.w, cs[2]);
+    asum = fmaf(T, b.x, asum);
+    dsum = fmaf(T, b.y, dsum);
+    T = T * a.x;
+  }
+  bs.dpart[2 * lane] = make_float4(T, cs[0], cs[1], cs[2]);
+  bs.dpart[2 * lane + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
+}
+
+// level 2, one thread per (ray, depth segment) again: the state before the lane = fold of the ray's earlier lanes; the
+// lane's segment states become absolute; the thread of the LAST depth segment also folds its own lane and writes the outputs
+template <int COUT>
+__global__ __launch_bounds__(256) void region_combine_kernel(DevCfg c, BinScratch bs, float* __restrict__ colour,
+                                                             float* __restrict__ depth, float* __restrict__ acc,
+                                                             float* __restrict__ disparity) {
+  const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nseg = num_segments(c.S, c.seg_len);
+  if (lane >= c.R * nseg) return;
+  const long long r = lane / nseg;
+  const int s = (int)(lane - r * nseg);
+  const unsigned n = bs.lane_n[lane];
+  const bool is_last = s == nseg - 1;
+  if (n == 0 && !is_last) return;
+  float cs[3] = {0.0f, 0.0f, 0.0f};
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  for (int q = 0; q < s; ++q) {   // (transmittance-weighted fold of the earlier lanes: <= nseg - 1 reads of 32 B, contiguous per ray)
+    const float4 a = bs.dpart[2 * (r * nseg + q)], b = bs.dpart[2 * (r * nseg + q) + 1];
+    cs[0] = fmaf(T, a.y, cs[0]);
+    cs[1] = fmaf(T, a.z, cs[1]);
+    cs[2] = fmaf(T, a.w, cs[2]);
+    asum = fmaf(T, b.x, asum);
+    dsum = fmaf(T, b.y, dsum);
+    T = T * a.x;
+  }
+  for (unsigned j = 0; j < n; ++j) {
+    const size_t pos = bs.slot_pos[lane * kSlotsPerLane + j];
+    const float4 a = bs.state[2 * pos], b = bs.state[2 * pos + 1];   // relative to the lane start
+    bs.state[2 * pos] = make_float4(T * a.x, fmaf(T, a.y, cs[0]), fmaf(T, a.z, cs[1]), fmaf(T, a.w, cs[2]));
+    bs.state[2 * pos + 1] = make_float4(fmaf(T, b.x, asum), fmaf(T, b.y, dsum), 0.0f, 0.0f);
+  }
+  if (!is_last) return;
+  {
+    const float4 a = bs.dpart[2 * lane], b = bs.dpart[2 * lane + 1];
+    cs[0] = fmaf(T, a.y, cs[0]);
+    cs[1] = fmaf(T, a.z, cs[1]);
+    cs[2] = fmaf(T, a.w, cs[2]);
+    asum = fmaf(T, b.x, asum);
+    dsum = fmaf(T, b.y, dsum);
+  }
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) {
+    float col = cs[ch];
+    if (c.white) {
+      float bk = 1.0f - asum;
+      if (c.attn) bk = bk * 0.0f;
+      col = col + bk;
+    }
+    if (colour) colour[r * COUT + ch] = col;
+  }
+  if (depth) depth[r] = dsum;
+  if (acc) acc[r] = asum;
+  if (disparity) {
+    const float q = dsum / asum;
+    const float m = (q != q) ? q : (q > kZeroPlus ? q : kZeroPlus);  // torch.maximum keeps NaN
+    disparity[r] = 1.0f / m;
+  }
+}
+
+// ---- pass 5: backward, one block per region ------------------------------------------------------------------------------------
+template <int COUT, int NCM>
+__global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
+    DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ jitter, const float* __restrict__ colour, const float* __restrict__ depth,
+    const float* __restrict__ acc, const float* __restrict__ d_colour, const float* __restrict__ d_depth,
+    const float* __restrict__ d_acc, float* __restrict__ gpacked, const int want_d, const int want_f, BinScratch bs,
+    const int nreg) {
+  constexpr int C = COUT + 1, CM = COUT * NCM + 1;
+  __shared__ float tex[kRWin * C];
   __shared__ double win[C * kRPlane];
   const int tid = threadIdx.x;
   const unsigned region = blockIdx.x;
-  const unsigned n = rs.count[region];
+  const unsigned n = bs.count[region];
   if (n == 0) return;                       // block-uniform
-  const unsigned first = rs.start[region];
-  for (int i = tid; i < C * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
-  const int nry = regions_along(g.Y), nrz = regions_along(g.Z);
-  const int rz = (int)(region % (unsigned)nrz), ry = (int)((region / (unsigned)nrz) % (unsigned)nry);
-  const int rx = (int)(region / (unsigned)(nrz * nry));
-  const int ox = rx * kRB, oy = ry * kRB, oz = rz * kRB;   // window origin (voxels)
+  const unsigned first = bs.start[region];
+  const RegionBlock rb = region_block(g, region, nreg);
+  if (!rb.generic) {
+    load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+    for (int i = tid; i < C * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
+  }
   __syncthreads();
+  const float basis0[1] = {kC0};
+  const bool white = c.white && !c.attn;
+  for (unsigned i = tid; i < n; i += VOXE_REGION_BLOCK) {
+    const uint2 rec = bs.sorted[first + i];
+    const long long r = rec.x;
+    const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
+    SegRay ray;
+    ray.init(g, c, r, rays_o, rays_d, jitter);
+    // state before the segment (region_combine_kernel) and the per-ray constants of the backward (render_bwd_kernel)
+    const float4 sa = bs.state[2 * (size_t)(first + i)], sb = bs.state[2 * (size_t)(first + i) + 1];
+    float T = sa.x;
+    const float pre_c[3] = {sa.y, sa.z, sa.w};
+    const float pre_a = sb.x, pre_d = sb.y;
+    float gc[COUT], gsum = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
+    const float gdep = d_depth ? d_depth[r] : 0.0f;
+    const float gacc = d_acc ? d_acc[r] : 0.0f;
+    const float asum = acc[r];
+    float total = gdep * depth[r] + gacc * asum;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) {
+      const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
+      total += gc[ch] * csum;
+    }
+    if (white) total -= gsum * asum;
+    float prefix = gdep * pre_d + gacc * pre_a;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
+    if (white) prefix -= gsum * pre_a;
 
-  for (unsigned base = 0; base < n; base += VOXE_REGION_BLOCK) {
-    const unsigned i = base + tid;
-    if (i < n) {
-      const uint2 sg = rs.sorted[first + i];
-      const long long r = sg.x;
-      const int k0 = (int)(sg.y & 0xFFFFu), k1 = (int)(sg.y >> 16);
-      // ray context: origin, direction and the depth generator (no bounds, no SH basis: index math only)
-      float o[3], d[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { o[a] = rays_o[3 * r + a]; d[a] = rays_d[3 * r + a]; }
-      DepthGen dg;
-      dg.near = c.near; dg.far = c.far;
-      dg.lindisp = c.lindisp != 0;
-      if (c.aabb_clip) { ray_aabb_bounds(g, o, d, dg.near, dg.far); dg.lindisp = false; }
-      dg.S = c.S; dg.half = c.S >> 1;
-      dg.step = 1.0f / (float)(c.S - 1);
-      dg.perturb = c.perturb != 0;
-      dg.jit = jitter ? jitter + r * c.S : nullptr;
-      dg.base = jitter_base(c.key0, c.key1, r);
-      dg.kc = INT_MIN;
-      for (int k = k0; k <= k1; ++k) {
-        const float4 s4 = rs.src[r * c.S + k];
-        const float z = dg.z(k);
-        const float s[4] = {s4.x, s4.y, s4.z, s4.w};
-        bool any = false;
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) any = any || (s[ch] != 0.0f);
-        if (!any) continue;
-        float p[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { const float dz = d[a] * z; p[a] = o[a] + dz; }
-        Footprint fp;
-        footprint(g, p, fp);
-        Cell cell;
-        make_cell(g, fp, cell);
-        const int lx = cell.i[0] - ox, ly = cell.i[1] - oy, lz = cell.i[2] - oz;
+    float z_next = ray.dg.z(k0);
+    for (int k = k0; k <= k1; ++k) {
+      const float z = z_next;
+      const bool last = (k == c.S - 1);
+      if (!last) z_next = ray.dg.z(k + 1);
+      float p[3];
+      ray.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      if (!fp.inside) continue;
+      Cell cell;
+      make_cell(g, fp, cell);
+      float v, rad[COUT];
+      int idx0 = 0;
+      if (rb.generic) {
+        gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
+      } else {
+        const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
         if ((unsigned)lx >= (unsigned)kRB || (unsigned)ly >= (unsigned)kRB || (unsigned)lz >= (unsigned)kRB) continue;
-        const int idx0 = (lx * kRW + ly) * kRW + lz;
+        idx0 = (lx * kRW + ly) * kRW + lz;
+        gather_lds<COUT>(tex, idx0, cell, v, rad);
+      }
+      float sigma, dpost;
+      post_activate_vg(g.post_act, v, sigma, dpost);
+      const float dl = last ? kInfinity : (z_next - z);
+      const float delta = dl * ray.dnorm;
+      const float e = fast_exp(-(sigma * delta));
+      const float alpha = 1.0f - e;
+      const float om = 1.0f - alpha;
+      const float wk = alpha * T;
+      float col[COUT], dldw = fmaf(gdep, z, gacc);
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
+      if (white) dldw -= gsum;
+      prefix = fmaf(dldw, wk, prefix);
+      const float suffix = last ? 0.0f : (total - prefix);
+      const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+      const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+      float gch[C];
+      bool any = false;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) {
+        gch[ch] = want_f ? ((wk * gc[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0 : 0.0f;
+        any = any || (gch[ch] != 0.0f);
+      }
+      gch[COUT] = want_d ? dsig * dpost : 0.0f;
+      any = any || (gch[COUT] != 0.0f);
+      T = T * om;
+      if (!any) continue;
+      if (rb.generic) {
+        const CellAddr ad = cell_addr(g, cell);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float w = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
+          if (w == 0.0f) continue;
+          float* __restrict__ texel =
+              gpacked + (long long)(ad.base + (j & 1) * ad.sx + ((j >> 1) & 1) * ad.sy + (j >> 2) * ad.sz) * CM;
+#pragma unroll
+          for (int ch = 0; ch < C; ++ch)
+            if (gch[ch] != 0.0f) atomicAdd(texel + (ch == COUT ? CM - 1 : ch * NCM), gch[ch] * w);
+        }
+      } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float w = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
           const int idx = idx0 + (j & 1) * (kRW * kRW) + ((j >> 1) & 1) * kRW + (j >> 2);
 #pragma unroll
           for (int ch = 0; ch < C; ++ch) {
-            if ((chmask >> ch) & 1)
-              __hip_atomic_fetch_add(&win[ch * kRPlane + idx], (double)(s[ch] * w), __ATOMIC_RELAXED,
+            if ((ch < COUT) ? want_f : want_d)
+              __hip_atomic_fetch_add(&win[ch * kRPlane + idx], (double)(gch[ch] * w), __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
       }
     }
   }
+  if (rb.generic) return;
   __syncthreads();
   // flush: lanes = (voxel, channel), channel fastest -> 16-byte dense global atomics along the z-runs of the window
-  const int CM = cout * ncm + 1;
   for (int e = tid; e < kRWin * C; e += VOXE_REGION_BLOCK) {
     const int vl = e / C, ch = e - vl * C;
     const double val = win[ch * kRPlane + vl];
     if (val == 0.0) continue;
-    const int x = ox + vl / (kRW * kRW), y = oy + (vl / kRW) % kRW, zz = oz + vl % kRW;
-    if (x >= g.X || y >= g.Y || zz >= g.Z) continue;   // (weight-0 corners of size-1 axes / the grid's far faces)
+    const int x = rb.ox + vl / (kRW * kRW), y = rb.oy + (vl / kRW) % kRW, zz = rb.oz + vl % kRW;
+    if (x >= g.X || y >= g.Y || zz >= g.Z) continue;   // (weight-0 corners of size-1 axes / beyond the grid's far faces)
     const long long vox = ((long long)x * g.Y + y) * g.Z + zz;
-    atomicAdd(gpacked + vox * CM + (ch == cout ? CM - 1 : ch * ncm), (float)val);
+    atomicAdd(gpacked + vox * CM + (ch == COUT ? CM - 1 : ch * NCM), (float)val);
   }
 }
 
@@ -326,7 +546,7 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
   if (!(c.attn || deg == 0 || diffuse)) return false;          // one channel group (SH-0 / diffuse / attention)
   if (c.R >= (1ll << 32) || c.S >= 65536) return false;        // segment records: 32-bit ray, 16-bit sample indices
-  if (!tiled) return true;                                     // unordered rays, image rows below the tile threshold
+  if (!tiled) return true;                                     // unordered rays, images below the tile threshold
   // image-ordered launches: only when the pixels are clearly more than a voxel apart (nothing to combine inside a wave:
   // 100x100 cameras on a 160^3 grid).  The pixel spacing is not known on the host; for a camera that frames the volume
   // it is ~ grid side / image width.
@@ -337,18 +557,23 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
 }
 
 static inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
-struct RegionLayout { size_t src, slot_region, slot_seg, sorted, counters, total; long long nslots; int nreg; };
+struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, dpart, counters, total; long long nslots, nlanes; int nreg; };
 static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   RegionLayout l;
   const int nseg = num_segments(S, seg_len_for(R));
   l.nslots = R * nseg * kSlotsPerLane;
+  l.nlanes = R * nseg;
   l.nreg = regions_along(X) * regions_along(Y) * regions_along(Z);
   size_t off = 0;
-  l.src = off; off += up256((size_t)R * S * sizeof(float4));
   l.slot_region = off; off += up256((size_t)l.nslots * sizeof(unsigned));
+  l.slot_pos = off; off += up256((size_t)l.nslots * sizeof(unsigned));
   l.slot_seg = off; off += up256((size_t)l.nslots * sizeof(uint2));
   l.sorted = off; off += up256((size_t)l.nslots * sizeof(uint2));
-  l.counters = off; off += up256((size_t)3 * l.nreg * sizeof(unsigned));
+  l.part = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
+  l.state = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
+  l.lane_n = off; off += up256((size_t)l.nlanes * sizeof(unsigned));
+  l.dpart = off; off += up256((size_t)l.nlanes * 2 * sizeof(float4));
+  l.counters = off; off += up256((size_t)2 * (l.nreg + 1) * sizeof(unsigned));
   l.total = off;
   return l;
 }
@@ -356,41 +581,67 @@ size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S) {
   if (R <= 0 || S <= 0) return 0;
   return region_layout(X, Y, Z, R, S).total;
 }
+static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
+  char* base = (char*)scratch;
+  BinScratch bs;
+  bs.slot_region = (unsigned*)(base + l.slot_region);
+  bs.slot_pos = (unsigned*)(base + l.slot_pos);
+  bs.slot_seg = (uint2*)(base + l.slot_seg);
+  bs.sorted = (uint2*)(base + l.sorted);
+  bs.part = (float4*)(base + l.part);
+  bs.state = (float4*)(base + l.state);
+  bs.lane_n = (unsigned*)(base + l.lane_n);
+  bs.dpart = (float4*)(base + l.dpart);
+  bs.count = (unsigned*)(base + l.counters);
+  bs.start = bs.count + (l.nreg + 1);
+  return bs;
+}
+
+template <int COUT, int NCM>
+static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st) {
+  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
+  const BinScratch bs = bin_scratch(l, scratch);
+  (void)hipMemsetAsync(bs.lane_n, 0, (size_t)l.nlanes * sizeof(unsigned), st);
+  (void)hipMemsetAsync(bs.count, 0, (size_t)2 * (l.nreg + 1) * sizeof(unsigned), st);
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * nseg;
+  region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, l.nreg + 1);
+  region_fill_kernel<<<(int)((l.nslots + 255) / 256), 256, 0, st>>>(bs, l.nslots);
+  region_fwd_kernel<COUT, NCM><<<l.nreg + 1, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  region_fold_lane_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs);
+  region_combine_kernel<COUT><<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs, a.colour, a.depth, a.acc, a.disparity);
+}
 
 template <int COUT, int NCM>
 static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, void* scratch, hipStream_t st) {
   const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
-  char* base = (char*)scratch;
-  RegionScratch rs;
-  rs.src = (float4*)(base + l.src);
-  rs.slot_region = (unsigned*)(base + l.slot_region);
-  rs.slot_seg = (uint2*)(base + l.slot_seg);
-  rs.sorted = (uint2*)(base + l.sorted);
-  rs.count = (unsigned*)(base + l.counters);
-  rs.start = rs.count + l.nreg;
-  rs.fill = rs.start + l.nreg;
-  (void)hipMemsetAsync(rs.slot_region, 0xFF, (size_t)l.nslots * sizeof(unsigned), st);
-  (void)hipMemsetAsync(rs.count, 0, (size_t)3 * l.nreg * sizeof(unsigned), st);
-  const int nseg = num_segments(c.S, c.seg_len);
-  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * nseg;
-  render_bwd_src_kernel<COUT, NCM><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc,
-                                                      a.d_colour, a.d_depth, a.d_acc, a.ray_state, a.gpacked,
-                                                      a.want_d ? 1 : 0, a.want_f ? 1 : 0, rs);
-  region_scan_kernel<<<1, 1024, 0, st>>>(rs.count, rs.start, l.nreg);
-  region_fill_kernel<<<(int)((l.nslots + 255) / 256), 256, 0, st>>>(rs, l.nslots);
-  constexpr int C = COUT + 1;
-  const int chmask = (a.want_f ? ((1 << COUT) - 1) : 0) | (a.want_d ? (1 << COUT) : 0);
-  render_bwd_region_kernel<C><<<l.nreg, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, a.gpacked, COUT, NCM, chmask, rs);
+  const BinScratch bs = bin_scratch(l, scratch);
+  region_bwd_kernel<COUT, NCM><<<l.nreg + 1, VOXE_REGION_BLOCK, 0, st>>>(
+      g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
+      a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
 }
 
+#define VOXE_REGION_DISPATCH(FN, ...)                            \
+  do {                                                           \
+    if (c.attn) FN<1, 1>(__VA_ARGS__);                           \
+    else if (deg == 0) FN<3, 1>(__VA_ARGS__);                    \
+    else if (deg == 1) FN<3, 4>(__VA_ARGS__);                    \
+    else if (deg == 2) FN<3, 9>(__VA_ARGS__);                    \
+    else FN<3, 16>(__VA_ARGS__);                                 \
+  } while (0)
+
+// forward of the space-binned path: fills the segment tables + per-segment states in `scratch` (the backward reuses them
+// when the caller says they belong to this call: VoxeRenderCfg::ray_state_valid) and the outputs that are not null
+void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
+                       hipStream_t st) {
+  (void)diffuse;
+  VOXE_REGION_DISPATCH(launch_fwd_region_t, g, c, a, scratch, st);
+}
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
                        hipStream_t st) {
   (void)diffuse;
-  if (c.attn) launch_bwd_region_t<1, 1>(g, c, a, scratch, st);
-  else if (deg == 0) launch_bwd_region_t<3, 1>(g, c, a, scratch, st);
-  else if (deg == 1) launch_bwd_region_t<3, 4>(g, c, a, scratch, st);
-  else if (deg == 2) launch_bwd_region_t<3, 9>(g, c, a, scratch, st);
-  else launch_bwd_region_t<3, 16>(g, c, a, scratch, st);
+  VOXE_REGION_DISPATCH(launch_bwd_region_t, g, c, a, scratch, st);
 }
 
 }  // namespace voxe
