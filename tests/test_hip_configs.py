@@ -399,3 +399,20 @@ def test_region_backward_equals_scatter_backward_on_a_random_batch(monkeypatch):
     assert rel_l2(a[0], b[0]) < 5e-5 and rel_l2(a[1], b[1]) < 2e-6, (rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(b[0], rd) < GRAD_TOL and rel_l2(b[1], rf) < GRAD_TOL
+
+
+def test_region_render_generic_bin_vs_oracle(monkeypatch):
+    """few samples over a fine grid (a step of ~4 voxels): nearly every sample starts a new region, a (ray, 32-sample
+    depth segment) lane runs out of its 16 segment slots and the rest of its samples go through the GENERIC bin (texels
+    from global memory, global atomics, shared by many blocks) -- forward and gradients still equal the oracle"""
+    _region_env(monkeypatch)
+    grid = _grid(96, "random")
+    o, d = _rays(200, 13)
+    sel = np.random.default_rng(4).permutation(o.shape[0])[:21000]      # > 20000 rays: 32-sample depth segments
+    o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
+    cfg = make_render_cfg(48, NEAR, FAR, perturb=True, white_bkgd=True, seed=2, rng_offset=3)
+    _check_forward(gh.hip_forward(grid, cfg, o, d, rng=(2, 3)), vo.render_fwd(grid, cfg, o, d))
+    gc = np.random.default_rng(5).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(2, 3))
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))

@@ -47,18 +47,22 @@ constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient win
 #ifndef VOXE_REGION_BLOCK
 #define VOXE_REGION_BLOCK 256      // threads of a region block (its waves share the LDS windows)
 #endif
-constexpr int kSlotsPerLane = 16;  // segment slots of one (ray, depth segment)
+#ifndef VOXE_REGION_SLOTS
+#define VOXE_REGION_SLOTS 16
+#endif
+constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, depth segment)
 constexpr unsigned kNoRegion = 0xFFFFFFFFu;
 
 __host__ __device__ inline int regions_along(int N) { return ((N > 1 ? N - 1 : 1) + kRB - 1) / kRB; }
 
 struct BinScratch {
   unsigned* slot_region;  // [nslots] region of every USED segment slot (nreg: the generic bin); slot j of a lane is used iff j < lane_n
-  unsigned* slot_pos;     // [nslots] rank inside the region (seg kernel), then position in `sorted` (fill kernel)
+  unsigned* slot_pos;     // [nslots] rank of the segment inside its region (returned by the counting atomic)
   uint2* slot_seg;        // [nslots] (ray, k0 | k1 << 16)
-  uint2* sorted;          // [nslots] (ray, k0 | k1 << 16) grouped by region
-  float4* part;           // [nslots][2] by position: forward partials of the segment (Tseg, csum[0..2] | asum, dsum)
-  float4* state;          // [nslots][2] by position: compositing state BEFORE the segment (T, csum[0..2] | asum, dsum)
+  uint4* sorted;          // [nslots] (ray, k0 | k1 << 16, slot, -) grouped by region
+  float4* part;           // [nslots][2] by SLOT: forward partials of the segment (Tseg, csum[0..2] | asum, dsum)
+  float4* state;          // [nslots][2] by SLOT: compositing state BEFORE the segment (T, csum[0..2] | asum, dsum) -- the
+                          // folds walk a lane's slots contiguously; the region kernels scatter / gather by slot
   unsigned* lane_n;       // [R * nseg] segments of every (ray, depth segment) lane
   float4* dpart;          // [R * nseg][2] fold of a lane's segments (local transmittance / partial sums)
   unsigned* count;        // [nreg + 1] segments per region (+ generic bin)
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     footprint(g, p, fp);
     if (!fp.inside) continue;          // contributes nothing (process.py:83): not part of any segment
     Cell cell;
-    make_cell(g, fp, cell);
+    make_cell_fast(g, fp, cell);
     unsigned region = (unsigned)(((cell.i[0] / kRB) * nry + cell.i[1] / kRB) * nrz + cell.i[2] / kRB);
     if (cur == (unsigned)nreg) region = cur;              // the generic bin keeps the rest of this lane's samples
     if (region != cur || (cur != (unsigned)nreg && k - k0 + 1 > VOXE_REGION_CHUNK)) {
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long lo
   if ((unsigned)(i % kSlotsPerLane) >= bs.lane_n[i / kSlotsPerLane]) return;   // unused slot
   const unsigned region = bs.slot_region[i];
   const unsigned pos = bs.start[region] + bs.slot_pos[i];
-  bs.slot_pos[i] = pos;
-  bs.sorted[pos] = bs.slot_seg[i];
+  const uint2 sg = bs.slot_seg[i];
+  bs.sorted[pos] = make_uint4(sg.x, sg.y, (unsigned)i, 0u);
 }
 
 // ---- the region's texels in LDS ----------------------------------------------------------------------------------------------
@@ -233,9 +237,10 @@ struct RegionBlock {
   int ox, oy, oz;   // window origin (voxels)
   bool generic;     // the generic bin: texels from global memory, global atomics
 };
+constexpr int kGenericBlocks = 256;   // blocks that share the generic bin (no LDS involved: any number can work on it)
 __device__ __forceinline__ RegionBlock region_block(const DevGrid& g, unsigned region, int nreg) {
   RegionBlock b;
-  b.generic = region == (unsigned)nreg;
+  b.generic = region >= (unsigned)nreg;
   const int nry = regions_along(g.Y), nrz = regions_along(g.Z);
   b.oz = (int)(region % (unsigned)nrz) * kRB;
   b.oy = (int)((region / (unsigned)nrz) % (unsigned)nry) * kRB;
@@ -253,16 +258,18 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
   constexpr int C = COUT + 1;
   __shared__ float tex[kRWin * C];
   const int tid = threadIdx.x;
-  const unsigned region = blockIdx.x;
+  const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
   const unsigned n = bs.count[region];
   if (n == 0) return;                       // block-uniform
   const unsigned first = bs.start[region];
-  const RegionBlock rb = region_block(g, region, nreg);
+  const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   if (!rb.generic) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
   __syncthreads();
   const float basis0[1] = {kC0};
-  for (unsigned i = tid; i < n; i += VOXE_REGION_BLOCK) {
-    const uint2 rec = bs.sorted[first + i];
+  const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
+  const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
+  for (unsigned i = i_begin; i < n; i += i_step) {
+    const uint4 rec = bs.sorted[first + i];
     const long long r = rec.x;
     const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
     SegRay ray;
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
       footprint(g, p, fp);
       if (!fp.inside) continue;
       Cell cell;
-      make_cell(g, fp, cell);
+      make_cell_fast(g, fp, cell);
       float v, rad[COUT];
       if (rb.generic) {
         gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
@@ -302,8 +309,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
       asum = asum + w;
       dsum = fmaf(z, w, dsum);
     }
-    bs.part[2 * (size_t)(first + i)] = make_float4(T, csum[0], csum[1], csum[2]);
-    bs.part[2 * (size_t)(first + i) + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
+    bs.part[2 * (size_t)rec.z] = make_float4(T, csum[0], csum[1], csum[2]);
+    bs.part[2 * (size_t)rec.z + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
   }
 }
 
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void region_fold_lane_kernel(DevCfg c, BinScra
   float cs[3] = {0.0f, 0.0f, 0.0f};
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
   for (unsigned j = 0; j < n; ++j) {
-    const size_t pos = bs.slot_pos[lane * kSlotsPerLane + j];
+    const size_t pos = (size_t)lane * kSlotsPerLane + j;
     bs.state[2 * pos] = make_float4(T, cs[0], cs[1], cs[2]);
     bs.state[2 * pos + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
     const float4 a = bs.part[2 * pos], b = bs.part[2 * pos + 1];
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256) void region_combine_kernel(DevCfg c, BinScratc
     T = T * a.x;
   }
   for (unsigned j = 0; j < n; ++j) {
-    const size_t pos = bs.slot_pos[lane * kSlotsPerLane + j];
+    const size_t pos = (size_t)lane * kSlotsPerLane + j;
     const float4 a = bs.state[2 * pos], b = bs.state[2 * pos + 1];   // relative to the lane start
     bs.state[2 * pos] = make_float4(T * a.x, fmaf(T, a.y, cs[0]), fmaf(T, a.z, cs[1]), fmaf(T, a.w, cs[2]));
     bs.state[2 * pos + 1] = make_float4(fmaf(T, b.x, asum), fmaf(T, b.y, dsum), 0.0f, 0.0f);
@@ -404,11 +411,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   __shared__ float tex[kRWin * C];
   __shared__ double win[C * kRPlane];
   const int tid = threadIdx.x;
-  const unsigned region = blockIdx.x;
+  const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
   const unsigned n = bs.count[region];
   if (n == 0) return;                       // block-uniform
   const unsigned first = bs.start[region];
-  const RegionBlock rb = region_block(g, region, nreg);
+  const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   if (!rb.generic) {
     load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
     for (int i = tid; i < C * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
@@ -416,14 +423,16 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   __syncthreads();
   const float basis0[1] = {kC0};
   const bool white = c.white && !c.attn;
-  for (unsigned i = tid; i < n; i += VOXE_REGION_BLOCK) {
-    const uint2 rec = bs.sorted[first + i];
+  const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
+  const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
+  for (unsigned i = i_begin; i < n; i += i_step) {
+    const uint4 rec = bs.sorted[first + i];
     const long long r = rec.x;
     const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
     SegRay ray;
     ray.init(g, c, r, rays_o, rays_d, jitter);
     // state before the segment (region_combine_kernel) and the per-ray constants of the backward (render_bwd_kernel)
-    const float4 sa = bs.state[2 * (size_t)(first + i)], sb = bs.state[2 * (size_t)(first + i) + 1];
+    const float4 sa = bs.state[2 * (size_t)rec.z], sb = bs.state[2 * (size_t)rec.z + 1];
     float T = sa.x;
     const float pre_c[3] = {sa.y, sa.z, sa.w};
     const float pre_a = sb.x, pre_d = sb.y;
@@ -456,7 +465,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
       footprint(g, p, fp);
       if (!fp.inside) continue;
       Cell cell;
-      make_cell(g, fp, cell);
+      make_cell_fast(g, fp, cell);
       float v, rad[COUT];
       int idx0 = 0;
       if (rb.generic) {
@@ -568,7 +577,7 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   l.slot_region = off; off += up256((size_t)l.nslots * sizeof(unsigned));
   l.slot_pos = off; off += up256((size_t)l.nslots * sizeof(unsigned));
   l.slot_seg = off; off += up256((size_t)l.nslots * sizeof(uint2));
-  l.sorted = off; off += up256((size_t)l.nslots * sizeof(uint2));
+  l.sorted = off; off += up256((size_t)l.nslots * sizeof(uint4));
   l.part = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
   l.state = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
   l.lane_n = off; off += up256((size_t)l.nlanes * sizeof(unsigned));
@@ -587,7 +596,7 @@ static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
   bs.slot_region = (unsigned*)(base + l.slot_region);
   bs.slot_pos = (unsigned*)(base + l.slot_pos);
   bs.slot_seg = (uint2*)(base + l.slot_seg);
-  bs.sorted = (uint2*)(base + l.sorted);
+  bs.sorted = (uint4*)(base + l.sorted);
   bs.part = (float4*)(base + l.part);
   bs.state = (float4*)(base + l.state);
   bs.lane_n = (unsigned*)(base + l.lane_n);
@@ -608,7 +617,7 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, l.nreg + 1);
   region_fill_kernel<<<(int)((l.nslots + 255) / 256), 256, 0, st>>>(bs, l.nslots);
-  region_fwd_kernel<COUT, NCM><<<l.nreg + 1, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  region_fwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_fold_lane_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs);
   region_combine_kernel<COUT><<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs, a.colour, a.depth, a.acc, a.disparity);
 }
@@ -617,7 +626,7 @@ template <int COUT, int NCM>
 static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, void* scratch, hipStream_t st) {
   const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
   const BinScratch bs = bin_scratch(l, scratch);
-  region_bwd_kernel<COUT, NCM><<<l.nreg + 1, VOXE_REGION_BLOCK, 0, st>>>(
+  region_bwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
       a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
 }
