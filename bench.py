@@ -242,7 +242,7 @@ def main():
     bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
     bytes_bwd = s_in_total * 256 + R * (24 + 12 + 20)
     if ms_bwd >= ms_fwd:
-        bwd_name = "render_bwd_tile_kernel<3,1,1,true,true,0,8>" if args.ray_order == "image" else "render_bwd_packed_scatter_kernel<3,1,1,true,true>"
+        bwd_name = "render_bwd_tile_kernel<3,1,1,true,true,0,8,false>" if args.ray_order == "image" else "region_bwd_kernel<3,1>"
         kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
         kname, kbytes, kms = "render_fwd_seg_kernel<3,1,1>", bytes_fwd, ms_fwd
@@ -266,8 +266,12 @@ def main():
         pmc_rel = os.path.join("profiles", pmc_files[-1])
         pmc = json.load(open(os.path.join(ROOT, pmc_rel)))["kernels"]
         prefix = "voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0," if ms_bwd >= ms_fwd else "voxe::render_fwd_seg_kernel<3, 1, 1>"
-        # (the backward's last template argument is the LDS window width; 400x400 at 160^3 runs the 8-wide one)
-        keys = [k for k in pmc if k.startswith(prefix) and (ms_bwd < ms_fwd or k.rstrip(">").endswith(" 8"))]
+        # (template arguments of the backward: ..., MODE, window width KL[, deterministic]; 400x400 at 160^3 runs the 8-wide
+        #  float-atomic one)
+        def _is_headline_bwd(name):
+            targs = [a.strip() for a in name[name.index("<") + 1: name.rindex(">")].split(",")]
+            return len(targs) >= 7 and targs[6] == "8" and (len(targs) < 8 or targs[7] == "false")
+        keys = [k for k in pmc if k.startswith(prefix) and (ms_bwd < ms_fwd or _is_headline_bwd(k))]
         cnt = pmc[keys[0]] if keys else {}
         if "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
             traffic = int((2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"]) * 1024)
