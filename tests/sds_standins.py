@@ -54,10 +54,26 @@ class _LatentDist:
         return self.mean + self.std * torch.randn_like(self.mean)
 
 
+class _PatchLinear(nn.Module):
+    """a convolution whose kernel equals its stride, written as patchify + matmul: no MIOpen involved (its backward-data
+    kernel for these shapes faults on this ROCm stack -- 'Memory access fault' -- depending on the allocator state;
+    found with the full-size SDS loop test, reproduced with torch.backends.cudnn.enabled = False as the cure)"""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.k, self.lin = k, nn.Linear(cin * k * k, cout)
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        k = self.k
+        p = x.reshape(b, c, h // k, k, w // k, k).permute(0, 2, 4, 1, 3, 5).reshape(b, h // k, w // k, c * k * k)
+        return self.lin(p).permute(0, 3, 1, 2)
+
+
 class AutoencoderKL(nn.Module, _FromPretrained):
     def __init__(self):
         super().__init__()
-        self.enc = nn.Sequential(nn.Conv2d(3, 8, 4, 4), nn.SiLU(), nn.Conv2d(8, 8, 2, 2))   # /8 like the SD VAE
+        self.enc = nn.Sequential(_PatchLinear(3, 8, 4), nn.SiLU(), _PatchLinear(8, 8, 2))   # /8 like the SD VAE
         _seeded(self, 101)
 
     def encode(self, imgs):
@@ -69,16 +85,17 @@ class UNet2DConditionModel(nn.Module, _FromPretrained):
 
     def __init__(self):
         super().__init__()
-        self.conv_in = nn.Conv2d(4, 8, 3, padding=1)
+        self.lin_in = nn.Linear(4, 8)          # pointwise (1x1) layers + a fixed 3x3 box filter for spatial mixing
         self.text = nn.Linear(EMBED_DIM, 8)
-        self.conv_out = nn.Conv2d(8, 4, 3, padding=1)
+        self.lin_out = nn.Linear(8, 4)
         _seeded(self, 202)
 
     def forward(self, x, t, encoder_hidden_states=None):
         temb = torch.sin(t.to(x.dtype).reshape(-1, 1, 1, 1) * 0.01)
         ctx = self.text(encoder_hidden_states).mean(dim=1)[:, :, None, None]   # [B, 8, 1, 1]: text-dependent shift
-        h = torch.tanh(self.conv_in(x) + ctx + temb)
-        return types.SimpleNamespace(sample=self.conv_out(h))
+        mixed = x + torch.nn.functional.avg_pool2d(x, 3, 1, 1)
+        h = torch.tanh(self.lin_in(mixed.permute(0, 2, 3, 1)).permute(0, 3, 1, 2) + ctx + temb)
+        return types.SimpleNamespace(sample=self.lin_out(h.permute(0, 2, 3, 1)).permute(0, 3, 1, 2))
 
 
 class DDIMScheduler(_FromPretrained):

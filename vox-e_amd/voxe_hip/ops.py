@@ -2,6 +2,7 @@
 the whole-grid passes.  Tensors are plumbing (device memory + streams); all compute is in the HIP
 library.  Nothing here falls back to torch ops or to the CPU oracle."""
 import ctypes as C
+import os
 import dataclasses
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
@@ -218,6 +219,11 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_colour, g_depth, g_acc, g_disp):
         densities, features, ro, rd, jit, colour, depth, acc = ctx.saved_tensors
         need_d, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if os.environ.get("VOXE_DEBUG_SYNC"):
+            print("[voxe] _RenderFn.backward entered", None if g_colour is None else (tuple(g_colour.shape), g_colour.dtype,
+                  g_colour.is_contiguous(), g_colour.stride()), g_depth is None, g_acc is None, g_disp is None, flush=True)
+            torch.cuda.synchronize()
+            print("[voxe] sync ok; ws ptr", hex(ctx.workspace.buf.data_ptr()), ctx.workspace.buf.numel(), flush=True)
         if not (need_d or need_f):
             return (None,) * 9
         device = densities.device

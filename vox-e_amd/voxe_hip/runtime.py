@@ -41,10 +41,16 @@ def lib():
     return _lib
 
 
+_DEBUG_SYNC = bool(os.environ.get("VOXE_DEBUG_SYNC"))   # debugging aid: synchronise + log after every library call
+
+
 def check(status: int, what: str) -> None:
     if status != 0:
         msg = lib().voxe_strerror(status).decode()
         raise VoxeError(f"{what}: {msg} (status {status})")
+    if _DEBUG_SYNC:
+        torch.cuda.synchronize()
+        print(f"[voxe] {what} done", flush=True)
 
 
 def require_device(t: torch.Tensor, what: str) -> None:
