@@ -416,3 +416,51 @@ def test_region_render_generic_bin_vs_oracle(monkeypatch):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(2, 3))
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+# ---- LDS-staged forward (render_fwd_tile_kernel) against the ray-ordered forward: bit-identical outputs -------------------
+@pytest.mark.parametrize("case", ["400", "266_oblique", "100_sparse", "multi_view", "clip_jitter_tensor", "lindisp", "tiny_grid"])
+def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, monkeypatch):
+    """same interpolation arithmetic, texels from the LDS window instead of L1 / L2 (or from the global fallback for
+    footprints outside the window: sparse pixels, oblique tiles, tiny grids): every output bit equal, and equal to the
+    oracle within the forward tolerance"""
+    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
+    rng = np.random.default_rng(abs(hash(case)) % 997)
+    kw, over, jit = dict(white_bkgd=True), {}, None
+    if case == "tiny_grid":
+        dens = rng.uniform(-1, 1, (5, 6, 7, 1)).astype(np.float32)
+        feat = rng.uniform(-1, 1, (5, 6, 7, 3)).astype(np.float32)
+        grid = vo.Grid(dens, feat, [(-1.5, 1.5), (-1.2, 1.3), (-1.5, 1.4)], 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+        hw, cam = 40, 5
+    else:
+        grid = _grid(160, "random" if case in ("400", "multi_view") else "sphere")
+        hw, cam = {"400": (400, 3), "266_oblique": (266, 40), "100_sparse": (100, 7), "multi_view": (200, 9),
+                   "clip_jitter_tensor": (240, 11), "lindisp": (320, 21)}[case]
+    o, d = _rays(hw, cam)
+    if case == "multi_view":
+        o2, d2 = _rays(hw, cam + 30)
+        o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+        over["image_height"] = hw
+    S_ = 64 if case == "tiny_grid" else S
+    if case in ("400", "multi_view", "100_sparse"):
+        kw.update(perturb=True, seed=4, rng_offset=2)
+    if case == "clip_jitter_tensor":
+        kw.update(perturb=True, aabb_clip=True)
+        jit = rng.random((o.shape[0], S_)).astype(np.float32)
+    if case == "lindisp":
+        kw.update(linear_disparity=True)
+    cfg = make_render_cfg(S_, NEAR, FAR, **kw)
+    monkeypatch.setenv("VOXE_FWD_TILE", "0")
+    a = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+    monkeypatch.setenv("VOXE_FWD_TILE", "1")
+    b = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+    for key in ("colour", "depth", "acc"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    np.testing.assert_array_equal(np.isnan(a["disparity"]), np.isnan(b["disparity"]))
+    _check_forward(b, vo.render_fwd(grid, cfg, o, d, jitter=jit))
+    # the backward consumes the forward's depth-segment states: gradients unchanged
+    if case in ("400", "266_oblique"):
+        gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+        gb = gh.hip_backward(grid, cfg, o, d, gc, rng=(4, 2), image_width=hw)
+        rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+        assert rel_l2(gb[0], rd) < GRAD_TOL and rel_l2(gb[1], rf) < GRAD_TOL

@@ -56,6 +56,10 @@ bool tile_bwd_supported(const DevCfg& c, int deg);
 // bytes of BwdArgs::sample_src for an image of R rays, width W, S samples (0: that render does not use it)
 size_t tile_src_bytes(long long R, int W, int H, int S, int deg, int diffuse, int attn);
 void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
+// LDS-staged forward for SH-0 image-ordered renders: writes the per-segment partials into a.segbuf (the caller then runs
+// the ordinary combine pass)
+bool fwd_tile_supported(const DevGrid& g, const DevCfg& c, int cout, int ncm);
+void launch_fwd_tile(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st);
 // deterministic (ordered-accumulation) backward: single-group image-ordered renders only
 bool det_bwd_supported(const DevCfg& c, int deg, int diffuse);
 size_t det_bytes(long long nvox, int C);   // [fixed-point gradient | 4 floats], 256-byte aligned parts

@@ -817,8 +817,11 @@ static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hi
     const int nrb64 = c.image_width > 0
                           ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
                           : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64);
-    render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
-        g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
+    if (NCU == 1 && fseg == 1 && fwd_tile_supported(g, c, COUT, NCM))
+      launch_fwd_tile(g, c, a, st);      // texels of a tile staged in LDS (voxe_render_tile.hip)
+    else
+      render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
+          g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
     render_fwd_combine_kernel<COUT><<<(int)((c.R + 255) / 256), 256, 0, st>>>(
         c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
     return;

@@ -554,7 +554,8 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
   const long long min_rays = region_min_rays();
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
   if (!(c.attn || deg == 0 || diffuse)) return false;          // one channel group (SH-0 / diffuse / attention)
-  if (c.R >= (1ll << 32) || c.S >= 65536) return false;        // segment records: 32-bit ray, 16-bit sample indices
+  if (c.R > (1ll << 20) || c.S >= 65536) return false;         // segment records hold 32-bit rays / 16-bit sample indices;
+                                                               // the tables take ~12 KB per ray (S = 256): capped at 1 M rays per launch
   if (!tiled) return true;                                     // unordered rays, images below the tile threshold
   // image-ordered launches: only when the pixels are clearly more than a voxel apart (nothing to combine inside a wave:
   // 100x100 cameras on a 160^3 grid).  The pixel spacing is not known on the host; for a camera that frames the volume

@@ -657,6 +657,222 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Forward with the tile's texels staged in LDS (SH-0 grids, image-ordered rays; r02).
+//
+// The ray-ordered forward (render_fwd_seg_kernel) fetches the 8 corner texels of every sample from L1 / L2: at 400x400 on
+// 160^3 a texel is requested ~13 times by the 64 rays of a tile within one 32-sample segment, and those requests -- not
+// the ~180 VALU instructions of a sample -- pace the kernel (VALU issue 44 % busy).  Here one wave (8x8-pixel tile, depth
+// segment) keeps the same sheared, ray-aligned window as the backward -- a ring of kTexRing layers along the march axis x
+// 8 x 8 lateral voxels, but of TEXELS (float4: 6 KB) -- loads every layer ONCE with one coalesced 1 KB read when the march
+// reaches it, and serves the corner fetches with ds_read_b128.  Samples whose 2x2x2 footprint is not inside the window
+// (oblique tile borders, pixels more than ~0.7 voxel apart) take the global gather: results never depend on the window.
+// Interpolation: the same products and FMA order as gather<3,1,1>() -- bit-identical outputs to render_fwd_seg_kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kTexRing = 6;
+__device__ __forceinline__ int tex_slot(int key) {
+  const int m = key % kTexRing;
+  return m < 0 ? m + kTexRing : m;
+}
+
+__global__ __launch_bounds__(64, 4) void render_fwd_tile_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
+                                                                const float* __restrict__ rays_o,
+                                                                const float* __restrict__ rays_d,
+                                                                const float* __restrict__ jitter,
+                                                                float* __restrict__ segbuf) {
+  constexpr int COUT = 3, NC = COUT + 3;
+  __shared__ float4 tex[kTexRing * 64];
+  const int lane = threadIdx.x;
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nrb = gridDim.x / nseg;                    // tile slots (segment-major block order, like render_fwd_seg_kernel)
+  const int seg = blockIdx.x / nrb, rb = blockIdx.x - seg * nrb;
+  const int W = c.image_width;
+  const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
+  const int tile = logical_tile_of(c, rb, nrb, ntx, nty);
+  if (tile < 0) return;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  long long r_px;
+  const bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  const long long r = alive ? r_px : 0;
+  RayCtx<3, 1, 1> rc;
+  rc.init(g, c, r, rays_o, rays_d, jitter);
+  const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
+  const int k_lo = max(rc.k_lo, ks);
+  const int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
+  const bool has = k_lo <= k_hi;
+  const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
+  const int kmax = wave_max_i32(has ? k_hi : -1);
+  float csum[COUT] = {0.0f, 0.0f, 0.0f};
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  if (kmin <= kmax) {   // wave-uniform
+    // ---- window geometry from the reference ray (as in render_bwd_tile_kernel) ----
+    Window w;
+    w.ctr = Lat<8>::kCentre;
+    {
+      const unsigned long long hm = __ballot(has);
+      const int ref = ((hm >> 27) & 1ull) ? 27 : (__ffsll((long long)hm) - 1);
+      const int N[3] = {g.X, g.Y, g.Z};
+      float U0[3], DU[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
+        const float half = 0.5f * (float)N[a];
+        U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
+        DU[a] = rd * g.scale[a] * half;
+      }
+      const float ax = fabsf(DU[0]), ay = fabsf(DU[1]), az = fabsf(DU[2]);
+      w.m = (ax >= ay && ax >= az) ? 0 : ((ay >= az) ? 1 : 2);
+      w.u = (w.m == 0) ? 1 : 0;
+      w.v = (w.m == 2) ? 1 : 2;
+      const float DUm = (w.m == 0) ? DU[0] : ((w.m == 1) ? DU[1] : DU[2]);
+      const float U0m = (w.m == 0) ? U0[0] : ((w.m == 1) ? U0[1] : U0[2]);
+      const float DUu = (w.u == 0) ? DU[0] : DU[1], U0u = (w.u == 0) ? U0[0] : U0[1];
+      const float DUv = (w.v == 1) ? DU[1] : DU[2], U0v = (w.v == 1) ? U0[1] : U0[2];
+      w.sgn = (DUm < 0.0f) ? -1 : 1;
+      const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
+      w.Bu = DUu * inv; w.Au = U0u - w.Bu * U0m;
+      w.Bv = DUv * inv; w.Av = U0v - w.Bv * U0m;
+      const int sx = g.Y * g.Z, sy = g.Z;
+      w.stride_m = (w.m == 0) ? sx : ((w.m == 1) ? sy : 1);
+      w.stride_u = (w.u == 0) ? sx : sy;
+      w.stride_v = (w.v == 1) ? sy : 1;
+    }
+    const int Nm = (w.m == 0) ? g.X : ((w.m == 1) ? g.Y : g.Z);
+    const int Nu = (w.u == 0) ? g.X : g.Y, Nv = (w.v == 1) ? g.Y : g.Z;
+    auto pick = [&](const int (&t)[3], int axis) { return axis == 0 ? t[0] : (axis == 1 ? t[1] : t[2]); };
+    auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
+    // one coalesced read per layer: lane (a, b) fetches voxel (im, off_u + a, off_v + b) -- b runs along z whenever z is lateral
+    auto load_layer = [&](int key) {
+      const int im = w.sgn * key;
+      const int iu = w.off_u(im) + (lane >> 3), iv = w.off_v(im) + (lane & 7);
+      float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if ((unsigned)im < (unsigned)Nm && (unsigned)iu < (unsigned)Nu && (unsigned)iv < (unsigned)Nv)
+        t = reinterpret_cast<const float4*>(packed)[(long long)im * w.stride_m + (long long)iu * w.stride_u +
+                                                   (long long)iv * w.stride_v];
+      tex[tex_slot(key) * 64 + lane] = t;
+    };
+    float z_cur = 0.0f;
+    Footprint fp_cur;
+    fp_cur.inside = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
+    int first_key = INT_MAX;
+    if (has) {
+      z_cur = rc.dg.z(k_lo);
+      float p[3];
+      rc.point(z_cur, p);
+      footprint(g, p, fp_cur);
+      first_key = minkey(pick(fp_cur.i0, w.m));
+    }
+    w.base = wave_min_i32(first_key);
+    for (int i = 0; i < kTexRing; ++i) load_layer(w.base + i);
+    __syncthreads();
+    for (int k = kmin; k <= kmax; ++k) {
+      const bool on = has && (k >= k_lo) && (k <= k_hi);
+      if (on) {
+        const float z = z_cur;
+        const Footprint fp = fp_cur;
+        const bool last = (k == c.S - 1);
+        float z_next = z;
+        if (!last) {
+          z_next = rc.dg.z(k + 1);
+          float pn[3];
+          rc.point(z_next, pn);
+          footprint(g, pn, fp_cur);
+          z_cur = z_next;
+        }
+        if (fp.inside) {
+          Cell cell;
+          make_cell_fast(g, fp, cell);
+          const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
+          int lofs[2], ab0[2];
+          bool fits = true;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int im = pm + s, key = w.sgn * im;
+            const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
+            fits = fits && ((unsigned)(key - w.base) < (unsigned)kTexRing) && ((unsigned)a0 < 7u) && ((unsigned)b0 < 7u);
+            lofs[s] = tex_slot(key) * 64;
+            ab0[s] = a0 * 8 + b0;
+          }
+          float v, rad[COUT];
+          if (fits) {
+            // gather<3,1,1>() with the eight texels read from the window: corner k = (x + (k & 1), y + ((k >> 1) & 1), z + (k >> 2))
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            float wxy[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wxy[q] = cell.w[0][q & 1] * cell.w[1][q >> 1];
+            v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int dm = (q >> w.m) & 1, du = (q >> w.u) & 1, dv = (q >> w.v) & 1;   // wave-uniform shifts
+              const float4 t = tex[(dm ? lofs[1] : lofs[0]) + (dm ? ab0[1] : ab0[0]) + du * 8 + dv];
+              const float wq = wxy[q & 3] * cell.w[2][q >> 2];
+              const v2f ww = {wq, wq};
+              const v2f a = {t.x, t.y}, b = {t.z, t.w};
+              rg = __builtin_elementwise_fma(a, ww, rg);
+              bs = __builtin_elementwise_fma(b, ww, bs);
+            }
+            rad[0] = rc.basis[0] * rg.x; rad[1] = rc.basis[0] * rg.y; rad[2] = rc.basis[0] * bs.x; v = bs.y;
+          } else {
+            gather<3, 1, 1>(g, packed, cell, rc.basis, v, rad);
+          }
+          const float sigma = post_activate(g.post_act, v);
+          const float dl = last ? kInfinity : (z_next - z);
+          const float delta = dl * rc.dnorm;
+          const float e = fast_exp(-(sigma * delta));
+          const float alpha = 1.0f - e;
+          const float om = 1.0f - alpha;
+          const float wgt = alpha * T;
+          T = T * om;
+#pragma unroll
+          for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), wgt, csum[ch]);
+          asum = asum + wgt;
+          dsum = fmaf(z, wgt, dsum);
+        }
+      }
+      // ---- slide the window: bring in the layers the march reaches next ----
+      int lb = INT_MAX;
+      if (has) {
+        if (k + 1 < k_lo) lb = first_key;
+        else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
+      }
+      const int newbase = wave_min_i32(lb);
+      if (newbase > w.base && newbase != INT_MAX) {   // wave-uniform
+        __syncthreads();
+        const int from = max(w.base + kTexRing, newbase);
+        for (int key = from; key < newbase + kTexRing; ++key) load_layer(key);
+        w.base = newbase;
+        __syncthreads();
+      }
+    }
+  }
+  if (!alive) return;
+  const long long base = (long long)seg * NC;
+  segbuf[(base + 0) * c.R + r] = T;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) segbuf[(base + 1 + ch) * c.R + r] = csum[ch];
+  segbuf[(base + 1 + COUT) * c.R + r] = asum;
+  segbuf[(base + 2 + COUT) * c.R + r] = dsum;
+}
+
+// The LDS-staged forward is OFF by default: measured on MI355X it is 12 % SLOWER than the ray-ordered forward (400x400 on
+// 160^3: 0.273 vs 0.243 ms; 266x266: 0.164 vs 0.142; 800x800 on 256^3: 1.03 vs 0.89 -- profiles/r02_ab_fwd_tile.txt): L1
+// already captures the texel reuse of a tile, and the lock-step march + window bookkeeping cost more issue slots than the
+// LDS reads save.  Kept as an A/B switch (VOXE_FWD_TILE = 1, read per launch) and as a bit-exactness cross-check of the
+// forward (tests/test_hip_configs.py::test_lds_staged_forward_*).
+bool fwd_tile_supported(const DevGrid& g, const DevCfg& c, int cout, int ncm) {
+  (void)g;
+  if (cout != 3 || ncm != 1 || c.image_width <= 0 || c.term_eps > 0.0f) return false;
+  const char* e = getenv("VOXE_FWD_TILE");
+  return e && e[0] == '1';
+}
+void launch_fwd_tile(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
+  render_fwd_tile_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
+}
+
 // Images of a few thousand rays leave the chip empty whatever the kernel and usually have pixels far apart (little to
 // combine in LDS): the depth-segmented line-dense scatter is faster there (64x64: 0.18 vs 0.40 ms; 100x100: 0.40 vs 0.31 ms).
 // VOXE_TILE_MIN_RAYS overrides the threshold (the parity tests set 0 so that small images exercise this kernel).
