@@ -27,7 +27,13 @@ constexpr int kSegLen = VOXE_SEGMENT_SAMPLES;
 #ifndef VOXE_SEG16_MAX_RAYS
 #define VOXE_SEG16_MAX_RAYS 20000
 #endif
-__host__ __device__ inline int seg_len_for(long long R) { return (R <= VOXE_SEG16_MAX_RAYS && kSegLen > 16) ? 16 : kSegLen; }
+#ifndef VOXE_SEG8_MAX_RAYS
+#define VOXE_SEG8_MAX_RAYS 0     // (8-sample segments for the smallest launches: measured, no gain -- see DESIGN.md 4.9)
+#endif
+__host__ __device__ inline int seg_len_for(long long R) {
+  if (R <= VOXE_SEG8_MAX_RAYS && kSegLen > 8) return 8;
+  return (R <= VOXE_SEG16_MAX_RAYS && kSegLen > 16) ? 16 : kSegLen;
+}
 __host__ __device__ inline int num_segments(int S, int seg_len) { return (S + seg_len - 1) / seg_len; }
 __device__ __forceinline__ long long ray_state_index(int boundary, int comp, int ncomp, long long R, long long r) {
   return ((long long)(boundary - 1) * ncomp + comp) * R + r;
