@@ -108,7 +108,10 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
             # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
             picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
             rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
-                intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks, memory_order=True, fast_subset=True)
+                intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks,
+                # (sorting the batch by (camera, row, column) helps the ray-ordered gather of small batches; batches of 16384+
+                #  rays take the space-binned render, which does not care about the order: skip the sort)
+                memory_order=ray_batch_size < 16384, fast_subset=True)
 
             specular = vol_mod.render_rays(rays_batch).colour
             loss = torch.nn.functional.l1_loss(specular, pixels_batch)
