@@ -37,9 +37,19 @@
 
 namespace voxe {
 
-constexpr int kRB = 8;             // region edge in cells (low-corner indices)
-constexpr int kRW = kRB + 1;       // window edge in voxels
-constexpr int kRWin = kRW * kRW * kRW;      // 729 voxels
+// region edges in cells (low-corner indices) along x / y / z; a window is one voxel wider per axis
+#ifndef VOXE_REGION_BX
+#define VOXE_REGION_BX 8
+#endif
+#ifndef VOXE_REGION_BY
+#define VOXE_REGION_BY 8
+#endif
+#ifndef VOXE_REGION_BZ
+#define VOXE_REGION_BZ 8
+#endif
+constexpr int kRBX = VOXE_REGION_BX, kRBY = VOXE_REGION_BY, kRBZ = VOXE_REGION_BZ;
+constexpr int kRWX = kRBX + 1, kRWY = kRBY + 1, kRWZ = kRBZ + 1;
+constexpr int kRWin = kRWX * kRWY * kRWZ;   // 729 voxels for 8 x 8 x 8 cells
 constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient window (doubles), padded off the bank period
 #ifndef VOXE_REGION_CHUNK
 #define VOXE_REGION_CHUNK 16       // longest segment (samples): bounds the lane divergence of the region kernels
@@ -52,11 +62,17 @@ constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient win
 #endif
 constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, depth segment)
 constexpr unsigned kNoRegion = 0xFFFFFFFFu;
+// Segments of a region are grouped by LENGTH class (longest first): the lanes of a wave then run similar trip counts
+// instead of all waiting for the longest segment among 64 random ones (mean length ~5, cap 16).
+constexpr int kLenClasses = 4;
+__host__ __device__ inline int len_class(int len) { return len >= 9 ? 0 : (len >= 5 ? 1 : (len >= 3 ? 2 : 3)); }
+constexpr unsigned kRegionMask = 0x00FFFFFFu;   // slot_region = region | class << 24
 
-__host__ __device__ inline int regions_along(int N) { return ((N > 1 ? N - 1 : 1) + kRB - 1) / kRB; }
+__host__ __device__ inline int regions_along(int N, int edge) { return ((N > 1 ? N - 1 : 1) + edge - 1) / edge; }
 
 struct BinScratch {
-  unsigned* slot_region;  // [nslots] region of every USED segment slot (nreg: the generic bin); slot j of a lane is used iff j < lane_n
+  unsigned* slot_region;  // [nslots] region | length class << 24 of every USED segment slot (region nreg: the generic bin);
+                          // slot j of a lane is used iff j < lane_n
   unsigned* slot_pos;     // [nslots] rank of the segment inside its region (returned by the counting atomic)
   uint2* slot_seg;        // [nslots] (ray, k0 | k1 << 16)
   uint4* sorted;          // [nslots] (ray, k0 | k1 << 16, slot, -) grouped by region
@@ -65,8 +81,9 @@ struct BinScratch {
                           // folds walk a lane's slots contiguously; the region kernels scatter / gather by slot
   unsigned* lane_n;       // [R * nseg] segments of every (ray, depth segment) lane
   float4* dpart;          // [R * nseg][2] fold of a lane's segments (local transmittance / partial sums)
-  unsigned* count;        // [nreg + 1] segments per region (+ generic bin)
-  unsigned* start;        // [nreg + 1] first position of the region in `sorted`
+  unsigned* count;        // [(nreg + 1) * 4 + 1] segments per (region, length class) (+ generic bin; last entry stays 0)
+  unsigned* start;        // [(nreg + 1) * 4 + 1] exclusive scan of `count`: first position in `sorted`; a region's segments are
+                          // start[region * 4] .. start[(region + 1) * 4]
 };
 
 // ---- ray context of a segment lane: origin, direction, depth generator (no sample range, no SH basis) ----------------------
@@ -112,16 +129,17 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
   const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
   if (k_lo > k_hi) return;
-  const int nry = regions_along(g.Y), nrz = regions_along(g.Z);
+  const int nry = regions_along(g.Y, kRBY), nrz = regions_along(g.Z, kRBZ);
   const long long slot0 = (r * nseg + seg) * kSlotsPerLane;
   int nslots = 0;
   unsigned cur = kNoRegion;
   int k0 = 0, k_prev = 0;
   auto emit = [&](int k_end) {
     if (cur == kNoRegion) return;
-    bs.slot_region[slot0 + nslots] = cur;
+    const unsigned cls = (unsigned)len_class(k_end - k0 + 1);
+    bs.slot_region[slot0 + nslots] = cur | (cls << 24);
     bs.slot_seg[slot0 + nslots] = make_uint2((unsigned)r, (unsigned)k0 | ((unsigned)k_end << 16));
-    bs.slot_pos[slot0 + nslots] = atomicAdd(bs.count + cur, 1u);   // rank of this segment inside its region
+    bs.slot_pos[slot0 + nslots] = atomicAdd(bs.count + cur * kLenClasses + cls, 1u);   // rank inside (region, class)
     ++nslots;
   };
   for (int k = k_lo; k <= k_hi; ++k) {
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     if (!fp.inside) continue;          // contributes nothing (process.py:83): not part of any segment
     Cell cell;
     make_cell_fast(g, fp, cell);
-    unsigned region = (unsigned)(((cell.i[0] / kRB) * nry + cell.i[1] / kRB) * nrz + cell.i[2] / kRB);
+    unsigned region = (unsigned)(((cell.i[0] / kRBX) * nry + cell.i[1] / kRBY) * nrz + cell.i[2] / kRBZ);
     if (cur == (unsigned)nreg) region = cur;              // the generic bin keeps the rest of this lane's samples
     if (region != cur || (cur != (unsigned)nreg && k - k0 + 1 > VOXE_REGION_CHUNK)) {
       emit(k_prev);
@@ -171,8 +189,8 @@ __global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long lo
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nslots) return;
   if ((unsigned)(i % kSlotsPerLane) >= bs.lane_n[i / kSlotsPerLane]) return;   // unused slot
-  const unsigned region = bs.slot_region[i];
-  const unsigned pos = bs.start[region] + bs.slot_pos[i];
+  const unsigned rc = bs.slot_region[i];
+  const unsigned pos = bs.start[(rc & kRegionMask) * kLenClasses + (rc >> 24)] + bs.slot_pos[i];
   const uint2 sg = bs.slot_seg[i];
   bs.sorted[pos] = make_uint4(sg.x, sg.y, (unsigned)i, 0u);
 }
@@ -185,7 +203,7 @@ __device__ __forceinline__ void load_window(const DevGrid& g, const float* __res
                                             int ox, int oy, int oz, int tid) {
   constexpr int C = COUT + 1, CM = COUT * NCM + 1;
   for (int v = tid; v < kRWin; v += VOXE_REGION_BLOCK) {
-    const int x = ox + v / (kRW * kRW), y = oy + (v / kRW) % kRW, z = oz + v % kRW;
+    const int x = ox + v / (kRWY * kRWZ), y = oy + (v / kRWZ) % kRWY, z = oz + v % kRWZ;
     const bool in = x < g.X && y < g.Y && z < g.Z;
     const long long vox = ((long long)x * g.Y + y) * g.Z + z;
     if constexpr (CM == 4) {
@@ -211,7 +229,7 @@ __device__ __forceinline__ void gather_lds(const float* __restrict__ tex, int id
     v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float4 t = reinterpret_cast<const float4*>(tex)[idx0 + (k & 1) * (kRW * kRW) + ((k >> 1) & 1) * kRW + (k >> 2)];
+      const float4 t = reinterpret_cast<const float4*>(tex)[idx0 + (k & 1) * (kRWY * kRWZ) + ((k >> 1) & 1) * kRWZ + (k >> 2)];
       const float w = wxy[k & 3] * cell.w[2][k >> 2];
       const v2f ww = {w, w};
       const v2f a = {t.x, t.y}, b = {t.z, t.w};
@@ -224,7 +242,7 @@ __device__ __forceinline__ void gather_lds(const float* __restrict__ tex, int id
     v = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float2 t = reinterpret_cast<const float2*>(tex)[idx0 + (k & 1) * (kRW * kRW) + ((k >> 1) & 1) * kRW + (k >> 2)];
+      const float2 t = reinterpret_cast<const float2*>(tex)[idx0 + (k & 1) * (kRWY * kRWZ) + ((k >> 1) & 1) * kRWZ + (k >> 2)];
       const float w = wxy[k & 3] * cell.w[2][k >> 2];
       f = fmaf(t.x, w, f);
       v = fmaf(t.y, w, v);
@@ -241,10 +259,10 @@ constexpr int kGenericBlocks = 256;   // blocks that share the generic bin (no L
 __device__ __forceinline__ RegionBlock region_block(const DevGrid& g, unsigned region, int nreg) {
   RegionBlock b;
   b.generic = region >= (unsigned)nreg;
-  const int nry = regions_along(g.Y), nrz = regions_along(g.Z);
-  b.oz = (int)(region % (unsigned)nrz) * kRB;
-  b.oy = (int)((region / (unsigned)nrz) % (unsigned)nry) * kRB;
-  b.ox = (int)(region / (unsigned)(nrz * nry)) * kRB;
+  const int nry = regions_along(g.Y, kRBY), nrz = regions_along(g.Z, kRBZ);
+  b.oz = (int)(region % (unsigned)nrz) * kRBZ;
+  b.oy = (int)((region / (unsigned)nrz) % (unsigned)nry) * kRBY;
+  b.ox = (int)(region / (unsigned)(nrz * nry)) * kRBX;
   return b;
 }
 
@@ -259,9 +277,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
   __shared__ float tex[kRWin * C];
   const int tid = threadIdx.x;
   const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
-  const unsigned n = bs.count[region];
+  const unsigned first = bs.start[region * kLenClasses];
+  const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
   if (n == 0) return;                       // block-uniform
-  const unsigned first = bs.start[region];
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   if (!rb.generic) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
   __syncthreads();
@@ -293,8 +311,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
         gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
       } else {
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
-        if ((unsigned)lx >= (unsigned)kRB || (unsigned)ly >= (unsigned)kRB || (unsigned)lz >= (unsigned)kRB) continue;
-        gather_lds<COUT>(tex, (lx * kRW + ly) * kRW + lz, cell, v, rad);
+        if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
+        gather_lds<COUT>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, v, rad);
       }
       const float sigma = post_activate(g.post_act, v);
       const float dl = last ? kInfinity : (z_next - z);
@@ -412,9 +430,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   __shared__ double win[C * kRPlane];
   const int tid = threadIdx.x;
   const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
-  const unsigned n = bs.count[region];
+  const unsigned first = bs.start[region * kLenClasses];
+  const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
   if (n == 0) return;                       // block-uniform
-  const unsigned first = bs.start[region];
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   if (!rb.generic) {
     load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
@@ -472,8 +490,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
         gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
       } else {
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
-        if ((unsigned)lx >= (unsigned)kRB || (unsigned)ly >= (unsigned)kRB || (unsigned)lz >= (unsigned)kRB) continue;
-        idx0 = (lx * kRW + ly) * kRW + lz;
+        if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
+        idx0 = (lx * kRWY + ly) * kRWZ + lz;
         gather_lds<COUT>(tex, idx0, cell, v, rad);
       }
       float sigma, dpost;
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float w = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
-          const int idx = idx0 + (j & 1) * (kRW * kRW) + ((j >> 1) & 1) * kRW + (j >> 2);
+          const int idx = idx0 + (j & 1) * (kRWY * kRWZ) + ((j >> 1) & 1) * kRWZ + (j >> 2);
 #pragma unroll
           for (int ch = 0; ch < C; ++ch) {
             if ((ch < COUT) ? want_f : want_d)
@@ -537,7 +555,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
     const int vl = e / C, ch = e - vl * C;
     const double val = win[ch * kRPlane + vl];
     if (val == 0.0) continue;
-    const int x = rb.ox + vl / (kRW * kRW), y = rb.oy + (vl / kRW) % kRW, zz = rb.oz + vl % kRW;
+    const int x = rb.ox + vl / (kRWY * kRWZ), y = rb.oy + (vl / kRWZ) % kRWY, zz = rb.oz + vl % kRWZ;
     if (x >= g.X || y >= g.Y || zz >= g.Z) continue;   // (weight-0 corners of size-1 axes / beyond the grid's far faces)
     const long long vox = ((long long)x * g.Y + y) * g.Z + zz;
     atomicAdd(gpacked + vox * CM + (ch == COUT ? CM - 1 : ch * NCM), (float)val);
@@ -573,7 +591,7 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   const int nseg = num_segments(S, seg_len_for(R));
   l.nslots = R * nseg * kSlotsPerLane;
   l.nlanes = R * nseg;
-  l.nreg = regions_along(X) * regions_along(Y) * regions_along(Z);
+  l.nreg = regions_along(X, kRBX) * regions_along(Y, kRBY) * regions_along(Z, kRBZ);
   size_t off = 0;
   l.slot_region = off; off += up256((size_t)l.nslots * sizeof(unsigned));
   l.slot_pos = off; off += up256((size_t)l.nslots * sizeof(unsigned));
@@ -583,7 +601,7 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   l.state = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
   l.lane_n = off; off += up256((size_t)l.nlanes * sizeof(unsigned));
   l.dpart = off; off += up256((size_t)l.nlanes * 2 * sizeof(float4));
-  l.counters = off; off += up256((size_t)2 * (l.nreg + 1) * sizeof(unsigned));
+  l.counters = off; off += up256((size_t)2 * ((l.nreg + 1) * kLenClasses + 1) * sizeof(unsigned));
   l.total = off;
   return l;
 }
@@ -603,7 +621,7 @@ static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
   bs.lane_n = (unsigned*)(base + l.lane_n);
   bs.dpart = (float4*)(base + l.dpart);
   bs.count = (unsigned*)(base + l.counters);
-  bs.start = bs.count + (l.nreg + 1);
+  bs.start = bs.count + ((l.nreg + 1) * kLenClasses + 1);
   return bs;
 }
 
@@ -612,11 +630,11 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
   const BinScratch bs = bin_scratch(l, scratch);
   (void)hipMemsetAsync(bs.lane_n, 0, (size_t)l.nlanes * sizeof(unsigned), st);
-  (void)hipMemsetAsync(bs.count, 0, (size_t)2 * (l.nreg + 1) * sizeof(unsigned), st);
+  (void)hipMemsetAsync(bs.count, 0, (size_t)2 * ((l.nreg + 1) * kLenClasses + 1) * sizeof(unsigned), st);
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * nseg;
   region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
-  region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, l.nreg + 1);
+  region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
   region_fill_kernel<<<(int)((l.nslots + 255) / 256), 256, 0, st>>>(bs, l.nslots);
   region_fwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_fold_lane_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs);
