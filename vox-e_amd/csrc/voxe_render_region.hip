@@ -61,6 +61,9 @@ constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient win
 #define VOXE_REGION_SLOTS 16
 #endif
 constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, depth segment)
+#ifndef VOXE_REGION_BWD_TEX
+#define VOXE_REGION_BWD_TEX 1      // backward: stage the region's texels in LDS too (0: gather them from L1 / L2)
+#endif
 constexpr unsigned kNoRegion = 0xFFFFFFFFu;
 // Segments of a region are grouped by LENGTH class (longest first): the lanes of a wave then run similar trip counts
 // instead of all waiting for the longest segment among 64 random ones (mean length ~5, cap 16).
@@ -457,7 +460,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
     const float* __restrict__ d_acc, float* __restrict__ gpacked, const int want_d, const int want_f, BinScratch bs,
     const int nreg) {
   constexpr int C = COUT + 1, CM = COUT * NCM + 1;
-  __shared__ float tex[kRWin * C];
+  constexpr bool kTexLds = VOXE_REGION_BWD_TEX != 0;
+  __shared__ float tex[kTexLds ? kRWin * C : 1];
   __shared__ double win[C * kRPlane];
   const int tid = threadIdx.x;
   const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   if (n == 0) return;                       // block-uniform
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   if (!rb.generic) {
-    load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+    if constexpr (kTexLds) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
     for (int i = tid; i < C * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
   }
   __syncthreads();
@@ -524,7 +528,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
         if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
         idx0 = (lx * kRWY + ly) * kRWZ + lz;
-        gather_lds<COUT>(tex, idx0, cell, v, rad);
+        if constexpr (kTexLds) gather_lds<COUT>(tex, idx0, cell, v, rad);
+        else gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
       }
       float sigma, dpost;
       post_activate_vg(g.post_act, v, sigma, dpost);
