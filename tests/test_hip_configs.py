@@ -464,3 +464,23 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, mo
         gb = gh.hip_backward(grid, cfg, o, d, gc, rng=(4, 2), image_width=hw)
         rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
         assert rel_l2(gb[0], rd) < GRAD_TOL and rel_l2(gb[1], rf) < GRAD_TOL
+
+
+# ---- view-dependent field (SH degree 1: 13-channel texels) at the full grid size: both backward routes vs the oracle ----------
+@pytest.mark.parametrize("order", ["image", "random"])
+def test_sh1_160_full_size_vs_oracle(order):
+    """f3 at BASELINE size: 160^3 grid with 12 feature channels (SH-1), S = 256; a 400x400 camera through the two-phase
+    LDS-window backward (channel groups) and a 32400-ray random batch through the line-dense scatter"""
+    dens, feat = random_grid(160, nfeat=12, seed=7)
+    grid = vo.Grid(dens.numpy(), 0.3 * feat.numpy(), AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    o, d = _rays(400, 27)
+    over = dict(image_width=400)
+    if order == "random":
+        sel = np.random.default_rng(1).permutation(o.shape[0])[:32400]
+        o, d, over = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel]), {}
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, sh_degree=1, seed=12, rng_offset=5)
+    _check_forward(gh.hip_forward(grid, cfg, o, d, rng=(12, 5), **over), vo.render_fwd(grid, cfg, o, d))
+    gc = np.random.default_rng(2).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(12, 5), **over)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
