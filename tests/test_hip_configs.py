@@ -484,3 +484,24 @@ def test_sh1_160_full_size_vs_oracle(order):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(12, 5), **over)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+# ---- the reference's real-scene configuration: 200^3 grid, 416 samples per ray, linear-disparity sampling --------------------
+def test_real_scene_config_200_grid_416_samples_lindisp_vs_oracle():
+    """bash_scripts/real_scenes/train_default_relu_field_real.sh:22-28 (grid 200^3, num_samples_per_ray 416,
+    linear_disparity_sampling): forward and gradients of a 400x400 camera and of a 32768-ray random batch vs the oracle"""
+    dens, feat = random_grid(200, seed=11)
+    grid = vo.Grid(dens.numpy(), feat.numpy(), AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+    cfg = make_render_cfg(416, NEAR, FAR, perturb=True, linear_disparity=True, white_bkgd=True, seed=21, rng_offset=4)
+    o, d = _rays(400, 33)
+    _check_forward(gh.hip_forward(grid, cfg, o, d, rng=(21, 4), image_width=400), vo.render_fwd(grid, cfg, o, d))
+    gc = np.random.default_rng(3).standard_normal((o.shape[0], 3)).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(21, 4), image_width=400)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+    sel = np.random.default_rng(4).permutation(o.shape[0])[:32768]
+    o2, d2, g2 = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel]), np.ascontiguousarray(gc[sel])
+    _check_forward(gh.hip_forward(grid, cfg, o2, d2, rng=(21, 4)), vo.render_fwd(grid, cfg, o2, d2))
+    gd, gf = gh.hip_backward(grid, cfg, o2, d2, g2, rng=(21, 4))
+    rd, rf = vo.render_bwd(grid, cfg, o2, d2, g2)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
