@@ -66,6 +66,9 @@ __device__ __forceinline__ int ring_slot(int key) {
 #ifndef VOXE_TILE_F64MUL
 #define VOXE_TILE_F64MUL 0
 #endif
+#ifndef VOXE_TILE_SLIDE_MIN
+#define VOXE_TILE_SLIDE_MIN 1
+#endif
 // LDS mapping constants, swept on hardware with tools/variants.py + tools/ab_variants.sh (three cameras): channel
 // rotation by lane & 3 instead of (lane >> 1) & 3: backward -6.5 %; layer rotation 9 / 17 / 25 ~ equal, 21 +0.4 %;
 // plane padding 6 ~ 10 < 2 < 4 << 8 (+35 %: bank aliasing)
@@ -611,7 +614,9 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
         else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
       }
       const int newbase = wave_min_i32(lb);
-      if (newbase > w.base) {  // wave-uniform
+      // VOXE_TILE_SLIDE_MIN > 1: let the window lag -- flush only once that many layers can go at once (every flush
+      // drains the wave's LDS queue: fewer, larger flushes; the ring must hold the extra layers)
+      if (newbase >= w.base + VOXE_TILE_SLIDE_MIN) {  // wave-uniform
         __syncthreads();
         const long long adv = (long long)newbase - (long long)w.base;
         const int nflush = adv < kRing ? (int)adv : kRing;
