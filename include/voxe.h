@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 5
+#define VOXE_ABI_VERSION 6
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -299,8 +299,37 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
                         const float* extra_d_densities, const float* extra_d_features,
                         float* exp_avg_densities, float* exp_avg_sq_densities,
                         float* exp_avg_features, float* exp_avg_sq_features,
-                        float lr, float beta1, float beta2, float eps, int64_t step,
+                        float lr, float beta1, float beta2, float eps, int64_t step, int64_t step_features,
                         void* workspace, size_t workspace_bytes, void* stream);
+/*   `step` / `step_features`: the 1-based Adam step counts of the densities and of the features (torch.optim.Adam keeps
+ *   one counter per parameter; step_features = 0 means "the same as step").                                          */
+
+/* Which kernels render (grid, cfg, R).  The per-ray states a forward leaves in the workspace belong to ONE route, so a
+ * caller that sets cfg->ray_state_valid must know that forward and backward resolve to the same one (the choice also
+ * depends on process-level tuning switches); negative VOXE_ERR_* below -1 for invalid arguments.                      */
+enum { VOXE_ROUTE_NONE = -1, VOXE_ROUTE_SCATTER = 0, VOXE_ROUTE_TILE = 1, VOXE_ROUTE_PACKED_SCATTER = 2,
+       VOXE_ROUTE_REGION = 3, VOXE_ROUTE_DETERMINISTIC = 4 };
+int voxe_render_route(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R);
+
+/* disparity = 1 / max(1e-10, depth / acc)   rendering/volumetric/accumulate.py:85-88
+ *   chain rule of an upstream d_disparity [R] into d_depth / d_acc (what autograd does through those three tensor ops):
+ *   d_depth_out = d_depth_in + dq / acc,  d_acc_out = d_acc_in - dq * depth / acc^2,  dq = -d_disparity / q^2 where
+ *   q = depth / acc > 1e-10, 0 elsewhere (and wherever a term is NaN / infinite: rays that miss the volume).
+ *   d_*_in may be NULL (= 0); the outputs may alias the inputs.                                                       */
+int voxe_disparity_bwd(const float* depth, const float* acc, const float* d_disparity, const float* d_depth_in,
+                       const float* d_acc_in, float* d_depth_out, float* d_acc_out, int64_t R, void* stream);
+
+/* Measurement aids (bench.py, tests): not part of the reference's interface.
+ * voxe_clock_probe        sustained shader clock in Hz: a chip-filling VALU + LDS kernel on `stream` reads the shader-clock
+ *                         and the constant reference-clock counters around its loop (blocking; `spin` iterations per
+ *                         thread, <= 0: default, ~0.3 ms of device time);
+ * voxe_region_debug_layout byte offsets (from the start of the workspace) and dimensions of the segment tables of the
+ *                         space-binned route: out[0] = offset of the region scratch, out[1..16] = {slot_region, slot_pos,
+ *                         slot_seg, sorted, lane_n, count, start} offsets inside it, nslots, nlanes, nreg, slots per
+ *                         lane, region edge x / y / z (cells), length classes, longest segment; VOXE_ERR_UNSUPPORTED when
+ *                         (grid, cfg, R) does not take that route.                                                    */
+int voxe_clock_probe(int32_t spin, double* shader_hz, void* stream);
+int voxe_region_debug_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R, int64_t out[17]);
 
 /* torch.optim.Adam(betas, eps, weight_decay=0, amsgrad=False) single-tensor step
  *   modules/sds_trainer.py:200-203, modules/trainers.py:247-255; `step` is the 1-based step count. */

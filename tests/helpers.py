@@ -43,3 +43,19 @@ def nan_equal(a, b, rtol, atol):
     na, nb = np.isnan(a), np.isnan(b)
     assert np.array_equal(na, nb), "NaN pattern differs"
     np.testing.assert_allclose(a[~na], b[~nb], rtol=rtol, atol=atol)
+
+
+def band_errors(got, ref, bands):
+    """relative error of `got` per magnitude band of the reference: for every (lo, hi] in `bands` (fractions of max |ref|)
+    that holds at least one element -> (count, median of |got - ref| / |ref|, 99th percentile)"""
+    ref = np.asarray(ref, np.float64).ravel()
+    err = np.abs(np.asarray(got, np.float64).ravel() - ref)
+    mag = np.abs(ref)
+    big = float(mag.max())
+    out = {}
+    for lo, hi in bands:
+        m = (mag > lo * big) & (mag <= hi * big)
+        if m.any():
+            rel = err[m] / mag[m]
+            out[(lo, hi)] = (int(m.sum()), float(np.median(rel)), float(np.quantile(rel, 0.99)))
+    return out

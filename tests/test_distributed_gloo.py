@@ -241,6 +241,23 @@ def _sharded_worker(rank, world, port, results):
             assert torch.equal(d[other], dens0[other]), "a rank must not touch the raw parameters outside its slab"
         opt.gather_parameters()
         assert torch.equal(d, rd) and torch.equal(f, rf), name
+        if name == "indivisible":
+            # a backend WITHOUT all-to-all: uneven slabs only run as the direct exchange, so the step takes the
+            # replicated all-reduce step instead of crashing in a collective the backend lacks; autotune() times
+            # "reduce-scatter" and "all-to-all" only once when they are the same code path
+            d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
+            opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps)
+            opt.supported = {"reduce-scatter": True, "all-to-all": False, "all-reduce": True}
+            for per_rank in grads:
+                _CpuOps.store_gradient(ws, per_rank[rank], layout)
+                opt.step(ws, layout)
+            assert opt.mode.startswith("all-reduce"), opt.mode
+            assert torch.equal(ws.packed, rws.packed) and torch.equal(d, rd) and torch.equal(f, rf)
+            d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
+            ws.packed.copy_(torch.cat((f, d), dim=-1).reshape(-1))
+            opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps)
+            opt.autotune(ws, layout, iters=1)
+            assert opt.tuned_ms["reduce-scatter"] is None and opt.tuned_ms["all-to-all"] is not None
     assert modes["linear"].startswith("reduce-scatter") and modes["bricked"].startswith("reduce-scatter")
     assert modes["bricked_odd_x"].startswith("all-to-all (uneven slabs)")    # e.g. 6 x-planes = 3 brick pairs on 2 ranks
     assert modes["indivisible"].startswith("all-to-all (uneven slabs)")

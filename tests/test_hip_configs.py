@@ -5,6 +5,7 @@ with an 800x800 camera (configs[4], one rank's share) and the attention render o
 (configs[3], thre3d_atom/modules/attn_grid_trainer.py:335-378).  Tolerances: forward 1e-5 abs (colour / acc), gradients
 1e-4 rel-L2 (north_star: "within a stated float tolerance"; index math is bit exact and checked on a probe)."""
 import os
+import zlib
 
 import numpy as np
 import pytest
@@ -340,7 +341,7 @@ def _region_env(monkeypatch, image_too=False):
                                   "density_only", "features_only", "jitter_tensor"])
 def test_region_backward_variants_vs_oracle(case, monkeypatch):
     _region_env(monkeypatch, image_too=(case == "image_ordered"))
-    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)   # (not hash(): salted per process)
     dims = (5, 6, 7) if case == "tiny_grid" else (40, 33, 48)
     nfeat = 12 if case == "diffuse_sh1" else (1 if case == "attn" else 3)
     dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
@@ -425,7 +426,7 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, mo
     footprints outside the window: sparse pixels, oblique tiles, tiny grids): every output bit equal, and equal to the
     oracle within the forward tolerance"""
     monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
-    rng = np.random.default_rng(abs(hash(case)) % 997)
+    rng = np.random.default_rng(zlib.crc32(case.encode()) % 997)
     kw, over, jit = dict(white_bkgd=True), {}, None
     if case == "tiny_grid":
         dens = rng.uniform(-1, 1, (5, 6, 7, 1)).astype(np.float32)

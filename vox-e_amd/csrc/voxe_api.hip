@@ -459,6 +459,48 @@ int voxe_render_bwd_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, i
   return (packed_bwd && !cfg->linear_grad) ? VOXE_GRAD_BRICKED : VOXE_GRAD_LINEAR;
 }
 
+int voxe_render_route(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st < -1 ? st : VOXE_ERR_BAD_SHAPE;
+  if (R == 0) return VOXE_ROUTE_NONE;
+  DevGrid dg; DevCfg dc;
+  make_dev(grid, cfg, R, v, &dg, &dc);
+  if (cfg->deterministic) return VOXE_ROUTE_DETERMINISTIC;
+  if (ws_layout(grid, cfg, R).region) return VOXE_ROUTE_REGION;
+  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd()) return VOXE_ROUTE_TILE;
+  if (packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd()) return VOXE_ROUTE_PACKED_SCATTER;
+  return VOXE_ROUTE_SCATTER;
+}
+
+int voxe_disparity_bwd(const float* depth, const float* acc, const float* d_disparity, const float* d_depth_in,
+                       const float* d_acc_in, float* d_depth_out, float* d_acc_out, int64_t R, void* stream) {
+  if (R < 0) return VOXE_ERR_BAD_SHAPE;
+  if (R > 0 && (!depth || !acc || !d_disparity || !d_depth_out || !d_acc_out)) return VOXE_ERR_NULL_POINTER;
+  launch_disparity_bwd(depth, acc, d_disparity, d_depth_in, d_acc_in, d_depth_out, d_acc_out, R, (hipStream_t)stream);
+  return finish();
+}
+
+int voxe_clock_probe(int32_t spin, double* shader_hz, void* stream) {
+  if (!shader_hz) return VOXE_ERR_NULL_POINTER;
+  *shader_hz = run_clock_probe(spin, (hipStream_t)stream);
+  return *shader_hz > 0.0 ? finish() : VOXE_ERR_LAUNCH;
+}
+
+int voxe_region_debug_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R, int64_t out[17]) {
+  if (!out) return VOXE_ERR_NULL_POINTER;
+  Variant v;
+  const int st = validate(grid, cfg, R, &v);
+  if (st) return st;
+  const WsLayout l = ws_layout(grid, cfg, R);
+  if (!l.region) return VOXE_ERR_UNSUPPORTED;   // (grid, cfg, R) does not take the space-binned route
+  long long t[16];
+  region_debug_layout(grid->X, grid->Y, grid->Z, R, cfg->num_samples, t);
+  out[0] = (int64_t)l.region_off;
+  for (int i = 0; i < 16; ++i) out[1 + i] = t[i];
+  return VOXE_OK;
+}
+
 size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid) {
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
   return ws_layout(grid, nullptr, 0).grad_off;
@@ -473,9 +515,9 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
                         const float* extra_d_densities,
                         const float* extra_d_features, float* exp_avg_d, float* exp_avg_sq_d, float* exp_avg_f,
                         float* exp_avg_sq_f, float lr, float beta1, float beta2, float eps, int64_t step,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        int64_t step_features, void* workspace, size_t workspace_bytes, void* stream) {
   if (!grid || !grid->densities || !grid->features) return VOXE_ERR_NULL_POINTER;
-  if (grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0 || step < 1) return VOXE_ERR_BAD_SHAPE;
+  if (grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0 || step < 1 || step_features < 0) return VOXE_ERR_BAD_SHAPE;
   if ((long long)grid->X * grid->Y * grid->Z * (grid->F + 1) >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
   if (x_begin < 0 || x_end > grid->X || x_begin > x_end) return VOXE_ERR_BAD_SHAPE;
   if (grad_layout == VOXE_GRAD_BRICKED && (x_begin & 1) && x_begin != x_end) return VOXE_ERR_BAD_SHAPE;
@@ -488,7 +530,8 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
   if (x_begin == x_end) return VOXE_OK;
   if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, x_begin, x_end, (float*)((char*)workspace + l.grad_off),
                         extra_d_densities, extra_d_features, exp_avg_d, exp_avg_sq_d, exp_avg_f, exp_avg_sq_f, lr, beta1,
-                        beta2, eps, step, (float*)((char*)workspace + l.packed_off), (hipStream_t)stream))
+                        beta2, eps, step, step_features > 0 ? step_features : step,
+                        (float*)((char*)workspace + l.packed_off), (hipStream_t)stream))
     return VOXE_ERR_UNSUPPORTED;
   return finish();
 }

@@ -324,4 +324,86 @@ void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, i
   upsample_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// disparity = 1 / max(1e-10, depth / acc)  (accumulate.py:85-88): chain rule of an upstream d_disparity into d_depth and
+// d_acc (what autograd does through the reference's three tensor ops), one thread per ray.  Rays whose quotient is below
+// the clamp, NaN (acc == 0: the reference's disparity is NaN there) or infinite receive no gradient.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float finite_or_zero(float x) { return (x - x == 0.0f) ? x : 0.0f; }   // NaN / +-inf -> 0
+
+__global__ __launch_bounds__(256) void disparity_bwd_kernel(const float* __restrict__ depth, const float* __restrict__ acc,
+                                                            const float* __restrict__ d_disp,
+                                                            const float* __restrict__ d_depth_in,
+                                                            const float* __restrict__ d_acc_in, float* __restrict__ d_depth_out,
+                                                            float* __restrict__ d_acc_out, long long R) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float dep = depth[r], a = acc[r];
+  const float q = dep / a;
+  const float live = q > 1e-10f ? 1.0f : 0.0f;
+  const float dq = finite_or_zero((-d_disp[r] / (q * q)) * live);
+  const float gd = finite_or_zero(dq / a);
+  const float ga = finite_or_zero((-dq * dep) / (a * a));
+  d_depth_out[r] = d_depth_in ? d_depth_in[r] + gd : gd;
+  d_acc_out[r] = d_acc_in ? d_acc_in[r] + ga : ga;
+}
+
+void launch_disparity_bwd(const float* depth, const float* acc, const float* d_disp, const float* d_depth_in,
+                          const float* d_acc_in, float* d_depth_out, float* d_acc_out, long long R, hipStream_t st) {
+  if (R <= 0) return;
+  disparity_bwd_kernel<<<(int)((R + 255) / 256), 256, 0, st>>>(depth, acc, d_disp, d_depth_in, d_acc_in, d_depth_out,
+                                                               d_acc_out, R);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sustained shader clock (measurement aid of bench.py: the issue-rate ceilings of the render kernels are quoted in shader
+// clocks, so the clock has to be MEASURED under load, not assumed).  s_memtime counts shader clocks, s_memrealtime a
+// constant reference clock (hipDeviceAttributeWallClockRate, 100 MHz); every block of a chip-filling launch that keeps
+// the VALU and LDS pipes busy (packed FMAs + LDS double adds: the mix of the render backward) for ~`spin` iterations
+// reports both deltas; the host sums them (per-block quantisation of the 100 MHz counter averages out).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* __restrict__ out, int spin) {
+  __shared__ double acc[256];
+  acc[threadIdx.x] = 0.0;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f x[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = v2f{1.0f + 1e-3f * threadIdx.x, 0.5f + i};
+  for (int it = 0; it < spin; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = __builtin_elementwise_fma(x[i], v2f{1.0001f, 0.9999f}, v2f{1e-3f, 1e-4f});
+    if ((it & 7) == 0)
+      __hip_atomic_fetch_add(&acc[(threadIdx.x * 5 + it) & 255], (double)x[0].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += x[i].x + x[i].y;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = t1 - t0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+    if (s == -1.0f && acc[0] == -1.0) out[0] = 0;   // (keeps the arithmetic alive)
+  }
+}
+
+// blocking: launches on `st`, waits, returns the clock in Hz (0 on failure).  ~0.3 ms of device time with the default spin.
+double run_clock_probe(int spin, hipStream_t st) {
+  static unsigned long long* dbuf = nullptr;
+  constexpr int kBlocks = 256 * 4;   // 4 blocks of 4 waves per CU: every SIMD holds 4 waves
+  if (!dbuf && hipMalloc(&dbuf, kBlocks * 2 * sizeof(unsigned long long)) != hipSuccess) return 0.0;
+  clock_probe_kernel<<<kBlocks, 256, 0, st>>>(dbuf, spin > 0 ? spin : 4000);
+  static unsigned long long host[kBlocks * 2];
+  if (hipMemcpyAsync(host, dbuf, sizeof(host), hipMemcpyDeviceToHost, st) != hipSuccess) return 0.0;
+  if (hipStreamSynchronize(st) != hipSuccess) return 0.0;
+  double shader = 0.0, wall = 0.0;
+  for (int i = 0; i < kBlocks; ++i) { shader += (double)host[2 * i]; wall += (double)host[2 * i + 1]; }
+  int dev = 0, wall_khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0.0;
+  if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || wall_khz <= 0) return 0.0;
+  return wall > 0.0 ? shader / wall * (double)wall_khz * 1e3 : 0.0;
+}
+
 }  // namespace voxe

@@ -39,7 +39,7 @@ void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_de
 // fused un-pack + Adam + re-pack (false: channel count without a kernel)
 bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
-                      long long step, float* packed_out, hipStream_t st);
+                      long long step_d, long long step_f, float* packed_out, hipStream_t st);
 void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
                 hipStream_t st);
 void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a,
@@ -76,6 +76,8 @@ void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, 
                        hipStream_t st);   // segment tables + forward; leaves the per-segment states in `scratch`
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
                        hipStream_t st);   // needs the tables / states of launch_fwd_region for the same rays
+// byte offsets of the segment tables inside the region scratch + their dimensions (test aid: voxe_region_debug_layout)
+void region_debug_layout(int X, int Y, int Z, long long R, int S, long long out[16]);
 
 // voxe_grid_ops.hip
 void launch_cast_rays(int H, int W, float focal, const float* rot, const float* trans, float* rays_o,
@@ -94,6 +96,9 @@ void launch_adam(float* param, const float* grad, float* m, float* v, long long 
                  float beta1, float beta2, float eps, long long step, hipStream_t st);
 void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, int X2, int Y2, int Z2,
                      hipStream_t st);
+void launch_disparity_bwd(const float* depth, const float* acc, const float* d_disp, const float* d_depth_in,
+                          const float* d_acc_in, float* d_depth_out, float* d_acc_out, long long R, hipStream_t st);
+double run_clock_probe(int spin, hipStream_t st);   // sustained shader clock in Hz (blocking; 0 on failure)
 
 
 // voxe_refine.hip: graph construction / minimum cut / connected components of the refinement stage

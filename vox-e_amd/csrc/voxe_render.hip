@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
                                                         float* __restrict__ v_d, float* __restrict__ m_f,
                                                         float* __restrict__ v_f, float* __restrict__ packed,
                                                         long long vox_begin, long long vox_end, float scale,
-                                                        int pre_act, int bricked, int Y, int Z, AdamHyper h) {
+                                                        int pre_act, int bricked, int Y, int Z, AdamHyper h_d, AdamHyper h_f) {
   constexpr int F = C - 1;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = vox_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox_end; i += stride) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
       if (m_f) {
         const float gi = extra_f ? g[f] + extra_f[j] : g[f];
         float m = m_f[j], v = v_f[j];
-        p = adam_update(p, gi, m, v, h);
+        p = adam_update(p, gi, m, v, h_f);
         feat[j] = p; m_f[j] = m; v_f[j] = v;
       }
       out[f] = p;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
       const float gd = g[F] * pre_activate_grad(pre_act, d, scale);
       const float gi = extra_d ? gd + extra_d[i] : gd;
       float m = m_d[i], v = v_d[i];
-      d = adam_update(d, gi, m, v, h);
+      d = adam_update(d, gi, m, v, h_d);
       dens[i] = d; m_d[i] = m; v_d[i] = v;
     }
     out[F] = pre_activate(pre_act, d, scale);
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
                                                              float* __restrict__ v_d, float* __restrict__ m_f,
                                                              float* __restrict__ v_f, float* __restrict__ packed,
                                                              long long vox_begin, long long vox_end, float scale,
-                                                             int pre_act, int bricked, int Y, int Z, AdamHyper h) {
+                                                             int pre_act, int bricked, int Y, int Z, AdamHyper h_d, AdamHyper h_f) {
   constexpr int F = C - 1;
   const unsigned e_end = (unsigned)(vox_end * C), stride = gridDim.x * blockDim.x;
   for (unsigned e = (unsigned)(vox_begin * C) + blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += stride) {
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
       if (m_f) {
         const float gi = extra_f ? g + extra_f[j] : g;
         float m = m_f[j], v = v_f[j];
-        p = adam_update(p, gi, m, v, h);
+        p = adam_update(p, gi, m, v, h_f);
         feat[j] = p; m_f[j] = m; v_f[j] = v;
       }
       packed[e] = p;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
         const float gd = g * pre_activate_grad(pre_act, d, scale);
         const float gi = extra_d ? gd + extra_d[i] : gd;
         float m = m_d[i], v = v_d[i];
-        d = adam_update(d, gi, m, v, h);
+        d = adam_update(d, gi, m, v, h_d);
         dens[i] = d; m_d[i] = m; v_d[i] = v;
       }
       packed[e] = pre_activate(pre_act, d, scale);
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
 
 template <int C>
 static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d,
-                               const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h,
-                               float* packed_out, hipStream_t st) {
+                               const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h_d,
+                               AdamHyper h_f, float* packed_out, hipStream_t st) {
   const long long plane = (long long)gd->Y * gd->Z, nvox = (x_end - x_begin) * plane;
   if constexpr (C > 4) {
     const long long n = nvox * C;
@@ -266,27 +266,32 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
     grid_adam_wide_kernel<C><<<nbw, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
                                                   extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane,
                                                   x_end * plane, gd->density_scale, gd->density_pre_act, bricked ? 1 : 0, gd->Y,
-                                                  gd->Z, h);
+                                                  gd->Z, h_d, h_f);
     return;
   }
   const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
   grid_adam_kernel<C><<<nb, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
                                           extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane, x_end * plane, gd->density_scale,
-                                          gd->density_pre_act, bricked ? 1 : 0, gd->Y, gd->Z, h);
+                                          gd->density_pre_act, bricked ? 1 : 0, gd->Y, gd->Z, h_d, h_f);
 }
 
 bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
-                      long long step, float* packed_out, hipStream_t st) {
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);   // same host arithmetic as launch_adam()
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  const AdamHyper h{(float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps};
+                      long long step_d, long long step_f, float* packed_out, hipStream_t st) {
+  // torch.optim.Adam keeps one step counter PER PARAMETER: the two tensors' bias corrections may differ (a tensor that
+  // skipped a step, e.g. a regulariser-only iteration on the densities)
+  auto hyper = [&](long long step) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);   // same host arithmetic as launch_adam()
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    return AdamHyper{(float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps};
+  };
+  const AdamHyper h_d = hyper(step_d), h_f = hyper(step_f);
   switch (gd->F + 1) {
-    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
-    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h, packed_out, st); return true;
+    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
+    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
+    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
+    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
+    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
   }
   return false;
 }
@@ -360,6 +365,20 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
     }
   }
   while (nextb <= nbound) { save_state(nextb); ++nextb; }  // boundaries behind the last sample: final state
+  // the backward wants SUFFIX sums (what lies at and behind the boundary), see render_fwd_combine_kernel: final - prefix
+  // (this single-march forward only runs with early termination or without the segment buffer; the segmented forward
+  // sums its suffixes back to front instead)
+  for (int b = 1; b <= nbound; ++b) {
+    constexpr int NC = COUT + 3;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) {
+      const long long i = ray_state_index(b, 1 + ch, NC, c.R, r);
+      ray_state[i] = csum[ch] - ray_state[i];
+    }
+    const long long ia = ray_state_index(b, 1 + COUT, NC, c.R, r), id = ray_state_index(b, 2 + COUT, NC, c.R, r);
+    ray_state[ia] = asum - ray_state[ia];
+    ray_state[id] = dsum - ray_state[id];
+  }
   // accumulate.py:77-88
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) {
@@ -497,19 +516,36 @@ __global__ __launch_bounds__(256) void render_fwd_combine_kernel(DevCfg c, const
   for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
   for (int s = 0; s < nseg; ++s) {
-    if (ray_state && s > 0) {  // state BEFORE segment s == boundary s
-      ray_state[ray_state_index(s, 0, NC, c.R, r)] = T;
-#pragma unroll
-      for (int ch = 0; ch < COUT; ++ch) ray_state[ray_state_index(s, 1 + ch, NC, c.R, r)] = csum[ch];
-      ray_state[ray_state_index(s, 1 + COUT, NC, c.R, r)] = asum;
-      ray_state[ray_state_index(s, 2 + COUT, NC, c.R, r)] = dsum;
-    }
+    if (ray_state && s > 0) ray_state[ray_state_index(s, 0, NC, c.R, r)] = T;   // transmittance BEFORE segment s == boundary s
     const long long base = (long long)s * NC;
 #pragma unroll
     for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(T, segbuf[(base + 1 + ch) * c.R + r], csum[ch]);
     asum = fmaf(T, segbuf[(base + 1 + COUT) * c.R + r], asum);
     dsum = fmaf(T, segbuf[(base + 2 + COUT) * c.R + r], dsum);
     T = T * segbuf[(base + 0) * c.R + r];
+  }
+  if (ray_state) {
+    // State of boundary s for the backward: transmittance before it and the SUFFIX sums -- what the samples at and
+    // behind the boundary contribute to (csum, asum, dsum) -- summed BACK TO FRONT (faint far segments first).  The
+    // backward needs sum_{j > k} dL/dw_j w_j; taking it as (whole ray) - (prefix) loses the samples deep inside a dense
+    // medium to cancellation (relative error 1e-7 / T_k); suffix sums keep it relative to the suffix itself, like the
+    // reference's reverse cumsum (torch's cumprod backward; rendering/volumetric/accumulate.py:63-67).
+    float sc[COUT], sa = 0.0f, sd = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) sc[ch] = 0.0f;
+    for (int s = nseg - 1; s > 0; --s) {
+      const float Ts = ray_state[ray_state_index(s, 0, NC, c.R, r)];   // (written by this thread above)
+      const long long base = (long long)s * NC;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) {
+        sc[ch] = fmaf(Ts, segbuf[(base + 1 + ch) * c.R + r], sc[ch]);
+        ray_state[ray_state_index(s, 1 + ch, NC, c.R, r)] = sc[ch];
+      }
+      sa = fmaf(Ts, segbuf[(base + 1 + COUT) * c.R + r], sa);
+      sd = fmaf(Ts, segbuf[(base + 2 + COUT) * c.R + r], sd);
+      ray_state[ray_state_index(s, 1 + COUT, NC, c.R, r)] = sa;
+      ray_state[ray_state_index(s, 2 + COUT, NC, c.R, r)] = sd;
+    }
   }
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) {

@@ -18,8 +18,9 @@ namespace voxe {
 // ------------------------------------------------------------------------------------------------
 // Per-ray depth-segment states.  The image-ordered backward splits every ray's march into segments of
 // kSegLen samples that are processed by different waves; the forward saves, at every segment boundary
-// k = b * kSegLen (b = 1 .. nseg-1), the state BEFORE sample k: transmittance T and the partial sums
-// (csum[COUT], asum, dsum).  Layout [boundary-1][component][ray] (component-major: coalesced per ray run).
+// k = b * kSegLen (b = 1 .. nseg-1), the transmittance T BEFORE sample k and the SUFFIX sums (csum[COUT], asum, dsum) of
+// the samples k, k+1, ... (summed back to front: render_fwd_combine_kernel).  Layout [boundary-1][component][ray]
+// (component-major: coalesced per ray run).
 constexpr int kSegLen = VOXE_SEGMENT_SAMPLES;
 // Small launches leave the chip under-filled, and what a wave then costs is its dependent chain of samples (~7 us each):
 // half-length segments double the waves (64x64: backward 0.26 -> 0.15 ms, 100x100: 0.26 -> 0.22 ms); at 400x400 the

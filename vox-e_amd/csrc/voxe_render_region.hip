@@ -609,8 +609,8 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
   const long long min_rays = region_min_rays();
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
   if (!(c.attn || deg == 0 || diffuse)) return false;          // one channel group (SH-0 / diffuse / attention)
-  if (c.R > (1ll << 20) || c.S >= 65536) return false;         // segment records hold 32-bit rays / 16-bit sample indices;
-                                                               // the tables take ~12 KB per ray (S = 256): capped at 1 M rays per launch
+  if (c.R > (1ll << 19) || c.S >= 65536) return false;         // segment records hold 32-bit rays / 16-bit sample indices;
+                                                               // the tables take ~12 KB per ray (S = 256): capped at 512 k rays (6 GB) per launch
   if (!tiled) return true;                                     // unordered rays, images below the tile threshold
   // image-ordered launches: only when the pixels are clearly more than a voxel apart (nothing to combine inside a wave:
   // 100x100 cameras on a 160^3 grid).  The pixel spacing is not known on the host; for a camera that frames the volume
@@ -660,6 +660,15 @@ static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
   bs.count = (unsigned*)(base + l.counters);
   bs.start = bs.count + up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)) / sizeof(unsigned);
   return bs;
+}
+
+void region_debug_layout(int X, int Y, int Z, long long R, int S, long long out[16]) {
+  const RegionLayout l = region_layout(X, Y, Z, R, S);
+  const size_t start_off = l.counters + up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned));
+  const long long v[16] = {(long long)l.slot_region, (long long)l.slot_pos, (long long)l.slot_seg, (long long)l.sorted,
+                           (long long)l.lane_n, (long long)l.counters, (long long)start_off, l.nslots, l.nlanes, l.nreg,
+                           kSlotsPerLane, kRBX, kRBY, kRBZ, kLenClasses, VOXE_REGION_CHUNK};
+  for (int i = 0; i < 16; ++i) out[i] = v[i];
 }
 
 template <int COUT, int NCM>

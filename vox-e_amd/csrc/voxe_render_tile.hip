@@ -264,16 +264,16 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
     int k_hi = alive_q ? min(rc.k_hi, ke) : k_lo - 1;
     bool has = k_lo <= k_hi;
     // state at the segment start (transmittance + partial sums of the forward), see save_state()
-    float T = 1.0f, pre_c[COUT], pre_a = 0.0f, pre_d = 0.0f;
+    float T = 1.0f, suf_c[COUT], suf_a = 0.0f, suf_d = 0.0f;   // (suffix sums of the samples from the segment start on)
   #pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = 0.0f;
+    for (int ch = 0; ch < COUT; ++ch) suf_c[ch] = 0.0f;
     if (has && seg > 0) {
       constexpr int NC = COUT + 3;
       T = ray_state[ray_state_index(seg, 0, NC, c.R, r)];
   #pragma unroll
-      for (int ch = 0; ch < COUT; ++ch) pre_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
-      pre_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
-      pre_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
+      for (int ch = 0; ch < COUT; ++ch) suf_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
+      suf_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
+      suf_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
       if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
     }
     const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
@@ -331,11 +331,16 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
       total += gc[ch] * csum;
     }
     if (white) total -= gsum * asum;
-    // prefix = sum_{j < segment start} dL/dw_j w_j from the saved partial sums
-    float prefix = gdep * pre_d + gacc * pre_a;
-  #pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
-    if (white) prefix -= gsum * pre_a;
+    // suffix0 = sum_{j >= segment start} dL/dw_j w_j: the whole ray (from the forward outputs) for the first segment, the
+    // saved suffix sums (back-to-front sums of the forward: no cancellation against the part in front) otherwise
+    float suffix0 = total;
+    if (seg > 0) {
+      suffix0 = gdep * suf_d + gacc * suf_a;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) suffix0 += gc[ch] * suf_c[ch];
+      if (white) suffix0 -= gsum * suf_a;
+    }
+    float run = 0.0f;   // sum of dL/dw_j w_j over the samples of this segment up to and including the current one
 
     // window channel s of this block = gradient channel q = grp * C + s: coefficient j of colour ch = q / NCU (texel
     // channel ch * NCM + j, factor basis_j of this ray) or, last, the density (texel channel CM - 1, factor 1).
@@ -429,8 +434,8 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
   #pragma unroll
               for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
               if (white) dldw -= gsum;
-              prefix = fmaf(dldw, wk, prefix);
-              const float suffix = last ? 0.0f : (total - prefix);
+              run = fmaf(dldw, wk, run);
+              const float suffix = last ? 0.0f : (suffix0 - run);
               const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
               const float dsig = (delta * e) * fmaf(T, dldw, -tail);
   #pragma unroll

@@ -181,61 +181,62 @@ def refine_edited_relu_field(
     trained_time, last = 0.0, time.perf_counter()
     data_cursor = 0
     pose = None
-    for global_step in range(1, num_iterations + 1):
-        if data_pose_mode:
-            _, pose_mat, _ = train_dataset[data_cursor % len(train_dataset)]
-            data_cursor += 1
-            pose = CameraPose(rotation=pose_mat[:, :3], translation=pose_mat[:, 3:])
-            direction = _get_dir_batch_from_poses(pose_mat[None])[0]
-        else:
-            pose, direction, _, _ = get_random_pose(hemispherical_radius)
-        rays_batch = flatten_rays(cast_rays(camera_intrinsics, pose, device=device))
+    try:
+        for global_step in range(1, num_iterations + 1):
+            if data_pose_mode:
+                _, pose_mat, _ = train_dataset[data_cursor % len(train_dataset)]
+                data_cursor += 1
+                pose = CameraPose(rotation=pose_mat[:, :3], translation=pose_mat[:, 3:])
+                direction = _get_dir_batch_from_poses(pose_mat[None])[0]
+            else:
+                pose, direction, _, _ = get_random_pose(hemispherical_radius)
+            rays_batch = flatten_rays(cast_rays(camera_intrinsics, pose, device=device))
 
-        # RGB render of the edited field -> cross-attention maps of the prompt tokens (boundary to the UNet)
-        rgb = vol_mod_edit.render(pose, camera_intrinsics).colour
-        out_imgs = rgb.unsqueeze(0).permute(0, 3, 1, 2).to(device)
-        m_prompt = prompt + f", {direction} view"
-        num_tokens = attn_guidance.get_num_tokens(m_prompt)
-        maps, _ = attn_guidance.get_attn_map(prompt=m_prompt, pred_rgb=out_imgs, timestamp=timestamp,
-                                             indices_to_fetch=list(range(1, num_tokens + 1)))
-        edit_attn_map, object_attn_map = split_attention_maps(maps, edit_idx, object_idx)
+            # RGB render of the edited field -> cross-attention maps of the prompt tokens (boundary to the UNet)
+            rgb = vol_mod_edit.render(pose, camera_intrinsics).colour
+            out_imgs = rgb.unsqueeze(0).permute(0, 3, 1, 2).to(device)
+            m_prompt = prompt + f", {direction} view"
+            num_tokens = attn_guidance.get_num_tokens(m_prompt)
+            maps, _ = attn_guidance.get_attn_map(prompt=m_prompt, pred_rgb=out_imgs, timestamp=timestamp,
+                                                 indices_to_fetch=list(range(1, num_tokens + 1)))
+            edit_attn_map, object_attn_map = split_attention_maps(maps, edit_idx, object_idx)
 
-        edit_render = vol_mod_edit.render_rays_attn(rays_batch).attn
-        object_render = vol_mod_object.render_rays_attn(rays_batch).attn
-        edit_attn_loss = calc_loss_on_attn_grid(edit_render, edit_attn_map, token="edit", global_step=global_step)
-        object_attn_loss = calc_loss_on_attn_grid(object_render, object_attn_map, token="object", global_step=global_step)
-        total_loss_edit = edit_attn_loss + _tv_loss_on_grid(edit_grid.attn) * attn_tv_weight
-        total_loss_object = object_attn_loss + _tv_loss_on_grid(object_grid.attn) * attn_tv_weight
+            edit_render = vol_mod_edit.render_rays_attn(rays_batch).attn
+            object_render = vol_mod_object.render_rays_attn(rays_batch).attn
+            edit_attn_loss = calc_loss_on_attn_grid(edit_render, edit_attn_map, token="edit", global_step=global_step)
+            object_attn_loss = calc_loss_on_attn_grid(object_render, object_attn_map, token="object", global_step=global_step)
+            total_loss_edit = edit_attn_loss + _tv_loss_on_grid(edit_grid.attn) * attn_tv_weight
+            total_loss_object = object_attn_loss + _tv_loss_on_grid(object_grid.attn) * attn_tv_weight
 
-        total_loss_edit.backward()
-        optimizer_edit.step()
-        optimizer_edit.zero_grad()
-        total_loss_object.backward()
-        optimizer_object.step()
-        optimizer_object.zero_grad()
-        trained_time += time.perf_counter() - last
+            total_loss_edit.backward()
+            optimizer_edit.step()
+            optimizer_edit.zero_grad()
+            total_loss_object.backward()
+            optimizer_object.step()
+            optimizer_object.zero_grad()
+            trained_time += time.perf_counter() - last
 
-        if global_step % summary_freq == 0 or global_step in (1, num_iterations):
-            log.info(f"Global Iteration: {global_step} attn_loss: {float(edit_attn_loss.detach()): .3f} "
-                     f"object_attn_loss: {float(object_attn_loss.detach()): .3f}")
-        if global_step % lr_decay_steps_per_stage == 0:
-            lr_scheduler_edit.step()
-            log.info(f"Adjusted learning rate | learning rates: {[g['lr'] for g in optimizer_edit.param_groups]}")
-        if global_step % feedback_freq == 0 or global_step in (1, num_iterations):
-            log.info(f"TIME CHECK: time spent actually training till now: {timedelta(seconds=trained_time)}")
-            with torch.no_grad():
-                _save_map(render_dir / f"edit_gt_attn_{global_step}.png", edit_attn_map)
-                _save_map(render_dir / f"object_gt_attn_{global_step}.png", object_attn_map)
-                _save_map(render_dir / f"edit_render_attn_{global_step}.png", edit_render.reshape(edit_attn_map.shape))
-                _save_map(render_dir / f"object_render_attn_{global_step}.png", object_render.reshape(edit_attn_map.shape))
-            if global_step % save_freq == 0 or global_step in (1, num_iterations):
-                torch.save(vol_mod_edit.get_save_info(extra_info=extra_info), model_dir / f"model_edit_iter_{global_step}.pth")
-                torch.save(vol_mod_object.get_save_info(extra_info=extra_info), model_dir / f"model_object_iter_{global_step}.pth")
-        last = time.perf_counter()
-
-    if fused_grid_step:
-        optimizer_edit.detach()
-        optimizer_object.detach()
+            if global_step % summary_freq == 0 or global_step in (1, num_iterations):
+                log.info(f"Global Iteration: {global_step} attn_loss: {float(edit_attn_loss.detach()): .3f} "
+                         f"object_attn_loss: {float(object_attn_loss.detach()): .3f}")
+            if global_step % lr_decay_steps_per_stage == 0:
+                lr_scheduler_edit.step()
+                log.info(f"Adjusted learning rate | learning rates: {[g['lr'] for g in optimizer_edit.param_groups]}")
+            if global_step % feedback_freq == 0 or global_step in (1, num_iterations):
+                log.info(f"TIME CHECK: time spent actually training till now: {timedelta(seconds=trained_time)}")
+                with torch.no_grad():
+                    _save_map(render_dir / f"edit_gt_attn_{global_step}.png", edit_attn_map)
+                    _save_map(render_dir / f"object_gt_attn_{global_step}.png", object_attn_map)
+                    _save_map(render_dir / f"edit_render_attn_{global_step}.png", edit_render.reshape(edit_attn_map.shape))
+                    _save_map(render_dir / f"object_render_attn_{global_step}.png", object_render.reshape(edit_attn_map.shape))
+                if global_step % save_freq == 0 or global_step in (1, num_iterations):
+                    torch.save(vol_mod_edit.get_save_info(extra_info=extra_info), model_dir / f"model_edit_iter_{global_step}.pth")
+                    torch.save(vol_mod_object.get_save_info(extra_info=extra_info), model_dir / f"model_object_iter_{global_step}.pth")
+            last = time.perf_counter()
+    finally:
+        if fused_grid_step:   # (also when the loop raised: the deferred-gradient mode must not outlive its optimiser)
+            optimizer_edit.detach()
+            optimizer_object.detach()
     # ---- graph cut and splice ----------------------------------------------------------------------------
     log.info("Starting Grid Refinement!")
     t0 = time.perf_counter()

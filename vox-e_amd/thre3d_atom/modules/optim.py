@@ -5,6 +5,7 @@
 state layout (`step`, `exp_avg`, `exp_avg_sq`) and update rule whose `step()` is ONE streaming HIP kernel
 per tensor (voxe_adam_step: 7 * n * 4 bytes), so LR schedulers and checkpoint code that expect a
 torch Optimizer keep working."""
+import weakref
 from typing import Iterable
 
 import torch
@@ -54,7 +55,13 @@ class FusedGridAdam(torch.optim.Optimizer):
     The same arithmetic, schedulers and `state_dict` layout (`step`, `exp_avg`, `exp_avg_sq` per parameter) as the
     reference's `torch.optim.Adam(params=[{"params": grid.parameters(), "lr": lr}], betas=(0.9, 0.999))`
     (modules/trainers.py:247-255, modules/sds_trainer.py:200-203, modules/attn_grid_trainer.py:243-247).
-    `kind`: "sh" optimises (densities, features), "attn" the attention grid alone (densities frozen)."""
+    `kind`: "sh" optimises (densities, features), "attn" the attention grid alone (densities frozen).
+
+    Scope of the deferred-gradient mode: it lasts from construction to `detach()`.  While it is on, renders through the
+    grid return NO `.grad` for the grid tensors, so it must not outlive its optimiser: use the optimiser as a context
+    manager (`with FusedGridAdam(grid, ...) as opt:` -- `detach()` runs on exit, also when the loop raises) or call
+    `detach()` in a `finally`; a finalizer clears the mode when the optimiser is garbage collected without either, and
+    a second optimiser on a grid whose mode is still on raises instead of silently taking over an accumulated gradient."""
 
     def __init__(self, voxel_grid, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, kind: str = "sh"):
         if kind not in ("sh", "attn"):
@@ -73,11 +80,34 @@ class FusedGridAdam(torch.optim.Optimizer):
         self.workspace = voxel_grid.voxe_workspace(kind)
         train_d = any(p is self._dens for p in params)
         train_f = any(p is self._feat for p in params)
-        self.workspace.deferred = _ops.DeferredGrad(want_densities=train_d, want_features=train_f)
+        live = self.workspace.deferred
+        if live is not None:
+            raise RuntimeError("FusedGridAdam: this grid is already in deferred-gradient mode (another FusedGridAdam is "
+                               "attached to it); detach() that optimiser first")
+        mine = _ops.DeferredGrad(want_densities=train_d, want_features=train_f)
+        self.workspace.deferred = mine
         self._train = (train_d, train_f)
+        # dropped without detach() (an exception unwound the training loop, the caller forgot): leave the mode anyway
+        self._finalizer = weakref.finalize(self, FusedGridAdam._release, self.workspace, mine)
+
+    @staticmethod
+    def _release(workspace, mine) -> None:
+        if workspace.deferred is mine:
+            if mine.dirty:
+                workspace.invalidate()
+                mine.clean_ptr = 0     # (the region holds an unconsumed gradient: whoever attaches next clears it first)
+            workspace.deferred = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.detach()
+        return False
 
     def detach(self) -> None:
         """leave the deferred-gradient mode (renders return ordinary .grad tensors again)"""
+        self._finalizer.detach()
         if self.workspace.deferred is not None and self.workspace.deferred.dirty:
             self.workspace.invalidate()   # (an unconsumed gradient would otherwise leak into a later fused step)
             _ops.workspace_grad_view(self.spec, self._dens, self._feat, self.workspace).zero_()
@@ -122,14 +152,16 @@ class FusedGridAdam(torch.optim.Optimizer):
             return loss
         st_d = self._state_of(self._dens) if train_d else None
         st_f = self._state_of(self._feat) if train_f else None
-        step_no = 0
         for st in (st_d, st_f):
             if st is not None:
                 st["step"] += 1
-                step_no = st["step"]
+        # torch.optim.Adam counts steps PER PARAMETER: after a step in which only one tensor had a gradient (the per-tensor
+        # branch above) the two counters differ, and so do the bias corrections
+        step_d = st_d["step"] if st_d is not None else st_f["step"]
+        step_f = st_f["step"] if st_f is not None else step_d
         extra_d = self._dens.grad.contiguous() if (train_d and self._dens.grad is not None) else None
         extra_f = self._feat.grad.contiguous() if (train_f and self._feat.grad is not None) else None
-        _ops.grid_adam_step_(self.spec, self._dens, self._feat, d.layout, self.workspace, step_no, group["lr"],
+        _ops.grid_adam_step_(self.spec, self._dens, self._feat, d.layout, self.workspace, step_d, group["lr"], step_features=step_f,
                              state_densities=None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
                              state_features=None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]),
                              extra_d_densities=extra_d, extra_d_features=extra_f, beta1=beta1, beta2=beta2,

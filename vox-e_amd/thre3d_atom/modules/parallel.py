@@ -258,6 +258,10 @@ class ShardedGridAdam:
         region = self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace)
         table = self._slab_table(grad_layout)
         even = len({t[3] for t in table}) == 1 and len({t[5] for t in table}) == 1 and table[0][3] > 0
+        supported = self.probe_exchanges()           # (lazy: the first step of a job that never called autotune())
+        if not supported[exchange] or (not even and not supported["all-to-all"]):
+            # uneven slabs only run as the direct exchange; a backend without all-to-all takes the replicated step
+            exchange = "all-reduce"
         e0 = self._mark() if timed else None
         if exchange == "all-reduce":
             self._fence()
@@ -381,9 +385,13 @@ class ShardedGridAdam:
             sync = torch.cuda.synchronize if self.densities.is_cuda else (lambda: None)
         supported = self.probe_exchanges()
         self.ops.workspace_grad_view(self.spec, self.densities, self.features, workspace).zero_()
+        table = self._slab_table(grad_layout)
+        even = len({t[3] for t in table}) == 1 and len({t[5] for t in table}) == 1 and table[0][3] > 0
         times = []
         for exchange in self.EXCHANGES:
-            if not supported[exchange]:        # the same skip on every rank (probe_exchanges)
+            # the same skips on every rank: what the backend lacks (probe_exchanges), and with uneven slabs
+            # "reduce-scatter" -- it would run as the very same direct exchange as "all-to-all" (timing it twice says nothing)
+            if not supported[exchange] or (not even and exchange == "reduce-scatter"):
                 times.append(float("inf"))
                 continue
             self._run(workspace, grad_layout, exchange, 1)          # buffers, communicator warm-up

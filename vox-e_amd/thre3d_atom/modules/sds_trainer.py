@@ -189,76 +189,77 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
     rays_batch, direction_batch, pose, pixels_batch = None, None, None, None
     data_cursor = 0
 
-    for global_step in range(1, num_iterations + 1):
-        if global_step % new_frame_frequency == 0 or global_step == 1:
-            if uncoupled_mode or data_pose_mode:
-                image, pose_mat, _ = train_dataset[data_cursor % len(train_dataset)]
-                data_cursor += 1
-                pose = CameraPose(rotation=pose_mat[:, :3], translation=pose_mat[:, 3:])
-                direction_batch = _get_dir_batch_from_poses(pose_mat[None])
-                pixels_batch = image.to(device).permute(1, 2, 0).reshape(-1, image.shape[0])
+    try:
+        for global_step in range(1, num_iterations + 1):
+            if global_step % new_frame_frequency == 0 or global_step == 1:
+                if uncoupled_mode or data_pose_mode:
+                    image, pose_mat, _ = train_dataset[data_cursor % len(train_dataset)]
+                    data_cursor += 1
+                    pose = CameraPose(rotation=pose_mat[:, :3], translation=pose_mat[:, 3:])
+                    direction_batch = _get_dir_batch_from_poses(pose_mat[None])
+                    pixels_batch = image.to(device).permute(1, 2, 0).reshape(-1, image.shape[0])
+                else:
+                    pose, direction, _, _ = get_random_pose(hemispherical_radius)
+                    direction_batch = [direction]
+                full_rays = cast_rays(intr, pose, device=device)
+                if world > 1:  # this rank's band of rows (a smaller image-ordered ray batch)
+                    from thre3d_atom.rendering.volumetric.render_interface import Rays
+
+                    band = Rays(full_rays.origins[row_lo:row_hi], full_rays.directions[row_lo:row_hi],
+                                image_shape=(row_hi - row_lo, im_w))
+                    rays_batch = flatten_rays(band)
+                else:
+                    rays_batch = flatten_rays(full_rays)
+
+            rendered = sds_vol_mod.render_rays(rays_batch)
+            colour = rendered.colour
+            if world > 1:
+                colour = parallel.gather_image_rows(colour.reshape(row_hi - row_lo, im_w, -1), im_h).reshape(im_h * im_w, -1)
+            reg_scale = 1.0 / world
+            total_loss = 0
+            if do_sds:
+                total_loss = total_loss + guidance.training_step(colour, im_h, im_w, directions=direction_batch,
+                                                                 global_step=global_step)
+            if uncoupled_mode:
+                fit = torch.nn.functional.mse_loss if uncoupled_l2_mode else torch.nn.functional.l1_loss
+                total_loss = total_loss + fit(colour, pixels_batch) * density_correlation_weight
             else:
-                pose, direction, _, _ = get_random_pose(hemispherical_radius)
-                direction_batch = [direction]
-            full_rays = cast_rays(intr, pose, device=device)
-            if world > 1:  # this rank's band of rows (a smaller image-ordered ray batch)
-                from thre3d_atom.rendering.volumetric.render_interface import Rays
+                dcl, _ = density_correlation_loss_fn(grid.densities, regular_density, l2_mode=l2_mode, l1_mode=l1_mode)
+                total_loss = total_loss + dcl * (density_correlation_weight * reg_scale)
+            if feature_correlation_weight > 0.0:
+                total_loss = total_loss + _feature_correlation_loss(grid.features, regular_features) * (feature_correlation_weight * reg_scale)
+            if tv_density_weight > 0:
+                total_loss = total_loss + _tv_loss_on_grid(torch.relu(grid.densities)) * (tv_density_weight * reg_scale)
+            if tv_features_weight > 0:
+                total_loss = total_loss + _tv_loss_on_grid(grid.features) * (tv_features_weight * reg_scale)
 
-                band = Rays(full_rays.origins[row_lo:row_hi], full_rays.directions[row_lo:row_hi],
-                            image_shape=(row_hi - row_lo, im_w))
-                rays_batch = flatten_rays(band)
-            else:
-                rays_batch = flatten_rays(full_rays)
+            if flat is not None:
+                flat.zero_grad()
+            total_loss.backward()
+            if flat is not None:
+                flat.all_reduce_grad()      # sum of the per-band render gradients (+ world x regulariser / world)
+            optimizer.step()
+            if flat is None:
+                optimizer.zero_grad()
+            trained_time += time.perf_counter() - last
 
-        rendered = sds_vol_mod.render_rays(rays_batch)
-        colour = rendered.colour
-        if world > 1:
-            colour = parallel.gather_image_rows(colour.reshape(row_hi - row_lo, im_w, -1), im_h).reshape(im_h * im_w, -1)
-        reg_scale = 1.0 / world
-        total_loss = 0
-        if do_sds:
-            total_loss = total_loss + guidance.training_step(colour, im_h, im_w, directions=direction_batch,
-                                                             global_step=global_step)
-        if uncoupled_mode:
-            fit = torch.nn.functional.mse_loss if uncoupled_l2_mode else torch.nn.functional.l1_loss
-            total_loss = total_loss + fit(colour, pixels_batch) * density_correlation_weight
-        else:
-            dcl, _ = density_correlation_loss_fn(grid.densities, regular_density, l2_mode=l2_mode, l1_mode=l1_mode)
-            total_loss = total_loss + dcl * (density_correlation_weight * reg_scale)
-        if feature_correlation_weight > 0.0:
-            total_loss = total_loss + _feature_correlation_loss(grid.features, regular_features) * (feature_correlation_weight * reg_scale)
-        if tv_density_weight > 0:
-            total_loss = total_loss + _tv_loss_on_grid(torch.relu(grid.densities)) * (tv_density_weight * reg_scale)
-        if tv_features_weight > 0:
-            total_loss = total_loss + _tv_loss_on_grid(grid.features) * (tv_features_weight * reg_scale)
-
-        if flat is not None:
-            flat.zero_grad()
-        total_loss.backward()
-        if flat is not None:
-            flat.all_reduce_grad()      # sum of the per-band render gradients (+ world x regulariser / world)
-        optimizer.step()
-        if flat is None:
-            optimizer.zero_grad()
-        trained_time += time.perf_counter() - last
-
-        if global_step % summary_freq == 0 or global_step in (1, num_iterations):
-            log.info(f"Iteration: {global_step}, total_loss: {float(total_loss.detach()): .3f}")
-        if global_step % lr_freq == 0 and global_step >= lr_decay_start:
-            lr_scheduler.step()
-            log.info(f"Adjusted learning rate | learning rates: {[g['lr'] for g in optimizer.param_groups]}")
-        if rank != 0:
+            if global_step % summary_freq == 0 or global_step in (1, num_iterations):
+                log.info(f"Iteration: {global_step}, total_loss: {float(total_loss.detach()): .3f}")
+            if global_step % lr_freq == 0 and global_step >= lr_decay_start:
+                lr_scheduler.step()
+                log.info(f"Adjusted learning rate | learning rates: {[g['lr'] for g in optimizer.param_groups]}")
+            if rank != 0:
+                last = time.perf_counter()
+                continue
+            if global_step % feedback_freq == 0 or global_step in (1, num_iterations):
+                log.info(f"TIME CHECK: time spent actually training till now: {timedelta(seconds=trained_time)}")
+                _write_feedback(sds_vol_mod, render_feedback_pose or pose, intr, render_dir / f"sds_{global_step}.png")
+            if global_step % save_freq == 0 or global_step in (1, num_iterations):
+                torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / f"model_iter_{global_step}.pth")
             last = time.perf_counter()
-            continue
-        if global_step % feedback_freq == 0 or global_step in (1, num_iterations):
-            log.info(f"TIME CHECK: time spent actually training till now: {timedelta(seconds=trained_time)}")
-            _write_feedback(sds_vol_mod, render_feedback_pose or pose, intr, render_dir / f"sds_{global_step}.png")
-        if global_step % save_freq == 0 or global_step in (1, num_iterations):
-            torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / f"model_iter_{global_step}.pth")
-        last = time.perf_counter()
-
-    if isinstance(optimizer, FusedGridAdam):
-        optimizer.detach()
+    finally:
+        if isinstance(optimizer, FusedGridAdam):   # (also when the loop raised: the mode must not outlive its optimiser)
+            optimizer.detach()
     if rank == 0:
         torch.save(sds_vol_mod.get_save_info(extra_info=extra_info), model_dir / "model_final.pth")
     log.info("Training complete")

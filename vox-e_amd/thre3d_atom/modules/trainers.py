@@ -102,44 +102,46 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
             optimizer = VoxeAdam([{"params": vol_mod.thre3d_repr.parameters(), "lr": lr}], betas=(0.9, 0.999))
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_decay_gamma_per_stage)
         log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
-        for it in range(1, num_iterations_per_stage + 1):
-            t0 = time.perf_counter()
-            # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
-            # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
-            picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
-            rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
-                intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks,
-                # (sorting the batch by (camera, row, column) helps the ray-ordered gather of small batches; batches of 16384+
-                #  rays take the space-binned render, which does not care about the order: skip the sort)
-                memory_order=ray_batch_size < 16384, fast_subset=True)
+        try:
+            for it in range(1, num_iterations_per_stage + 1):
+                t0 = time.perf_counter()
+                # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
+                # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
+                picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
+                rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
+                    intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks,
+                    # (sorting the batch by (camera, row, column) helps the ray-ordered gather of small batches; batches of 16384+
+                    #  rays take the space-binned render, which does not care about the order: skip the sort)
+                    memory_order=ray_batch_size < 16384, fast_subset=True)
 
-            specular = vol_mod.render_rays(rays_batch).colour
-            loss = torch.nn.functional.l1_loss(specular, pixels_batch)
-            psnr = mse2psnr(torch.nn.functional.mse_loss(specular.detach(), pixels_batch))
-            if apply_diffuse_render_regularization:
-                diffuse = vol_mod.render_rays(rays_batch, render_diffuse=True).colour
-                loss = loss + torch.nn.functional.l1_loss(diffuse, pixels_batch)
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-            global_step += 1
-            trained += time.perf_counter() - t0
-            if global_step % summary_freq == 0 or it in (1, num_iterations_per_stage):
-                log.info(f"Stage: {stage} Global Iteration: {global_step} Stage Iteration: {it} "
-                         f"loss: {float(loss.detach()): .3f} psnr: {float(psnr): .3f}")
-            if it % lr_decay_steps_per_stage == 0:
-                scheduler.step()
-            last = it == num_iterations_per_stage
-            if not fast_debug_mode and (global_step % feedback_freq == 0 or it == 1 or last):
-                log.info(f"TIME CHECK: time spent actually training till now: {trained:.1f} s")
-                rendered_feedback(global_step)
-            if test_dataset is not None and not fast_debug_mode and (global_step % test_freq == 0 or last):
-                test_sh_vox_grid_vol_mod_with_posed_images(vol_mod, test_dataset, parallel_rays_chunk_size=ray_batch_size,
-                                                           global_step=global_step)
-            if it % save_freq == 0 and not fast_debug_mode:
-                torch.save(vol_mod.get_save_info(extra_info), model_dir / f"model_stage_{stage}_iter_{it}.pth")
-        if fused_grid_step:
-            optimizer.detach()
+                specular = vol_mod.render_rays(rays_batch).colour
+                loss = torch.nn.functional.l1_loss(specular, pixels_batch)
+                psnr = mse2psnr(torch.nn.functional.mse_loss(specular.detach(), pixels_batch))
+                if apply_diffuse_render_regularization:
+                    diffuse = vol_mod.render_rays(rays_batch, render_diffuse=True).colour
+                    loss = loss + torch.nn.functional.l1_loss(diffuse, pixels_batch)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+                global_step += 1
+                trained += time.perf_counter() - t0
+                if global_step % summary_freq == 0 or it in (1, num_iterations_per_stage):
+                    log.info(f"Stage: {stage} Global Iteration: {global_step} Stage Iteration: {it} "
+                             f"loss: {float(loss.detach()): .3f} psnr: {float(psnr): .3f}")
+                if it % lr_decay_steps_per_stage == 0:
+                    scheduler.step()
+                last = it == num_iterations_per_stage
+                if not fast_debug_mode and (global_step % feedback_freq == 0 or it == 1 or last):
+                    log.info(f"TIME CHECK: time spent actually training till now: {trained:.1f} s")
+                    rendered_feedback(global_step)
+                if test_dataset is not None and not fast_debug_mode and (global_step % test_freq == 0 or last):
+                    test_sh_vox_grid_vol_mod_with_posed_images(vol_mod, test_dataset, parallel_rays_chunk_size=ray_batch_size,
+                                                               global_step=global_step)
+                if it % save_freq == 0 and not fast_debug_mode:
+                    torch.save(vol_mod.get_save_info(extra_info), model_dir / f"model_stage_{stage}_iter_{it}.pth")
+        finally:
+            if fused_grid_step:   # leave the deferred-gradient mode even when the loop raised (renders would return no .grad)
+                optimizer.detach()
         if stage != num_stages:
             with torch.no_grad():
                 vol_mod.thre3d_repr = scale_voxel_grid_with_required_output_size(vol_mod.thre3d_repr, grid_sizes[stage])

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # VoxeStatus
 OK = 0
@@ -105,6 +105,7 @@ _COMMON = {
 }
 
 GRAD_ANY, GRAD_LINEAR, GRAD_BRICKED = -1, 0, 1
+ROUTE_NONE, ROUTE_SCATTER, ROUTE_TILE, ROUTE_PACKED_SCATTER, ROUTE_REGION, ROUTE_DETERMINISTIC = -1, 0, 1, 2, 3, 4
 GRAPH_CAP_ONE = 1 << 28
 DIR_XP, DIR_XM, DIR_YP, DIR_YM, DIR_ZP, DIR_ZM = range(6)
 
@@ -131,7 +132,11 @@ HIP_ONLY = {
     "workspace_grad_offset": (C.c_size_t, [_GD]),
     "workspace_grad_bytes": (C.c_size_t, [_GD]),
     "grid_adam_step": (C.c_int, [_GD, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                 C.c_int64, _P, C.c_size_t, _P]),
+                                 C.c_int64, C.c_int64, _P, C.c_size_t, _P]),
+    "render_route": (C.c_int, [_GD, _RC, C.c_int64]),
+    "disparity_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "clock_probe": (C.c_int, [C.c_int32, C.POINTER(C.c_double), _P]),
+    "region_debug_layout": (C.c_int, [_GD, _RC, C.c_int64, C.POINTER(C.c_int64)]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "graphcut_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

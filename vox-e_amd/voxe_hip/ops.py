@@ -2,7 +2,6 @@
 the whole-grid passes.  Tensors are plumbing (device memory + streams); all compute is in the HIP
 library.  Nothing here falls back to torch ops or to the CPU oracle."""
 import ctypes as C
-import os
 import dataclasses
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
@@ -111,11 +110,17 @@ def _pack_key(spec: GridSpec, densities: torch.Tensor, features: torch.Tensor):
             tuple(features.shape), spec.density_scale, spec.density_pre_act, spec.feature_kind)
 
 
-def _state_key(pack_key, params: RenderParams, rays_o, rays_d, jitter, rng):
-    """identity of a forward call: the backward may consume the ray states only of exactly this call"""
+def _state_key(pack_key, params: RenderParams, rays_o, rays_d, jitter, rng, route=None):
+    """identity of a forward call: the backward may consume the ray states only of exactly this call -- and only when it
+    resolves to the same kernels (`route` = voxe_render_route: ray-ordered and space-binned renders keep different
+    tables, and the choice also depends on process-level tuning switches that may change between the two calls)"""
     fwd = tuple((k, v) for k, v in vars(params).items() if k not in ("linear_grad", "deterministic"))   # backward-only knobs
     return (pack_key, fwd, rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0],
-            None if jitter is None else jitter.data_ptr(), tuple(rng))
+            None if jitter is None else jitter.data_ptr(), tuple(rng), route)
+
+
+def _route(g, c, R) -> int:
+    return int(lib().voxe_render_route(C.byref(g), C.byref(c), int(R)))
 
 
 def _descs(spec: GridSpec, params: RenderParams, densities, features, seed, rng_offset, reuse):
@@ -165,7 +170,7 @@ def render_fwd_into(spec: GridSpec, params: RenderParams, densities, features, r
                                 ptr(depth), ptr(acc), ptr(disparity), ptr(ws), ws.numel(),
                                 stream_ptr(device)), "voxe_render_fwd")
     workspace.key = key
-    workspace.state_key = _state_key(key, params, rays_o, rays_d, jitter, rng)
+    workspace.state_key = _state_key(key, params, rays_o, rays_d, jitter, rng, _route(g, c, R))
 
 
 def render_bwd_into(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
@@ -180,7 +185,7 @@ def render_bwd_into(spec: GridSpec, params: RenderParams, densities, features, r
     with torch.cuda.device(device):
         ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
         c.reuse_packed_grid = int(workspace.key == key)
-        c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng))
+        c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng, _route(g, c, R)))
         check(L.voxe_render_bwd(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
                                 ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
                                 ptr(d_densities), ptr(d_features), int(accumulate), ptr(ws), ws.numel(),
@@ -219,32 +224,18 @@ class _RenderFn(torch.autograd.Function):
     def backward(ctx, g_colour, g_depth, g_acc, g_disp):
         densities, features, ro, rd, jit, colour, depth, acc = ctx.saved_tensors
         need_d, need_f = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        if os.environ.get("VOXE_DEBUG_SYNC"):
-            print("[voxe] _RenderFn.backward entered", None if g_colour is None else (tuple(g_colour.shape), g_colour.dtype,
-                  g_colour.is_contiguous(), g_colour.stride()), g_depth is None, g_acc is None, g_disp is None, flush=True)
-            torch.cuda.synchronize()
-            print("[voxe] sync ok; ws ptr", hex(ctx.workspace.buf.data_ptr()), ctx.workspace.buf.numel(), flush=True)
         if not (need_d or need_f):
             return (None,) * 9
         device = densities.device
         spec, params, workspace = ctx.spec, ctx.params, ctx.workspace
+        g_depth = None if g_depth is None else f32c(g_depth)
+        g_acc = None if g_acc is None else f32c(g_acc)
         if g_disp is not None:
-            # disparity = 1 / max(1e-10, depth / acc)  (accumulate.py:85-88): chain into depth and acc
-            q = depth / acc
-            live = (q > 1e-10).to(g_disp.dtype)
-            dq = -g_disp / (q * q) * live
-            dq = torch.nan_to_num(dq, nan=0.0, posinf=0.0, neginf=0.0)
-            gd_extra = dq / acc
-            ga_extra = -dq * depth / (acc * acc)
-            gd_extra = torch.nan_to_num(gd_extra, nan=0.0, posinf=0.0, neginf=0.0)
-            ga_extra = torch.nan_to_num(ga_extra, nan=0.0, posinf=0.0, neginf=0.0)
-            g_depth = gd_extra if g_depth is None else g_depth + gd_extra
-            g_acc = ga_extra if g_acc is None else g_acc + ga_extra
+            # disparity = 1 / max(1e-10, depth / acc)  (accumulate.py:85-88): chained into d_depth and d_acc by one kernel
+            g_depth, g_acc = disparity_bwd(depth, acc, f32c(g_disp), g_depth, g_acc)
         if g_colour is None:
             g_colour = torch.zeros_like(colour)
         g_colour = f32c(g_colour)
-        g_depth = None if g_depth is None else f32c(g_depth)
-        g_acc = None if g_acc is None else f32c(g_acc)
         dens, feat = f32c(densities.detach()), f32c(features.detach())
         main = ctx.main_workspace
         deferred = main.deferred
@@ -552,7 +543,7 @@ def render_bwd_acc(spec: GridSpec, params: RenderParams, densities, features, ra
     with torch.cuda.device(device):
         ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
         c.reuse_packed_grid = int(workspace.key == key)
-        c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng))
+        c.ray_state_valid = int(workspace.state_key == _state_key(key, params, rays_o, rays_d, jitter, rng, _route(g, c, R)))
         gws = None if grad_workspace is None else grad_workspace.buf
         check(L.voxe_render_bwd_acc_into(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
                                          ptr(depth), ptr(acc), ptr(g_colour), ptr(g_depth), ptr(g_acc),
@@ -593,12 +584,13 @@ def workspace_packed_view(spec: GridSpec, densities, features, workspace: Worksp
 def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, workspace: Workspace, step: int, lr: float,
                     state_densities=None, state_features=None, extra_d_densities=None, extra_d_features=None,
                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                    x_range: Optional[Tuple[int, int]] = None) -> None:
+                    x_range: Optional[Tuple[int, int]] = None, step_features: Optional[int] = None) -> None:
     """voxe_grid_adam_step: consume the workspace gradient (+ optional extra gradients in tensor layout), update
     densities / features in place with torch.optim.Adam arithmetic, leave the NEW grid packed and a zeroed gradient
     region in the workspace.  state_* = (exp_avg, exp_avg_sq) or None to freeze that tensor.  x_range = (x_begin, x_end)
     restricts the step to a slab of x-planes (sharded optimiser: the caller exchanges the other slabs of the packed grid
-    before the next render)."""
+    before the next render).  `step` / `step_features`: the 1-based Adam step of the densities / of the features
+    (torch.optim.Adam counts per parameter; `step_features` None = the same as `step`)."""
     device = densities.device
     ensure_gfx950(device)
     tensors = [("densities", densities, densities), ("features", features, features)]
@@ -622,7 +614,8 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
         x0, x1 = (0, int(densities.shape[0])) if x_range is None else (int(x_range[0]), int(x_range[1]))
         check(lib().voxe_grid_adam_step(C.byref(g), int(grad_layout), x0, x1, ptr(extra_d_densities), ptr(extra_d_features),
                                         ptr(m_d), ptr(v_d), ptr(m_f), ptr(v_f), float(lr), float(beta1), float(beta2),
-                                        float(eps), int(step), ptr(ws), ws.numel(), stream_ptr(device)),
+                                        float(eps), int(step), int(step if step_features is None else step_features),
+                                        ptr(ws), ws.numel(), stream_ptr(device)),
               "voxe_grid_adam_step")
     for t in (densities, features, m_d, v_d, m_f, v_f):
         if t is not None:
@@ -715,6 +708,49 @@ def cc_largest_k(mask: torch.Tensor, k: int) -> Tuple[torch.Tensor, int]:
         check(lib().voxe_cc_largest_k(ptr(m), X, Y, Z, int(k), ptr(labels), ptr(ncomp), ptr(scratch), nbytes,
                                       stream_ptr(device)), "voxe_cc_largest_k")
     return labels, int(ncomp.item())
+
+
+@torch.no_grad()
+def disparity_bwd(depth: torch.Tensor, acc: torch.Tensor, g_disp: torch.Tensor, g_depth: Optional[torch.Tensor] = None,
+                  g_acc: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """voxe_disparity_bwd: (g_depth + d disparity/d depth * g_disp, g_acc + d disparity/d acc * g_disp), all [R, 1]"""
+    require_device(depth, "disparity_bwd")
+    out_d, out_a = torch.empty_like(depth), torch.empty_like(acc)
+    with torch.cuda.device(depth.device):
+        check(lib().voxe_disparity_bwd(ptr(depth), ptr(acc), ptr(g_disp), ptr(g_depth), ptr(g_acc), ptr(out_d), ptr(out_a),
+                                       depth.numel(), stream_ptr(depth.device)), "voxe_disparity_bwd")
+    return out_d, out_a
+
+
+def clock_probe(device, spin: int = 0) -> float:
+    """sustained shader clock in Hz (voxe_clock_probe: enqueued on the current stream, then waited for)"""
+    hz = C.c_double(0.0)
+    with torch.cuda.device(device):
+        check(lib().voxe_clock_probe(int(spin), C.byref(hz), stream_ptr(device)), "voxe_clock_probe")
+    return float(hz.value)
+
+
+def region_debug_tables(spec: GridSpec, params: RenderParams, densities, features, R: int, workspace: Workspace) -> dict:
+    """views of the space-binned route's segment tables in `workspace` (as the last forward of these R rays left them):
+    test aid, see voxe_region_debug_layout"""
+    g, c = _descs(spec, params, densities, features, 0, 0, False)
+    out = (C.c_int64 * 17)()
+    check(lib().voxe_region_debug_layout(C.byref(g), C.byref(c), int(R), out), "voxe_region_debug_layout")
+    base, (o_region, o_pos, o_seg, o_sorted, o_lane_n, o_count, o_start, nslots, nlanes, nreg, per_lane, bx, by, bz, ncls,
+           chunk) = int(out[0]), [int(v) for v in out[1:]]
+    buf = workspace.buf
+
+    def view(off, n, dtype, width=1):
+        nbytes = n * width * torch.empty((), dtype=dtype).element_size()
+        return buf[base + off: base + off + nbytes].view(dtype).view(n, width) if width > 1 else \
+            buf[base + off: base + off + nbytes].view(dtype)
+
+    ncnt = (nreg + 1) * ncls + 1
+    return {"slot_region": view(o_region, nslots, torch.int32), "slot_pos": view(o_pos, nslots, torch.int32),
+            "slot_seg": view(o_seg, nslots, torch.int32, 2), "sorted": view(o_sorted, nslots, torch.int32, 4),
+            "lane_n": view(o_lane_n, nlanes, torch.int32), "count": view(o_count, ncnt, torch.int32),
+            "start": view(o_start, ncnt, torch.int32), "nreg": nreg, "slots_per_lane": per_lane,
+            "region_cells": (bx, by, bz), "len_classes": ncls, "chunk": chunk}
 
 
 def profile_enable(on: bool = True) -> None:

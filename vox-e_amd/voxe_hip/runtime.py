@@ -41,7 +41,8 @@ def lib():
     return _lib
 
 
-_DEBUG_SYNC = bool(os.environ.get("VOXE_DEBUG_SYNC"))   # debugging aid: synchronise + log after every library call
+_DEBUG_SYNC = bool(os.environ.get("VOXE_DEBUG_SYNC"))   # debugging aid: synchronise after every library call, so that an
+                                                        # asynchronous device fault surfaces at the call that caused it
 
 
 def check(status: int, what: str) -> None:
@@ -49,8 +50,10 @@ def check(status: int, what: str) -> None:
         msg = lib().voxe_strerror(status).decode()
         raise VoxeError(f"{what}: {msg} (status {status})")
     if _DEBUG_SYNC:
-        torch.cuda.synchronize()
-        print(f"[voxe] {what} done", flush=True)
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError as e:
+            raise VoxeError(f"{what}: device fault surfaced at the synchronisation after this call: {e}") from e
 
 
 def require_device(t: torch.Tensor, what: str) -> None:
