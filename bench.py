@@ -24,7 +24,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), ROOT):
+for _p in (os.path.join(ROOT, "vox-e_amd"), ROOT):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
@@ -32,7 +32,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (MI355X_MICROARCH.md); the sustained clock under this load is lower
+SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (MI355X_MICROARCH.md); the run MEASURES the sustained clock (voxe_clock_probe)
+                         # and quotes the issue-rate ceilings against that; this constant is reported next to it
 # Same-host factor between the CPU oracle (kind "port") and the reference's PyTorch CPU path, measured in the 8-vCPU build
 # container: oracle 50.5 k rays/s vs reference 5.7 k rays/s at 160^3, 400x400, fwd+bwd, 8 threads
 ORACLE_VS_REFERENCE_400 = 8.9
@@ -63,12 +64,17 @@ def parse():
                     help="image: row-major image rays with the width hint (LDS-window backward); linear: same rays without the "
                          "hint; random: the rays in a random permutation (what a random-ray training batch looks like)")
     ap.add_argument("--camera", type=int, default=3, help="index of the synthetic camera (of 100) rendered by rank 0")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: one camera per rank (total work grows with N); strong: ONE camera, every rank renders a band of "
+                         "its rows (what a multi-GPU SDS iteration does: one image per step, modules/sds_trainer.py) -- same "
+                         "gradient exchange")
+    ap.add_argument("--no-gpu-baseline", action="store_true", help="skip timing the PyTorch restatement of the path on this GPU")
     return ap.parse_args()
 
 
 def main():
     args = parse()
-    from synth import FAR, NEAR, RADIUS, focal_for, random_grid, sphere_grid, synth_pose_angles
+    from voxe_hip.workload import FAR, NEAR, RADIUS, focal_for, random_grid, sphere_grid, synth_pose_angles
     from thre3d_atom.utils.imaging_utils import pose_spherical
     from voxe_hip import abi, ops
 
@@ -112,19 +118,31 @@ def main():
     d_dens = flat_g[nvox * 3:].view(G, G, G, 1)
     exp_avg, exp_avg_sq = torch.zeros_like(flat_p), torch.zeros_like(flat_p)
 
-    # weak scaling: every rank renders its own camera (cameras rank, rank + world, ... of the 100-view set)
-    yaw, pitch = synth_pose_angles(args.camera + rank, 100)
+    # weak scaling: every rank renders its own camera (cameras rank, rank + world, ... of the 100-view set);
+    # strong scaling: ONE camera, rank r renders the rows [row_lo, row_hi) (8-row aligned bands: whole pixel tiles)
+    strong = args.scaling == "strong"
+    if strong and args.ray_order != "image":
+        raise SystemExit("--scaling strong shards an IMAGE by rows: use --ray-order image")
+    yaw, pitch = synth_pose_angles(args.camera + (0 if strong else rank), 100)
     pose = pose_spherical(yaw, pitch, RADIUS)
     rays_o, rays_d = ops.cast_rays(HW, HW, focal_for(HW), pose.rotation, pose.translation, dev)
+    rows = (0, HW)
+    if strong:
+        from thre3d_atom.modules.parallel import shard_rows
+
+        rows = shard_rows(HW, rank, world)
+        rays_o = rays_o[rows[0] * HW: rows[1] * HW].contiguous()
+        rays_d = rays_d[rows[0] * HW: rows[1] * HW].contiguous()
     R = rays_o.shape[0]
+    R_job = HW * HW if strong else world * R          # rays of the whole job per step
     if args.ray_order == "random":
         perm = torch.randperm(R, generator=torch.Generator().manual_seed(7)).to(dev)
         rays_o, rays_d = rays_o[perm].contiguous(), rays_d[perm].contiguous()
     hint = HW if args.ray_order == "image" else 0
     params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=not args.no_jitter, white_bkgd=True,
                               term_eps=args.term_eps, image_width=hint)
-    gen = torch.Generator().manual_seed(43 + rank)
-    g_colour = torch.randn((R, 3), generator=gen).to(dev)
+    gen = torch.Generator().manual_seed(43 + (0 if strong else rank))
+    g_colour = torch.randn((HW * HW, 3), generator=gen)[rows[0] * HW: rows[1] * HW].contiguous().to(dev)
     colour = torch.empty((R, 3), dtype=torch.float32, device=dev)
     depth = torch.empty((R, 1), dtype=torch.float32, device=dev)
     acc = torch.empty((R, 1), dtype=torch.float32, device=dev)
@@ -231,7 +249,9 @@ def main():
         opt.gather_parameters()
         del packed
 
-    rays_per_s = world * R * args.steps / elapsed
+    # sustained shader clock, measured right behind the timed region (the chip is at its working temperature / power state)
+    clock_hz = ops.clock_probe(dev)
+    rays_per_s = R_job * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, voxe_profile_*) -------------
@@ -259,45 +279,67 @@ def main():
     # The kernel is bound by those two issue rates, not by HBM: `frac` (SURVEY.md 8(d)'s requested-bytes convention) can
     # exceed 1 because corner fetches shared by neighbouring rays are served on chip; `binding` names the ceiling that
     # actually limits the kernel and `binding_frac` its utilisation -- none of the physical fractions can exceed 1.
-    traffic, traffic_src, physical = None, None, None
-    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, args.ray_order) == (160, 400, 256, "random", 0.0, False, 3, "image")
+    # The PMC summary is only valid for the kernels it was collected on: tools/pmc_to_json.py stamps it with a hash of
+    # vox-e_amd/csrc/* + include/voxe.h, and a summary whose hash differs from this tree's is reported as stale, not used.
+    from voxe_hip.build import source_hash
+
+    src_hash = source_hash()
+    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, args.ray_order, strong) == (160, 400, 256, "random", 0.0, False, 3, "image", False)
+    pmc, pmc_rel, pmc_stale = None, None, None
     pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
     if default_cfg and pmc_files:
         pmc_rel = os.path.join("profiles", pmc_files[-1])
-        pmc = json.load(open(os.path.join(ROOT, pmc_rel)))["kernels"]
-        prefix = "voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0," if ms_bwd >= ms_fwd else "voxe::render_fwd_seg_kernel<3, 1, 1>"
-        # (template arguments of the backward: ..., MODE, window width KL[, deterministic]; 400x400 at 160^3 runs the 8-wide
-        #  float-atomic one)
-        def _is_headline_bwd(name):
-            targs = [a.strip() for a in name[name.index("<") + 1: name.rindex(">")].split(",")]
-            return len(targs) >= 7 and targs[6] == "8" and (len(targs) < 8 or targs[7] == "false")
-        keys = [k for k in pmc if k.startswith(prefix) and (ms_bwd < ms_fwd or _is_headline_bwd(k))]
+        summary = json.load(open(os.path.join(ROOT, pmc_rel)))
+        pmc_stale = summary.get("source_hash") != src_hash
+        if not pmc_stale:
+            pmc = summary["kernels"]
+
+    def physical_of(prefix, accept, launch_ms):
+        """ceilings of one kernel: counters per launch from the hash-matched PMC summary, launch time and clock from THIS run"""
+        if pmc_stale:
+            return {"stale": True, "reason": f"{pmc_rel} was collected on other kernel sources (source_hash differs from "
+                                             f"{src_hash}): re-run tools/gpu_pmc.sh + tools/pmc_to_json.py"}
+        if pmc is None or launch_ms <= 0:
+            return None
+        keys = [k for k in pmc if k.startswith(prefix) and accept(k)]
         cnt = pmc[keys[0]] if keys else {}
-        if "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
-            traffic = int((2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"]) * 1024)
-            traffic_src = f"{pmc_rel} (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB), kernel {keys[0]}"
-        if "SQ_INSTS_VALU" in cnt and "SQ_LDS_IDX_ACTIVE" in cnt and kms > 0:
-            compulsory = 2 * nvox * 4 * 4
-            valu = cnt["SQ_INSTS_VALU"] * 4.0 / (1024 * SHADER_CLOCK_HZ * kms * 1e-3)
-            lds = cnt["SQ_LDS_IDX_ACTIVE"] / (256 * SHADER_CLOCK_HZ * kms * 1e-3)
-            hbm = traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
-            ceilings = {"valu_issue": valu, "lds_issue": lds}
-            if hbm is not None:
-                ceilings["hbm"] = hbm
-            binding = max(ceilings, key=ceilings.get)
-            physical = {
-                "valu_issue_frac": round(valu, 4), "lds_issue_frac": round(lds, 4),
-                "hbm_frac_measured": round(hbm, 4) if hbm is not None else None,
-                "compulsory_bytes": int(compulsory),
-                "traffic_over_compulsory": round(traffic / compulsory, 2) if traffic else None,
-                "binding": binding, "binding_frac": round(ceilings[binding], 4),
-                "clock_hz_assumed": SHADER_CLOCK_HZ,
-                "counters": {k: cnt[k] for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
-                                                 "FETCH_SIZE", "WRITE_SIZE") if k in cnt},
-                "note": "counter values are per launch from the committed PMC summary, the launch time is this run's "
-                        "(HIP events); fractions are of the 2.4 GHz peak clock, i.e. lower bounds on the utilisation at the "
-                        "sustained clock",
-            }
+        if not all(k in cnt for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE")):
+            return None
+        t = launch_ms * 1e-3
+        hbm_bytes = int((2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"]) * 1024)
+        ceil = {"valu_issue": cnt["SQ_INSTS_VALU"] * 4.0 / (1024 * clock_hz * t), "lds_issue": cnt["SQ_LDS_IDX_ACTIVE"] / (256 * clock_hz * t),
+                "hbm": hbm_bytes / t / 1e9 / HBM_PEAK_GBS}
+        binding = max(ceil, key=ceil.get)
+        return {
+            "kernel": keys[0], "launch_ms": round(launch_ms, 4),
+            "valu_issue_frac": round(ceil["valu_issue"], 4), "lds_issue_frac": round(ceil["lds_issue"], 4),
+            "hbm_frac_measured": round(ceil["hbm"], 4), "traffic_bytes": hbm_bytes,
+            "binding": binding, "binding_frac": round(ceil[binding], 4),
+            "at_peak_clock": {"valu_issue_frac": round(ceil["valu_issue"] * clock_hz / SHADER_CLOCK_HZ, 4),
+                              "lds_issue_frac": round(ceil["lds_issue"] * clock_hz / SHADER_CLOCK_HZ, 4)},
+            "counters": {k: cnt[k] for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
+                                             "FETCH_SIZE", "WRITE_SIZE") if k in cnt},
+        }
+
+    def _is_headline_bwd(name):
+        # template arguments of the backward: ..., MODE, window width KL[, deterministic]; 400x400 at 160^3 runs the 8-wide
+        # float-atomic one
+        targs = [a.strip() for a in name[name.index("<") + 1: name.rindex(">")].split(",")]
+        return len(targs) >= 7 and targs[6] == "8" and (len(targs) < 8 or targs[7] == "false")
+
+    phys_bwd = physical_of("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0,", _is_headline_bwd, ms_bwd)
+    phys_fwd = physical_of("voxe::render_fwd_seg_kernel<3, 1, 1>", lambda k: True, ms_fwd)
+    physical = phys_bwd if ms_bwd >= ms_fwd else phys_fwd
+    traffic = physical.get("traffic_bytes") if physical and not physical.get("stale") else None
+    traffic_src = (f"{pmc_rel} (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB; source_hash {src_hash}), "
+                   f"kernel {physical['kernel']}") if traffic else None
+    if physical and not physical.get("stale"):
+        physical = dict(physical)
+        physical["compulsory_bytes"] = int(2 * nvox * 4 * 4)       # read the grid once + write the gradient once
+        physical["traffic_over_compulsory"] = round(traffic / (2 * nvox * 4 * 4), 2)
+        physical["note"] = ("counters per launch from the committed PMC summary whose source_hash equals this tree's; launch time "
+                            "(HIP events) and shader clock (voxe_clock_probe: s_memtime / s_memrealtime under a VALU + LDS load, "
+                            "right behind the timed steps) are THIS run's; `at_peak_clock` = the same fractions against 2.4 GHz")
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -308,12 +350,15 @@ def main():
                    "are served from L1 / L2 / the LDS gradient window); the physical ceilings are in `physical`",
         "hbm_measured_gbs": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None),
         "physical": physical,
+        # the other render kernel of the step (the forward when the backward dominates), same derivation
+        "physical_other": (phys_fwd if ms_bwd >= ms_fwd else phys_bwd),
+        "clock_hz_measured": round(clock_hz, 0), "clock_hz_peak": SHADER_CLOCK_HZ, "source_hash": src_hash,
         "phases_ms": {"pack": round(prof["ms_pack"] / max(prof["n_pack"], 1), 4), "fwd": round(ms_fwd, 4),
                       "memset": round(prof["ms_memset"] / max(prof["n_memset"], 1), 4), "bwd": round(ms_bwd, 4),
                       "unpack": round(prof["ms_unpack"] / max(prof["n_unpack"], 1), 4)},
-        "in_aabb_samples_per_ray": round(s_in_total / R, 2),
+        "in_aabb_samples_per_ray": round(s_in_total / max(R, 1), 2),
         # whole-step figure in BASELINE.md's convention: rays/s x (S_in*384 + 72) B, per GPU
-        "step_alg_gbs_per_gpu": round(rays_per_s / world * (s_in_total / R * 384 + 72) / 1e9, 2),
+        "step_alg_gbs_per_gpu": round(rays_per_s / world * (s_in_total / max(R, 1) * 384 + 72) / 1e9, 2),
     }
 
     # ---- secondary lines: the same step at 100x100 (BASELINE.json asks for both image sizes), N = 1 default run only:
@@ -364,16 +409,51 @@ def main():
             pr2 = ops.profile_read()
             ops.profile_enable(False)
             b2 = pr2["ms_bwd"] / max(pr2["n_bwd"], 1)
+            phys2 = None
+            if K > 1:   # the 8-camera launch takes the space-binned route: ceilings of its backward kernel (one launch per PH_BWD)
+                phys2 = physical_of("voxe::region_bwd_kernel<3, 1>", lambda k: True, b2)
             return {
                 "workload": f"same grid and step, {K} x {hw2}x{hw2} camera(s) in one launch", "cameras_per_step": K,
                 "value": round(R2 * args.steps / e2, 1), "unit": "rays/s",
                 "ms_per_step": round(1e3 * e2 / args.steps, 4), "in_aabb_samples_per_ray": round(s_in2 / R2, 2),
                 "bwd_ms": round(b2, 4), "fwd_ms": round(pr2["ms_fwd"] / max(pr2["n_fwd"], 1), 4),
                 "roofline_frac_bwd": round((s_in2 * 256 + R2 * 56) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b2 > 0 else None,
+                "physical_bwd": phys2,
             }
 
         secondary = small_step_bench(1)
         secondary["multi_view"] = small_step_bench(8)
+
+    # ---- same-GPU baseline: a plain PyTorch restatement of the path (the reference's execution model: ~40 ATen ops with
+    # [rays x samples] temporaries + autograd + torch.optim.Adam; voxe_hip/torch_baseline.py, pinned to the reference's
+    # outputs and gradients by tests/test_torch_baseline.py) under PyTorch-ROCm on this very GPU, outside the timed region ----
+    gpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_gpu_baseline:
+        from voxe_hip import torch_baseline as tb
+
+        torch.cuda.empty_cache()
+
+        def gpu_pass(hw, steps):
+            ro_b, rd_b = ops.cast_rays(hw, hw, focal_for(hw), pose.rotation, pose.translation, dev)
+            gb = torch.randn((hw * hw, 3), generator=torch.Generator().manual_seed(43)).to(dev)
+            dt = tb.time_step(dens_cpu.to(dev), feat_cpu.to(dev), aabb, 100.0 / 3.0, ro_b, rd_b, gb, S, NEAR, FAR,
+                              chunk=32768, steps=steps, warmup=1)
+            return hw * hw / dt, dt
+
+        try:
+            rps_full, dt_full = gpu_pass(HW, 3)
+            rps_small, dt_small = gpu_pass(100, 5)
+            gpu_baseline = {
+                "value": round(rps_full, 1), "unit": "rays/s", "kind": "port",
+                "what": "PyTorch-ROCm restatement of the reference path (F.grid_sample x2, softplus, exp, cumprod, autograd, "
+                        "torch.optim.Adam; 32768-ray chunks like parallel_rays_chunk_size) on this GPU, same grid / camera / S",
+                "ms_per_step": round(1e3 * dt_full, 2), "speedup": round(rays_per_s / rps_full, 1),
+                "at_100x100": {"value": round(rps_small, 1), "ms_per_step": round(1e3 * dt_small, 2)},
+                "torch": torch.__version__,
+            }
+        except RuntimeError as e:          # (e.g. out of memory on a shared box): report, do not fail the bench line
+            gpu_baseline = {"error": str(e).splitlines()[0][:200]}
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (a C port of the reference path) on the host cores, bounded sample ----
     cpu_baseline = None
@@ -416,15 +496,17 @@ def main():
         out = {
             "metric": "rendered rays/sec (fwd+bwd)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{G}^3 SH-0 softplus ReLU-field grid ({args.scene}), one {HW}x{HW} camera per GPU, "
+                "workload": f"{G}^3 SH-0 softplus ReLU-field grid ({args.scene}), "
+                            + (f"ONE {HW}x{HW} camera split into row bands over the GPUs, " if strong else f"one {HW}x{HW} camera per GPU, ") +
                             f"S={S}, jitter {'off' if args.no_jitter else 'on'}, white bkgd, ray order {args.ray_order}; step = render fwd + bwd"
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
                             f"{'' if args.no_adam else (' + Adam (fused grid step)' if fused else ' + Adam')}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
-                "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": f"rays sharded by camera over {world} GPU(s), grid replicated",
+                "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": (f"rows of one image sharded over {world} GPU(s), grid replicated" if strong else f"rays sharded by camera over {world} GPU(s), grid replicated"),
+                "rows_of_rank0": list(rows),
                 "replicas_consistent": replicas_consistent, "backend": (backend if dist is not None else None),
                 "exchange_autotune_ms": (opt.tuned_ms if fused else None),
                 # device time per step between the backward and the next render that is NOT the local optimiser kernel:
@@ -435,7 +517,7 @@ def main():
                 "untimed_steps_before_timing": PRE_WARM_STEPS + args.warmup,
             },
             "roofline": roofline, "secondary": secondary,
-            "cpu_baseline": cpu_baseline,
+            "gpu_baseline": gpu_baseline, "cpu_baseline": cpu_baseline,
         }
     if dist is not None:
         dist.destroy_process_group()

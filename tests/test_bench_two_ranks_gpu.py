@@ -43,6 +43,25 @@ def test_two_rank_bench_on_one_gpu(exchange, expect):
 
 
 @pytest.mark.timeout(600)
+def test_two_rank_strong_scaling_bench_on_one_gpu():
+    """`--scaling strong`: ONE camera split into row bands (what a multi-GPU SDS iteration does), same exchange; the job's
+    rays per step are the image's, not N images'"""
+    env = dict(os.environ, VOXE_BENCH_BACKEND="gloo", VOXE_GRAD_EXCHANGE="reduce-scatter", VOXE_BENCH_PRE_WARM="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--grid", "32", "--image", "100", "--samples", "64", "--scaling", "strong"]
+    res = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    cfg = out["config"]
+    assert cfg["replicas_consistent"] is True and cfg["rows_of_rank0"] == [0, 48]     # 13 tile rows of 8 pixels: 6 + 7
+    assert cfg["rays_per_gpu_per_step"] == 48 * 100
+    # value counts the IMAGE once per step
+    assert abs(out["value"] - 100 * 100 * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"])) < 1e-3 * out["value"]
+
+
+@pytest.mark.timeout(600)
 @pytest.mark.parametrize("exchange", ["reduce-scatter", "all-to-all", "all-reduce"])
 def test_two_ranks_equal_one_process(exchange):
     """4 optimiser steps of the 2-rank job (one camera per rank, gradient exchange, sharded / replicated fused Adam) land

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), ROOT]
 
 import torch  # noqa: E402
-from synth import FAR, NEAR, RADIUS, focal_for, sphere_grid, synth_pose_angles  # noqa: E402
+from voxe_hip.workload import FAR, NEAR, RADIUS, focal_for, sphere_grid, synth_pose_angles  # noqa: E402
 from thre3d_atom.utils.imaging_utils import pose_spherical  # noqa: E402
 from voxe_hip import abi, ops  # noqa: E402
 

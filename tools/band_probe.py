@@ -4,7 +4,7 @@ sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), RO
 import numpy as np, torch
 import gpu_helpers as gh
 from helpers import band_errors, rel_l2
-from synth import *
+from voxe_hip.workload import *
 from voxe_hip import abi
 from voxe_hip.desc import make_render_cfg
 from oracle import voxe_oracle as vo

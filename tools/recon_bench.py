@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), ROOT]
 
 import torch  # noqa: E402
-from synth import FAR, NEAR, RADIUS, focal_for, random_grid, synth_pose_angles  # noqa: E402
+from voxe_hip.workload import FAR, NEAR, RADIUS, focal_for, random_grid, synth_pose_angles  # noqa: E402
 from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam  # noqa: E402
 from thre3d_atom.modules.volumetric_model import VolumetricModel  # noqa: E402
 from thre3d_atom.rendering.volumetric.utils.misc import (  # noqa: E402

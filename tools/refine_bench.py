@@ -9,7 +9,7 @@ sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), RO
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from synth import refine_scene  # noqa: E402
+from voxe_hip.workload import refine_scene  # noqa: E402
 from voxe_hip import ops  # noqa: E402
 
 from oracle import voxe_oracle as vo  # noqa: E402

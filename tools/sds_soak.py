@@ -12,7 +12,7 @@ sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), os.path.join(ROOT, "tests"), RO
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from synth import FAR, NEAR, focal_for, sphere_grid  # noqa: E402
+from voxe_hip.workload import FAR, NEAR, focal_for, sphere_grid  # noqa: E402
 from thre3d_atom.modules.sds_trainer import train_sh_vox_grid_vol_mod_with_posed_images_and_sds  # noqa: E402
 from thre3d_atom.modules.volumetric_model import VolumetricModel  # noqa: E402
 from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, render_sh_voxel_grid  # noqa: E402

@@ -646,6 +646,7 @@ int voxe_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t 
                     size_t scratch_bytes, void* stream) {
   if (!grid || !loss_out) return VOXE_ERR_NULL_POINTER;
   if (X <= 0 || Y <= 0 || Z <= 0 || C <= 0) return VOXE_ERR_BAD_SHAPE;
+  if ((long long)Y * Z * C >= (1ll << 31) - 256) return VOXE_ERR_BAD_SHAPE;   // (32-bit index arithmetic inside an x-plane)
   if (!scratch || scratch_bytes < tv_scratch_bytes(X, Y, Z, C)) return VOXE_ERR_WORKSPACE;
   launch_tv(grid, X, Y, Z, C, grad_scale, loss_out, d_grid, accumulate, scratch, (hipStream_t)stream);
   return finish();
@@ -663,6 +664,7 @@ int voxe_upsample_trilinear(const float* src, int32_t X, int32_t Y, int32_t Z, i
                             int32_t X2, int32_t Y2, int32_t Z2, void* stream) {
   if (!src || !dst) return VOXE_ERR_NULL_POINTER;
   if (X <= 0 || Y <= 0 || Z <= 0 || C <= 0 || X2 <= 0 || Y2 <= 0 || Z2 <= 0) return VOXE_ERR_BAD_SHAPE;
+  if (X2 > 65535 || (long long)Y2 * Z2 * C >= (1ll << 31) - 256) return VOXE_ERR_BAD_SHAPE;   // (grid.y / 32-bit plane index)
   launch_upsample(src, X, Y, Z, C, dst, X2, Y2, Z2, (hipStream_t)stream);
   return finish();
 }

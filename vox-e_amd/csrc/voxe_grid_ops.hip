@@ -191,30 +191,35 @@ void launch_dcl(const float* a, const float* b, long long n, float grad_scale, f
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
+// Thread mapping: blockIdx.y walks x-planes, blockIdx.x / threadIdx.x the Y * Z * C elements of a plane (contiguous in
+// memory: coalesced), both with a stride, so that (x, y, z, channel) come from ONE 32-bit division per element (two for
+// channel counts other than 1 / 3) instead of 64-bit div / mod chains (which made this streaming pass instruction bound:
+// 0.7 TB/s at 160^3 before, r03).  Same per-element arithmetic as before; the double partial sums only change their order.
+template <int CT>   // CT = channel count known at compile time (1, 3) or 0: run-time C
 __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ grid, int X, int Y, int Z,
-                                                 int C, float gx, float gy, float gz,
+                                                 int C_rt, float gx, float gy, float gz,
                                                  double* __restrict__ partial,
                                                  float* __restrict__ d_grid, int accumulate) {
-  const long long n = (long long)X * Y * Z * C;
-  const long long sx = (long long)Y * Z * C, sy = (long long)Z * C, sz = C;
+  const unsigned C = CT > 0 ? (unsigned)CT : (unsigned)C_rt;
+  const unsigned sy = (unsigned)Z * C, plane = (unsigned)Y * sy;   // elements of a y-row / an x-plane (< 2^31: validated on the host)
   double s[3] = {0, 0, 0};
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const long long vox = i / C;
-    const int z = (int)(vox % Z);
-    const int y = (int)((vox / Z) % Y);
-    const int x = (int)(vox / ((long long)Z * Y));
-    const float v = grid[i];
-    float g = 0.0f;
-    if (x + 1 < X) { const float df = grid[i + sx] - v; s[0] += fabsf(df); g -= sgnf(df) * gx; }
-    if (x > 0) { const float df = v - grid[i - sx]; g += sgnf(df) * gx; }
-    if (y + 1 < Y) { const float df = grid[i + sy] - v; s[1] += fabsf(df); g -= sgnf(df) * gy; }
-    if (y > 0) { const float df = v - grid[i - sy]; g += sgnf(df) * gy; }
-    if (z + 1 < Z) { const float df = grid[i + sz] - v; s[2] += fabsf(df); g -= sgnf(df) * gz; }
-    if (z > 0) { const float df = v - grid[i - sz]; g += sgnf(df) * gz; }
-    if (d_grid) d_grid[i] = accumulate ? d_grid[i] + g : g;
+  for (unsigned x = blockIdx.y; x < (unsigned)X; x += gridDim.y) {
+    const long long base = (long long)x * plane;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < plane; e += gridDim.x * 256u) {
+      const unsigned y = e / sy, zc = e - y * sy, z = zc / C;
+      const long long i = base + e;
+      const float v = grid[i];
+      float g = 0.0f;
+      if (x + 1 < (unsigned)X) { const float df = grid[i + plane] - v; s[0] += fabsf(df); g -= sgnf(df) * gx; }
+      if (x > 0) { const float df = v - grid[i - plane]; g += sgnf(df) * gx; }
+      if (y + 1 < (unsigned)Y) { const float df = grid[i + sy] - v; s[1] += fabsf(df); g -= sgnf(df) * gy; }
+      if (y > 0) { const float df = v - grid[i - sy]; g += sgnf(df) * gy; }
+      if (z + 1 < (unsigned)Z) { const float df = grid[i + C] - v; s[2] += fabsf(df); g -= sgnf(df) * gz; }
+      if (z > 0) { const float df = v - grid[i - C]; g += sgnf(df) * gz; }
+      if (d_grid) d_grid[i] = accumulate ? d_grid[i] + g : g;
+    }
   }
-  block_sum<3>(s, partial + (long long)blockIdx.x * 3);
+  block_sum<3>(s, partial + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 3);
 }
 
 __global__ __launch_bounds__(256) void tv_finalize_kernel(const double* __restrict__ partial,
@@ -231,7 +236,10 @@ __global__ __launch_bounds__(256) void tv_finalize_kernel(const double* __restri
   if (threadIdx.x == 0) *loss_out = (float)((tot[0] / cx + tot[1] / cy + tot[2] / cz) / 3.0);
 }
 
-size_t tv_scratch_bytes(int, int, int, int) { return sizeof(double) * (kRedBlocks * 3 + 8); }
+// (r03: 16384 blocks instead of 1024 -- with 47 dependent-latency iterations per thread the pass ran at 0.9 TB/s; the
+//  partial sums stay per block and are folded in a fixed order: the loss is bit-reproducible)
+constexpr int kTvBlocks = 16384;
+size_t tv_scratch_bytes(int, int, int, int) { return sizeof(double) * (kTvBlocks * 3 + 8); }
 
 void launch_tv(const float* grid, int X, int Y, int Z, int C, float grad_scale, float* loss_out,
                float* d_grid, int accumulate, void* scratch, hipStream_t st) {
@@ -242,9 +250,16 @@ void launch_tv(const float* grid, int X, int Y, int Z, int C, float grad_scale, 
   const float gy = cy > 0 ? (float)((double)grad_scale / (3.0 * cy)) : 0.f;
   const float gz = cz > 0 ? (float)((double)grad_scale / (3.0 * cz)) : 0.f;
   double* partial = (double*)scratch;
-  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
-  tv_kernel<<<nb, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
-  tv_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, cx, cy, cz, loss_out);
+  (void)n;
+  // at most kTvBlocks blocks (the scratch holds their partial sums): bx along a plane, by over the planes
+  const long long plane = (long long)Y * Z * C;
+  const int bx = (int)((plane + 255) / 256 < 128 ? (plane + 255) / 256 : 128);
+  const int by = X < kTvBlocks / bx ? X : kTvBlocks / bx;
+  const dim3 gridsz(bx, by);
+  if (C == 1) tv_kernel<1><<<gridsz, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
+  else if (C == 3) tv_kernel<3><<<gridsz, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
+  else tv_kernel<0><<<gridsz, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
+  tv_finalize_kernel<<<1, 256, 0, st>>>(partial, bx * by, cx, cy, cz, loss_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,15 +311,17 @@ __device__ __forceinline__ void up_axis(int out_i, int in_n, int out_n, int& i0,
   l0 = 1.0f - l1;
 }
 
+// Thread mapping like tv_kernel: blockIdx.y = output x-plane, the Y2 * Z2 * C elements of the plane (contiguous) over
+// blockIdx.x / threadIdx.x; 32-bit index arithmetic (64-bit div / mod chains kept this pass at 0.6 TB/s before, r03).
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ src, int X, int Y,
                                                        int Z, int C, float* __restrict__ dst, int X2,
                                                        int Y2, int Z2) {
-  const long long n = (long long)X2 * Y2 * Z2 * C;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int ch = (int)(i % C);
-  const long long vox = i / C;
-  const int z = (int)(vox % Z2), y = (int)((vox / Z2) % Y2), x = (int)(vox / ((long long)Z2 * Y2));
+  const unsigned sy2 = (unsigned)Z2 * (unsigned)C, plane2 = (unsigned)Y2 * sy2;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= plane2) return;
+  const int x = blockIdx.y;
+  const unsigned yq = e / sy2, zc = e - yq * sy2, zq = zc / (unsigned)C;
+  const int y = (int)yq, z = (int)zq, ch = (int)(zc - zq * (unsigned)C);
   int x0, x1, y0, y1, z0, z1;
   float lx0, lx1, ly0, ly1, lz0, lz1;
   up_axis(x, X, X2, x0, x1, lx0, lx1);
@@ -315,13 +332,13 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
                          ly1 * (lz0 * S(x0, y1, z0) + lz1 * S(x0, y1, z1))) +
                   lx1 * (ly0 * (lz0 * S(x1, y0, z0) + lz1 * S(x1, y0, z1)) +
                          ly1 * (lz0 * S(x1, y1, z0) + lz1 * S(x1, y1, z1)));
-  dst[i] = v;
+  dst[(long long)x * plane2 + e] = v;
 }
 
 void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, int X2, int Y2, int Z2,
                      hipStream_t st) {
-  const long long n = (long long)X2 * Y2 * Z2 * C;
-  upsample_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
+  const long long plane2 = (long long)Y2 * Z2 * C;
+  upsample_kernel<<<dim3((unsigned)((plane2 + 255) / 256), (unsigned)X2), 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
 }
 
 // ------------------------------------------------------------------------------------------------

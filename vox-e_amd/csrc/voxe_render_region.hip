@@ -17,8 +17,9 @@
 //                             lanes = segments, trilinear gathers come from LDS; every segment composites with a LOCAL
 //                             transmittance starting at 1 (compositing is associative: the depth-segmented forward of
 //                             voxe_render.hip does the same with fixed 32-sample segments);
-//   4. region_combine_kernel  one lane per ray folds its segments front to back -> colour / depth / acc / disparity, and
-//                             leaves the state BEFORE every segment for the backward;
+//   4. region_fold_kernel     one thread per (ray, depth segment) folds that lane's segments, the lanes of a ray meet in LDS
+//                             -> colour / depth / acc / disparity, and for every segment the transmittance in front of
+//                             it and the SUFFIX sums behind it (Horner, back to front) for the backward;
 //   5. region_bwd_kernel      one block per region again: texels in LDS, lanes = segments starting from their saved
 //                             state; the 8 corners x C channels of every sample go into a 9x9x9-voxel LDS window of
 //                             doubles (ds_add_f64, as in the tile kernel); ONE dense flush per region.
@@ -73,6 +74,8 @@ constexpr unsigned kRegionMask = 0x00FFFFFFu;   // slot_region = region | class 
 
 __host__ __device__ inline int regions_along(int N, int edge) { return ((N > 1 ? N - 1 : 1) + edge - 1) / edge; }
 
+// Slot numbering: slot j of lane L is slot_of(L, j) = j * nlanes + L (j-major: threads that walk the lanes -- fill, fold --
+// touch consecutive records; the region kernels scatter / gather by slot id).
 struct BinScratch {
   unsigned* slot_region;  // [nslots] region | length class << 24 of every USED segment slot (region nreg: the generic bin);
                           // slot j of a lane is used iff j < lane_n
@@ -80,21 +83,15 @@ struct BinScratch {
   uint2* slot_seg;        // [nslots] (ray, k0 | k1 << 16)
   uint4* sorted;          // [nslots] (ray, k0 | k1 << 16, slot, -) grouped by region
   float4* part;           // [nslots][2] by SLOT: forward partials of the segment (Tseg, csum[0..2] | asum, dsum)
-  float4* state;          // [nslots][2] by SLOT: compositing state BEFORE the segment (T, csum[0..2] | asum, dsum) -- the
-                          // folds walk a lane's slots contiguously; the region kernels scatter / gather by slot
+  float4* state;          // [nslots][2] by SLOT, for the backward: (T in front of the segment, U_c[0..2] | U_a, U_d) with U
+                          // the suffix sums of (csum, asum, dsum) from the segment's first sample on, RELATIVE to T
   unsigned* lane_n;       // [R * nseg] segments of every (ray, depth segment) lane
-  float4* dpart;          // [R * nseg][2] fold of a lane's segments (local transmittance / partial sums)
   unsigned* count;        // [(nreg + 1) * 4 + 1] segments per (region, length class) (+ generic bin; last entry stays 0)
   unsigned* start;        // [(nreg + 1) * 4 + 1] exclusive scan of `count`: first position in `sorted`; a region's segments are
                           // start[region * 4] .. start[(region + 1) * 4]
 };
 
-// index of slot (lane, j) in `part` / `state`: j-major, so that the folds -- one thread per lane walking j = 0, 1, ... -- read
-// and write contiguous records across neighbouring threads (lane-major records are 512 bytes apart: 4x the traffic)
-__device__ __forceinline__ size_t fold_index(size_t lane, unsigned j, long long nlanes) { return (size_t)j * (size_t)nlanes + lane; }
-__device__ __forceinline__ size_t fold_index_of_slot(unsigned slot, long long nlanes) {
-  return fold_index(slot / kSlotsPerLane, slot % kSlotsPerLane, nlanes);
-}
+__device__ __forceinline__ size_t slot_of(size_t lane, unsigned j, long long nlanes) { return (size_t)j * (size_t)nlanes + lane; }
 
 // ---- ray context of a segment lane: origin, direction, depth generator (no sample range, no SH basis) ----------------------
 struct SegRay {
@@ -138,18 +135,19 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
   rc.init(g, c, r, rays_o, rays_d, jitter);
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
   const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
-  if (k_lo > k_hi) return;
+  const long long nlanes = c.R * nseg, lane_id = r * nseg + seg;
+  if (k_lo > k_hi) { bs.lane_n[lane_id] = 0u; return; }   // (every lane writes its count: no memset of the table)
   const int nry = regions_along(g.Y, kRBY), nrz = regions_along(g.Z, kRBZ);
-  const long long slot0 = (r * nseg + seg) * kSlotsPerLane;
   int nslots = 0;
   unsigned cur = kNoRegion;
   int k0 = 0, k_prev = 0;
   auto emit = [&](int k_end) {
     if (cur == kNoRegion) return;
     const unsigned cls = (unsigned)len_class(k_end - k0 + 1);
-    bs.slot_region[slot0 + nslots] = cur | (cls << 24);
-    bs.slot_seg[slot0 + nslots] = make_uint2((unsigned)r, (unsigned)k0 | ((unsigned)k_end << 16));
-    bs.slot_pos[slot0 + nslots] = atomicAdd(bs.count + cur * kLenClasses + cls, 1u);   // rank inside (region, class)
+    const size_t sl = slot_of((size_t)lane_id, (unsigned)nslots, nlanes);
+    bs.slot_region[sl] = cur | (cls << 24);
+    bs.slot_seg[sl] = make_uint2((unsigned)r, (unsigned)k0 | ((unsigned)k_end << 16));
+    bs.slot_pos[sl] = atomicAdd(bs.count + cur * kLenClasses + cls, 1u);   // rank inside (region, class)
     ++nslots;
   };
   for (int k = k_lo; k <= k_hi; ++k) {
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     k_prev = k;
   }
   emit(k_prev);
-  bs.lane_n[r * nseg + seg] = (unsigned)nslots;
+  bs.lane_n[lane_id] = (unsigned)nslots;
 }
 
 // ---- pass 2: counting sort of the segments by region ---------------------------------------------------------------------
@@ -218,14 +216,18 @@ __global__ __launch_bounds__(1024) void region_scan_kernel(const unsigned* __res
   }
 }
 
-__global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long long nslots) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nslots) return;
-  if ((unsigned)(i % kSlotsPerLane) >= bs.lane_n[i / kSlotsPerLane]) return;   // unused slot
-  const unsigned rc = bs.slot_region[i];
-  const unsigned pos = bs.start[(rc & kRegionMask) * kLenClasses + (rc >> 24)] + bs.slot_pos[i];
-  const uint2 sg = bs.slot_seg[i];
-  bs.sorted[pos] = make_uint4(sg.x, sg.y, (unsigned)i, 0u);
+__global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long long nlanes) {
+  // one thread per (ray, depth segment) lane: its USED slots only (mean ~4 of 16)
+  const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (lane >= nlanes) return;
+  const unsigned n = bs.lane_n[lane];
+  for (unsigned j = 0; j < n; ++j) {
+    const size_t sl = slot_of((size_t)lane, j, nlanes);
+    const unsigned rc = bs.slot_region[sl];
+    const unsigned pos = bs.start[(rc & kRegionMask) * kLenClasses + (rc >> 24)] + bs.slot_pos[sl];
+    const uint2 sg = bs.slot_seg[sl];
+    bs.sorted[pos] = make_uint4(sg.x, sg.y, (unsigned)sl, 0u);
+  }
 }
 
 // ---- the region's texels in LDS ----------------------------------------------------------------------------------------------
@@ -360,81 +362,102 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
       asum = asum + w;
       dsum = fmaf(z, w, dsum);
     }
-    const size_t pi = fold_index_of_slot(rec.z, c.R * num_segments(c.S, c.seg_len));
+    const size_t pi = rec.z;
     bs.part[2 * pi] = make_float4(T, csum[0], csum[1], csum[2]);
     bs.part[2 * pi + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
   }
 }
 
-// ---- pass 4: fold the segments of every ray front to back (two levels: inside a depth-segment lane, then across lanes) ----
-// level 1, one thread per (ray, depth segment): fold the lane's <= 16 segments with a transmittance starting at 1; leaves the
-// state before every segment RELATIVE to the lane start and the lane's own fold in dpart.
-__global__ __launch_bounds__(256) void region_fold_lane_kernel(DevCfg c, BinScratch bs) {
-  const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int nseg = num_segments(c.S, c.seg_len);
-  if (lane >= c.R * nseg) return;
-  const unsigned n = bs.lane_n[lane];
-  float cs[3] = {0.0f, 0.0f, 0.0f};
-  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
-  for (unsigned j = 0; j < n; ++j) {
-    const size_t pos = fold_index((size_t)lane, j, c.R * nseg);
-    bs.state[2 * pos] = make_float4(T, cs[0], cs[1], cs[2]);
-    bs.state[2 * pos + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
-    const float4 a = bs.part[2 * pos], b = bs.part[2 * pos + 1];
-    cs[0] = fmaf(T, a.y, cs[0]);
-    cs[1] = fmaf(T, a.z, cs[1]);
-    cs[2] = fmaf(T, a.w, cs[2]);
-    asum = fmaf(T, b.x, asum);
-    dsum = fmaf(T, b.y, dsum);
-    T = T * a.x;
-  }
-  bs.dpart[2 * lane] = make_float4(T, cs[0], cs[1], cs[2]);
-  bs.dpart[2 * lane + 1] = make_float4(asum, dsum, 0.0f, 0.0f);
-}
-
-// level 2, one thread per (ray, depth segment) again: the state before the lane = fold of the ray's earlier lanes; the
-// lane's segment states become absolute; the thread of the LAST depth segment also folds its own lane and writes the outputs
+// ---- pass 4: fold -----------------------------------------------------------------------------------------------------------
+// One thread per (ray, depth segment) lane; the nseg lanes of a ray are consecutive threads of one block and meet in LDS.
+// Compositing is a Horner scheme read back to front: with (T_j, P_j) the transmittance and partial sums of segment j,
+//   U_j = P_j + T_j * U_{j+1}            (sums of everything from segment j on, RELATIVE to the transmittance in front of j)
+// -- only products and sums of same-signed terms, small (far) contributions first.  The backward needs exactly this suffix
+// (sum_{i >= segment} dL/dw_i w_i = T * <g, U>); the r02 formulation took it as (whole ray) - (prefix), which loses the
+// samples deep inside a dense medium to cancellation.  U of a ray's first segment is its output.
+//   1. every lane loads its <= 16 segment partials ONCE (predicated, all loads in flight), Horner over them with
+//      U_end = 0 -> the lane's own (T_lane, U_lane) into LDS;
+//   2. back to front over the ray's later lanes (LDS): U behind the lane; front to back over the earlier ones: T in front;
+//   3. per segment: T in front of it (running product) and U_j = U_j(own) + (prod_{i >= j} T_i) * U_behind  -> `state`.
 template <int COUT>
-__global__ __launch_bounds__(256) void region_combine_kernel(DevCfg c, BinScratch bs, float* __restrict__ colour,
-                                                             float* __restrict__ depth, float* __restrict__ acc,
-                                                             float* __restrict__ disparity) {
-  const long long lane = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch bs, float* __restrict__ colour,
+                                                          float* __restrict__ depth, float* __restrict__ acc,
+                                                          float* __restrict__ disparity, const int rays_per_block) {
+  __shared__ float lds[256 * 6];     // per lane: T_lane, U_lane c0 c1 c2 a d
   const int nseg = num_segments(c.S, c.seg_len);
-  if (lane >= c.R * nseg) return;
-  const long long r = lane / nseg;
-  const int s = (int)(lane - r * nseg);
-  const unsigned n = bs.lane_n[lane];
-  const bool is_last = s == nseg - 1;
-  if (n == 0 && !is_last) return;
-  float cs[3] = {0.0f, 0.0f, 0.0f};
-  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
-  for (int q = 0; q < s; ++q) {   // (transmittance-weighted fold of the earlier lanes: <= nseg - 1 reads of 32 B, contiguous per ray)
-    const float4 a = bs.dpart[2 * (r * nseg + q)], b = bs.dpart[2 * (r * nseg + q) + 1];
-    cs[0] = fmaf(T, a.y, cs[0]);
-    cs[1] = fmaf(T, a.z, cs[1]);
-    cs[2] = fmaf(T, a.w, cs[2]);
-    asum = fmaf(T, b.x, asum);
-    dsum = fmaf(T, b.y, dsum);
-    T = T * a.x;
+  const long long nlanes = c.R * nseg;
+  const int lr = threadIdx.x / nseg, s = threadIdx.x - lr * nseg;          // ray of the block, depth segment
+  const long long r = (long long)blockIdx.x * rays_per_block + lr;
+  const bool live = lr < rays_per_block && r < c.R;
+  const long long lane = live ? r * nseg + s : 0;
+  const unsigned n = live ? bs.lane_n[lane] : 0u;
+  float4 pa[kSlotsPerLane];
+  float2 pb[kSlotsPerLane];
+#pragma unroll
+  for (int j = 0; j < kSlotsPerLane; ++j) {
+    pa[j] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    pb[j] = make_float2(0.0f, 0.0f);
+    if ((unsigned)j < n) {
+      const size_t sl = slot_of((size_t)lane, (unsigned)j, nlanes);
+      pa[j] = bs.part[2 * sl];
+      const float4 t = bs.part[2 * sl + 1];
+      pb[j] = make_float2(t.x, t.y);
+    }
   }
-  for (unsigned j = 0; j < n; ++j) {
-    const size_t pos = fold_index((size_t)lane, j, c.R * nseg);
-    const float4 a = bs.state[2 * pos], b = bs.state[2 * pos + 1];   // relative to the lane start
-    bs.state[2 * pos] = make_float4(T * a.x, fmaf(T, a.y, cs[0]), fmaf(T, a.z, cs[1]), fmaf(T, a.w, cs[2]));
-    bs.state[2 * pos + 1] = make_float4(fmaf(T, b.x, asum), fmaf(T, b.y, dsum), 0.0f, 0.0f);
+  // own Horner, back to front (unused slots are the identity: T = 1, P = 0)
+  float Tl = 1.0f, U[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = kSlotsPerLane - 1; j >= 0; --j) {
+    U[0] = fmaf(pa[j].x, U[0], pa[j].y);
+    U[1] = fmaf(pa[j].x, U[1], pa[j].z);
+    U[2] = fmaf(pa[j].x, U[2], pa[j].w);
+    U[3] = fmaf(pa[j].x, U[3], pb[j].x);
+    U[4] = fmaf(pa[j].x, U[4], pb[j].y);
+    Tl = Tl * pa[j].x;
   }
-  if (!is_last) return;
+  float* me = lds + threadIdx.x * 6;
+  me[0] = Tl;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) me[1 + q] = U[q];
+  __syncthreads();
+  if (!live) return;
+  // behind the lane: Horner over the ray's later lanes, back to front
+  float B[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  for (int q = nseg - 1; q > s; --q) {
+    const float* o = lds + (threadIdx.x - s + q) * 6;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) B[t] = fmaf(o[0], B[t], o[1 + t]);
+  }
+  // in front of the lane: product of the earlier lanes' transmittances
+  float T = 1.0f;
+  for (int q = 0; q < s; ++q) T = T * lds[(threadIdx.x - s + q) * 6];
+  // per segment: state = (T in front, U from the segment on); U_j = own_j + (prod_{i >= j} T_i) * B, again back to front
+  float Tfront[kSlotsPerLane];
   {
-    const float4 a = bs.dpart[2 * lane], b = bs.dpart[2 * lane + 1];
-    cs[0] = fmaf(T, a.y, cs[0]);
-    cs[1] = fmaf(T, a.z, cs[1]);
-    cs[2] = fmaf(T, a.w, cs[2]);
-    asum = fmaf(T, b.x, asum);
-    dsum = fmaf(T, b.y, dsum);
+    float t = T;
+#pragma unroll
+    for (int j = 0; j < kSlotsPerLane; ++j) { Tfront[j] = t; t = t * pa[j].x; }
   }
+  float V[5] = {B[0], B[1], B[2], B[3], B[4]};
+#pragma unroll
+  for (int j = kSlotsPerLane - 1; j >= 0; --j) {
+    V[0] = fmaf(pa[j].x, V[0], pa[j].y);
+    V[1] = fmaf(pa[j].x, V[1], pa[j].z);
+    V[2] = fmaf(pa[j].x, V[2], pa[j].w);
+    V[3] = fmaf(pa[j].x, V[3], pb[j].x);
+    V[4] = fmaf(pa[j].x, V[4], pb[j].y);
+    if ((unsigned)j < n) {
+      const size_t sl = slot_of((size_t)lane, (unsigned)j, nlanes);
+      bs.state[2 * sl] = make_float4(Tfront[j], V[0], V[1], V[2]);
+      bs.state[2 * sl + 1] = make_float4(V[3], V[4], 0.0f, 0.0f);
+    }
+  }
+  if (s != 0) return;
+  // the ray's first lane holds the whole ray: V = (csum, asum, dsum)   (accumulate.py:77-88)
+  const float asum = V[3], dsum = V[4];
 #pragma unroll
   for (int ch = 0; ch < COUT; ++ch) {
-    float col = cs[ch];
+    float col = V[ch];
     if (c.white) {
       float bk = 1.0f - asum;
       if (c.attn) bk = bk * 0.0f;
@@ -484,29 +507,25 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
     const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
     SegRay ray;
     ray.init(g, c, r, rays_o, rays_d, jitter);
-    // state before the segment (region_combine_kernel) and the per-ray constants of the backward (render_bwd_kernel)
-    const size_t pi = fold_index_of_slot(rec.z, c.R * num_segments(c.S, c.seg_len));
+    // transmittance in front of the segment and the suffix sums from it on, relative to it (region_fold_kernel); the
+    // per-ray constants of the backward (render_bwd_kernel)
+    const size_t pi = rec.z;
     const float4 sa = bs.state[2 * pi], sb = bs.state[2 * pi + 1];
     float T = sa.x;
-    const float pre_c[3] = {sa.y, sa.z, sa.w};
-    const float pre_a = sb.x, pre_d = sb.y;
+    const float suf_c[3] = {sa.y, sa.z, sa.w};
+    const float suf_a = sb.x, suf_d = sb.y;
     float gc[COUT], gsum = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
     const float gdep = d_depth ? d_depth[r] : 0.0f;
     const float gacc = d_acc ? d_acc[r] : 0.0f;
-    const float asum = acc[r];
-    float total = gdep * depth[r] + gacc * asum;
+    // suffix0 = sum_{i >= first sample of the segment} dL/dw_i w_i = T * <upstream gradient, U>
+    float suffix0 = gdep * suf_d + gacc * suf_a;
 #pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) {
-      const float csum = white ? colour[r * COUT + ch] - (1.0f - asum) : colour[r * COUT + ch];
-      total += gc[ch] * csum;
-    }
-    if (white) total -= gsum * asum;
-    float prefix = gdep * pre_d + gacc * pre_a;
-#pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) prefix += gc[ch] * pre_c[ch];
-    if (white) prefix -= gsum * pre_a;
+    for (int ch = 0; ch < COUT; ++ch) suffix0 += gc[ch] * suf_c[ch];
+    if (white) suffix0 -= gsum * suf_a;
+    suffix0 *= T;
+    float run = 0.0f;   // sum of dL/dw_i w_i over the samples of this segment up to and including the current one
 
     float z_next = ray.dg.z(k0);
     for (int k = k0; k <= k1; ++k) {
@@ -543,8 +562,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
 #pragma unroll
       for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
       if (white) dldw -= gsum;
-      prefix = fmaf(dldw, wk, prefix);
-      const float suffix = last ? 0.0f : (total - prefix);
+      run = fmaf(dldw, wk, run);
+      const float suffix = last ? 0.0f : (suffix0 - run);
       const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
       const float dsig = (delta * e) * fmaf(T, dldw, -tail);
       float gch[C];
@@ -609,6 +628,7 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
   const long long min_rays = region_min_rays();
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
   if (!(c.attn || deg == 0 || diffuse)) return false;          // one channel group (SH-0 / diffuse / attention)
+  if (num_segments(c.S, c.seg_len) > 256) return false;       // (the lanes of a ray meet in one block's LDS: region_fold_kernel)
   if (c.R > (1ll << 19) || c.S >= 65536) return false;         // segment records hold 32-bit rays / 16-bit sample indices;
                                                                // the tables take ~12 KB per ray (S = 256): capped at 512 k rays (6 GB) per launch
   if (!tiled) return true;                                     // unordered rays, images below the tile threshold
@@ -622,7 +642,7 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
 }
 
 static inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
-struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, dpart, counters, total; long long nslots, nlanes; int nreg; };
+struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, total; long long nslots, nlanes; int nreg; };
 static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   RegionLayout l;
   const int nseg = num_segments(S, seg_len_for(R));
@@ -637,7 +657,6 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   l.part = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
   l.state = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
   l.lane_n = off; off += up256((size_t)l.nlanes * sizeof(unsigned));
-  l.dpart = off; off += up256((size_t)l.nlanes * 2 * sizeof(float4));
   l.counters = off; off += 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned));   // count | start
   l.total = off;
   return l;
@@ -656,7 +675,6 @@ static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
   bs.part = (float4*)(base + l.part);
   bs.state = (float4*)(base + l.state);
   bs.lane_n = (unsigned*)(base + l.lane_n);
-  bs.dpart = (float4*)(base + l.dpart);
   bs.count = (unsigned*)(base + l.counters);
   bs.start = bs.count + up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)) / sizeof(unsigned);
   return bs;
@@ -675,16 +693,16 @@ template <int COUT, int NCM>
 static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st) {
   const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
   const BinScratch bs = bin_scratch(l, scratch);
-  (void)hipMemsetAsync(bs.lane_n, 0, (size_t)l.nlanes * sizeof(unsigned), st);
   (void)hipMemsetAsync(bs.count, 0, 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)), st);
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * nseg;
   region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
-  region_fill_kernel<<<(int)((l.nslots + 255) / 256), 256, 0, st>>>(bs, l.nslots);
+  region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes);
   region_fwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
-  region_fold_lane_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs);
-  region_combine_kernel<COUT><<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(c, bs, a.colour, a.depth, a.acc, a.disparity);
+  const int rays_per_block = 256 / nseg;        // (nseg <= 256: region_bwd_supported)
+  region_fold_kernel<COUT><<<(int)((c.R + rays_per_block - 1) / rays_per_block), 256, 0, st>>>(
+      c, bs, a.colour, a.depth, a.acc, a.disparity, rays_per_block);
 }
 
 template <int COUT, int NCM>

@@ -27,6 +27,21 @@ FLAGS = [
 ]
 
 
+def source_hash() -> str:
+    """identity of the kernel sources: sha256 over vox-e_amd/csrc/* and include/voxe.h (names + contents), 16 hex digits.
+    Stamped into profiles/*_pmc_summary.json by tools/pmc_to_json.py and re-computed by bench.py, so that counter values
+    are only ever combined with timings of the kernels they were collected on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp")))
+    files.append(os.path.join(INCLUDE, "voxe.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
