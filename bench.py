@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--image", type=int, default=400)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--scene", choices=["random", "sphere"], default="random")
-    ap.add_argument("--term-eps", type=float, default=0.0, help="early ray termination (NOT in the reference); 0 = off")
+    ap.add_argument("--term-eps", type=float, default=0.0, help="gradient truncation (NOT in the reference): the backward stops a ray once T < eps; the forward is always exact; 0 = off")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra 100x100 measurement of the default run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,

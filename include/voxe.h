@@ -83,8 +83,11 @@ typedef struct VoxeRenderCfg {
   int32_t white_bkgd;         /* accumulate.py:77-81 (for VOXE_FEAT_ATTN the term is *0.0, :166)  */
   int32_t sh_degree;          /* 0..3 ; F == 3*(sh_degree+1)^2 for VOXE_FEAT_SH                   */
   int32_t render_diffuse;     /* use only the degree-0 coefficient (process.py:59-63)             */
-  float term_eps;             /* 0 = integrate all S samples exactly like the reference;
-                                 >0 = stop a ray once transmittance < term_eps (NOT in reference) */
+  float term_eps;             /* gradient truncation (NOT in the reference; 0 = off).  The forward always integrates all S
+                                 samples exactly like the reference; with term_eps > 0 the BACKWARD stops marching a ray once
+                                 its transmittance is below term_eps: samples behind that point get no gradient (their
+                                 contributions scale with T < term_eps), the samples in front keep their EXACT gradient
+                                 (the suffix sums come from the full forward).  -20 % backward time on surface-like scenes. */
   uint64_t seed, rng_offset;  /* in-kernel jitter stream                                          */
   int32_t reuse_packed_grid;  /* 1: workspace already holds this grid packed by a previous call
                                  on the same workspace (grid values unchanged)                    */
@@ -318,6 +321,46 @@ int voxe_render_route(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_
  *   d_*_in may be NULL (= 0); the outputs may alias the inputs.                                                       */
 int voxe_disparity_bwd(const float* depth, const float* acc, const float* d_disparity, const float* d_depth_in,
                        const float* d_acc_in, float* d_depth_out, float* d_acc_out, int64_t R, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One iteration of the reconstruction loop in ONE call   modules/trainers.py:288-351
+ *   (cast the rays of a random pixel batch over K cached cameras -> render specular [-> render diffuse] -> L1 loss(es)
+ *   against the target pixels -> backward -> Adam): the same kernels the separate entry points launch, enqueued back to
+ *   back on `stream` with no host work in between -- at 32768 rays the host side of ~45 framework-level launches was
+ *   one third of the iteration.
+ *   batch   : voxe_random_subset(K*H*W, batch, cfg->seed, cfg->rng_offset) picks flat (camera, y, x) pixels (a uniformly
+ *             random set of distinct pixels, like the reference's randperm subset); rays by voxe_cast_rays_indexed; target
+ *             pixels gathered from images [N,3,H,W] (row image_rows[camera], or camera itself when image_rows == NULL);
+ *   renders : cfg as given with the jitter stream (seed, rng_offset + 1) for the specular render and, when
+ *             diffuse_regularisation != 0, a second render with render_diffuse = 1 and the stream (seed, rng_offset + 2)
+ *             (trainers.py:316,333); each runs in its own workspace (per-ray states), both gradients sum into the FIRST
+ *             workspace's gradient region (voxe_render_bwd_acc_into);
+ *   loss    : mean |colour - target| per render (torch.nn.functional.l1_loss), summed; losses[0..3] (DEVICE floats) receive
+ *             L1 specular, MSE specular (the trainer logs it as PSNR), L1 diffuse, MSE diffuse;
+ *   update  : voxe_grid_adam_step over the whole grid with the given Adam state / hyper-parameters; afterwards
+ *             `workspace` holds the updated grid packed (pass cfg->reuse_packed_grid = 1 next time) and a cleared gradient.
+ *   scratch : voxe_recon_scratch_bytes(batch) bytes of device memory (rays, targets, outputs, upstream gradients).
+ *   Requires an SH grid (3 colour channels).  Arithmetic identical to the composition of the separate calls.        */
+typedef struct {
+  int32_t H, W;
+  float focal;
+  const float* poses;           /* [K,3,4] camera-to-world (rotation | translation), device                    */
+  const int64_t* image_rows;    /* [K] rows of `images` of the K cameras, device; NULL = 0 .. K-1              */
+  const float* images;          /* [N,3,H,W] device                                                            */
+  int32_t K;
+  int64_t batch;                /* rays per iteration                                                          */
+  int32_t diffuse_regularisation;
+  float lr, beta1, beta2, eps;
+  int64_t step_densities, step_features;   /* 1-based Adam steps (torch counts per parameter)                  */
+  float *exp_avg_densities, *exp_avg_sq_densities, *exp_avg_features, *exp_avg_sq_features;
+  float* losses;                /* [4] device                                                                  */
+  int32_t zero_gradient_first;  /* != 0: clear the gradient region of `workspace` first (a workspace no fused step has
+                                   left cleared yet)                                                           */
+} VoxeReconStep;
+size_t voxe_recon_scratch_bytes(int64_t batch);
+int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* step,
+                    void* workspace, size_t workspace_bytes, void* workspace2, size_t workspace2_bytes,
+                    void* scratch, size_t scratch_bytes, void* stream);
 
 /* Measurement aids (bench.py, tests): not part of the reference's interface.
  * voxe_clock_probe        sustained shader clock in Hz: a chip-filling VALU + LDS kernel on `stream` reads the shader-clock

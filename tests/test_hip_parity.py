@@ -361,28 +361,24 @@ def test_tile_backward_attention_grid():
     assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4
 
 
-def test_early_termination_is_consistent():
-    """term_eps > 0 (not in the reference): the forward changes by < term_eps-ish, and the backward is the exact
-    gradient of THAT forward (directional finite differences)."""
+def test_gradient_truncation_leaves_the_forward_exact():
+    """term_eps > 0 (not in the reference; r03 semantics): the forward is unchanged bit for bit, the backward stops marching
+    a ray once its transmittance is below term_eps -- the gradient moves by O(term_eps), no more"""
     g = load_golden("frames32.npz")
     grid = grid_from_golden(g, "", "softplus")
     o, d = vo.cast_rays(40, 40, 0.5 * 40 / np.tan(0.5 * 0.6911112), g["rot"][3], g["trans"][3])
     cfg = cfg_from_bounds(g["bounds"], 128, white_bkgd=True)
-    full = gh.hip_forward(grid, cfg, o, d, image_width=40)["colour"]
-    cut = gh.hip_forward(grid, cfg, o, d, image_width=40, term_eps=1e-3)["colour"]
-    assert 0 < np.abs(full - cut).max() < 2e-3
-    gc = np.random.default_rng(7).standard_normal(full.shape).astype(np.float32)
-    _, gf = gh.hip_backward(grid, cfg, o, d, gc, image_width=40, term_eps=1e-3)
-    v = np.random.default_rng(8).standard_normal(grid.features.shape).astype(np.float32)
-    eps = 1e-2
-
-    def loss(feat):
-        gg = vo.Grid(grid.densities, feat, grid.aabb, grid.density_scale, grid.density_pre_act, grid.density_post_act)
-        return float(np.sum(gh.hip_forward(gg, cfg, o, d, image_width=40, term_eps=1e-3)["colour"].astype(np.float64) * gc))
-
-    fd = (loss(grid.features + eps * v) - loss(grid.features - eps * v)) / (2 * eps)
-    an = float(np.sum(gf.astype(np.float64) * v))
-    assert abs(fd - an) <= 3e-2 * max(abs(an), 1.0), (fd, an)
+    full = gh.hip_forward(grid, cfg, o, d, image_width=40)
+    cut = gh.hip_forward(grid, cfg, o, d, image_width=40, term_eps=1e-3)
+    for key in ("colour", "depth", "acc"):
+        np.testing.assert_array_equal(full[key], cut[key])
+    gc = np.random.default_rng(7).standard_normal(full["colour"].shape).astype(np.float32)
+    for over in (dict(image_width=40), {}):           # LDS-window backward / line-dense scatter
+        gd0, gf0 = gh.hip_backward(grid, cfg, o, d, gc, **over)
+        gd1, gf1 = gh.hip_backward(grid, cfg, o, d, gc, term_eps=1e-3, **over)
+        assert 0 < rel_l2(gf1, gf0) < 5e-3 and 0 < rel_l2(gd1, gd0) < 5e-3, (rel_l2(gf1, gf0), rel_l2(gd1, gd0))
+        gd2, gf2 = gh.hip_backward(grid, cfg, o, d, gc, term_eps=1e-6, **over)
+        assert rel_l2(gf2, gf0) < 2e-5 and rel_l2(gd2, gd0) < 2e-5
 
 
 @pytest.mark.parametrize("dims", [(2, 2, 2), (1, 4, 3), (3, 1, 1), (1, 1, 1), (2, 9, 5)])

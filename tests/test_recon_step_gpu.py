@@ -1,0 +1,125 @@
+"""voxe_recon_step (one reconstruction iteration in one library call) against the same iteration composed from the separate
+entry points with the same random streams: batch selection, both renders, L1 losses, backward, Adam."""
+import numpy as np
+import pytest
+import torch
+
+from synth import FAR, NEAR, RADIUS, focal_for, random_grid, synth_pose_angles
+from voxe_hip import abi
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+    from voxe_hip import ops
+
+    DEV = torch.device("cuda:0")
+
+
+def _setup(side, hw, nviews):
+    dens, feat = random_grid(side)
+    poses = []
+    for i in range(nviews):
+        p = pose_spherical(*synth_pose_angles(i, nviews), RADIUS)
+        poses.append(torch.cat([p.rotation, p.translation], dim=-1))
+    poses = torch.stack(poses).to(DEV).contiguous()
+    images = torch.rand(nviews, 3, hw, hw, generator=torch.Generator().manual_seed(1)).to(DEV)
+    spec = ops.GridSpec(aabb=((-1.5, 1.5),) * 3, density_scale=3.0, density_pre_act=abi.ACT_IDENTITY,
+                        density_post_act=abi.ACT_SOFTPLUS)
+    params = ops.RenderParams(num_samples=64, near=NEAR, far=FAR, perturb=True, white_bkgd=True)
+    return dens.to(DEV), feat.to(DEV), poses, images, spec, params
+
+
+@pytest.mark.parametrize("batch,diffuse", [(20000, True), (3000, True), (20000, False)])
+def test_recon_step_equals_the_composed_iteration(batch, diffuse):
+    """20000 rays take the space-binned route, 3000 the ray-ordered scatter: both inside the one call"""
+    side, hw, K = 48, 64, 6
+    dens0, feat0, poses, images, spec, params = _setup(side, hw, K)
+    rows = torch.tensor([4, 1, 5, 0, 2, 3], device=DEV)
+    lr, steps = 2e-2, 3
+    # ---- composed from the separate entry points (autograd + torch.optim.Adam arithmetic through VoxeAdam's kernel)
+    d_a, f_a = dens0.clone().requires_grad_(True), feat0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([d_a, f_a], lr=lr, betas=(0.9, 0.999))
+    ws = ops.Workspace()
+    ref_losses = []
+    for it in range(steps):
+        seed, off = 11, 1000 * it
+        subset = ops.random_subset(K * hw * hw, batch, DEV, rng=(seed, off))
+        o, d = ops.cast_rays_indexed(hw, hw, focal_for(hw), poses, subset)
+        cam = subset // (hw * hw)
+        rem = subset - cam * hw * hw
+        target = images[rows[cam], :, rem // hw, rem % hw]
+        opt.zero_grad()
+        c1 = ops.render(spec, params, d_a, f_a, o, d, workspace=ws, rng=(seed, off + 1))[0]
+        loss = torch.nn.functional.l1_loss(c1, target)
+        mse = torch.nn.functional.mse_loss(c1.detach(), target)
+        l1d = torch.zeros(())
+        if diffuse:
+            import dataclasses
+
+            c2 = ops.render(spec, dataclasses.replace(params, render_diffuse=True), d_a, f_a, o, d, workspace=ws, rng=(seed, off + 2))[0]
+            l1d = torch.nn.functional.l1_loss(c2, target)
+            loss = loss + l1d
+        ref_losses.append((float(loss - l1d), float(mse), float(l1d)))
+        loss.backward()
+        opt.step()
+    # ---- the one call
+    d_b, f_b = dens0.clone(), feat0.clone()
+    st_d = (torch.zeros_like(d_b), torch.zeros_like(d_b))
+    st_f = (torch.zeros_like(f_b), torch.zeros_like(f_b))
+    wa, wb = ops.Workspace(), ops.Workspace()
+    losses = torch.zeros(4, device=DEV)
+    for it in range(steps):
+        ops.recon_step_(spec, params, d_b, f_b, wa, wb, hw, hw, focal_for(hw), poses, rows, images,
+                        batch, diffuse, st_d, st_f, it + 1, it + 1, lr, losses, (11, 1000 * it), zero_gradient_first=(it == 0))
+        got = losses.tolist()
+        assert abs(got[0] - ref_losses[it][0]) < 2e-6 * max(1.0, abs(ref_losses[it][0])) + 2e-6, (it, got, ref_losses[it])
+        assert abs(got[1] - ref_losses[it][1]) < 1e-5, (it, got, ref_losses[it])
+        if diffuse:
+            assert abs(got[2] - ref_losses[it][2]) < 2e-6 + 2e-6 * abs(ref_losses[it][2]), (it, got, ref_losses[it])
+    torch.cuda.synchronize()
+    moved = float((d_a.detach() - dens0).abs().max())
+    assert moved > 1e-3
+    # Adam's first steps turn the rounding noise of near-zero gradients (float atomics) into +-lr moves: measure against the
+    # movement, like the two-rank tests
+    for a, b in ((d_a.detach(), d_b), (f_a.detach(), f_b)):
+        rel = float(torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(a - (dens0 if a.shape[-1] == 1 else feat0)))
+        assert rel < 0.05, rel
+    # the first iteration alone is deterministic up to float rounding of the gradient sums: |update| = lr for every voxel a
+    # ray touched, so both runs must agree on WHICH voxels moved
+    assert float(((d_a.detach() - dens0).abs() > 0).float().mean()) > 0.05
+
+
+def test_fused_grid_adam_reconstruction_step_drives_the_trainer_state():
+    """the optimiser-level wrapper: step counters, learning rate and Adam state are the optimiser's"""
+    from thre3d_atom.modules.optim import FusedGridAdam
+    from thre3d_atom.modules.volumetric_model import VolumetricModel
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, _render_params, render_sh_voxel_grid
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelSize
+    from thre3d_atom.utils.imaging_utils import CameraBounds
+
+    side, hw, K = 32, 48, 4
+    dens, feat, poses, images, _, _ = _setup(side, hw, K)
+    vg = VoxelGrid(dens.cpu(), feat.cpu(), VoxelSize(3.0 / side, 3.0 / side, 3.0 / side), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=3.0, tunable=True)
+    model = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(48, CameraBounds(NEAR, FAR), white_bkgd=True), device=DEV)
+    grid = model.thre3d_repr
+    before = grid.densities.detach().clone()
+    losses = torch.zeros(4, device=DEV)
+    params = _render_params(grid, None, model.render_config, attn=False)
+    with FusedGridAdam(grid, lr=1e-2) as opt:
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.5)
+        first = None
+        for it in range(6):
+            opt.reconstruction_step(params, hw, hw, focal_for(hw), poses, None, images, 4096, True, losses, (5, 100 * it))
+            if it == 2:
+                sched.step()
+            if first is None:
+                first = losses.tolist()
+        assert opt.state[grid.densities]["step"] == 6 and opt.state[grid.features]["step"] == 6
+        assert abs(opt.param_groups[0]["lr"] - 5e-3) < 1e-9
+        last = losses.tolist()
+    assert last[0] + last[2] < first[0] + first[2]                       # the loss went down
+    assert float((grid.densities.detach() - before).abs().max()) > 1e-3
+    # ordinary renders work again afterwards (the mode ended with the context manager)
+    assert grid.voxe_workspace("sh").deferred is None

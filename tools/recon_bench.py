@@ -1,6 +1,7 @@
 """Per-iteration time of the reconstruction trainer's inner loop at BASELINE.json configs[1] scale: 160^3 SH-0
 softplus field, 100 views @ 400x400 (synthetic images), 32768 random rays over 8 cached images per iteration,
-specular + diffuse L1, fused Adam.   gpurun -- python tools/recon_bench.py [iters]"""
+specular + diffuse L1, fused Adam.   gpurun -- python tools/recon_bench.py [iters]
+RECON_PYTHON_ITER=1: the iteration composed in Python from the separate ops (r02) instead of voxe_recon_step."""
 import os
 import sys
 import time
@@ -53,8 +54,20 @@ def main():
         marks[name] = marks.get(name, 0.0) + (time.perf_counter() - t0)
         return time.perf_counter()
 
+    one_call = not os.environ.get("RECON_PYTHON_ITER") and isinstance(opt, FusedGridAdam)
+    losses = torch.zeros(4, device=dev)
+    from thre3d_atom.thre3d_reprs.renderers import _render_params
+    rparams = _render_params(vm.thre3d_repr, None, vm.render_config, attn=False)
+
     def iteration(profile):
         t = time.perf_counter()
+        if one_call:   # what the trainer runs: the whole iteration as ONE library call (voxe_recon_step)
+            picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
+            opt.reconstruction_step(rparams, HW, HW, focal_for(HW), poses[picks].contiguous(), picks, images, B, True, losses,
+                                    ops._next_rng())
+            if profile:
+                mark("whole iteration (one library call)", t)
+            return
         if not os.environ.get("RECON_OLD_BATCH") and not os.environ.get("RECON_SORT"):
             picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
             rays_b, pix_b = sample_random_rays_and_pixels_from_cameras(intr, poses[picks], images, B, image_ids=picks,

@@ -481,6 +481,83 @@ int voxe_disparity_bwd(const float* depth, const float* acc, const float* d_disp
   return finish();
 }
 
+namespace {
+inline size_t up256b(size_t x) { return (x + 255) / 256 * 256; }
+struct ReconLayout { size_t subset, rays_o, rays_d, target, out[2], d_colour[2], partial, total; };
+ReconLayout recon_layout(int64_t B) {
+  ReconLayout l;
+  size_t off = 0;
+  const size_t b = (size_t)(B > 0 ? B : 0);
+  l.subset = off; off += up256b(b * sizeof(int64_t));
+  l.rays_o = off; off += up256b(b * 3 * sizeof(float));
+  l.rays_d = off; off += up256b(b * 3 * sizeof(float));
+  l.target = off; off += up256b(b * 3 * sizeof(float));
+  for (int i = 0; i < 2; ++i) { l.out[i] = off; off += up256b(b * 5 * sizeof(float)); }        // colour [B,3] | depth [B] | acc [B]
+  for (int i = 0; i < 2; ++i) { l.d_colour[i] = off; off += up256b(b * 3 * sizeof(float)); }
+  l.partial = off; off += up256b(l1_scratch_bytes());
+  l.total = off;
+  return l;
+}
+}  // namespace
+
+size_t voxe_recon_scratch_bytes(int64_t batch) { return batch > 0 ? recon_layout(batch).total : 0; }
+
+int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* rs, void* workspace,
+                    size_t workspace_bytes, void* workspace2, size_t workspace2_bytes, void* scratch, size_t scratch_bytes,
+                    void* stream) {
+  if (!grid || !cfg || !rs || !rs->poses || !rs->images || !rs->losses) return VOXE_ERR_NULL_POINTER;
+  if (grid->feature_kind != VOXE_FEAT_SH) return VOXE_ERR_UNSUPPORTED;
+  if (rs->H <= 0 || rs->W <= 0 || rs->K <= 0 || rs->batch <= 0 || rs->batch > (int64_t)rs->K * rs->H * rs->W)
+    return VOXE_ERR_BAD_SHAPE;
+  if (cfg->image_width != 0 || cfg->deterministic) return VOXE_ERR_UNSUPPORTED;   // a random batch has no image order
+  const int nrender = rs->diffuse_regularisation ? 2 : 1;
+  if (nrender == 2 && !workspace2) return VOXE_ERR_WORKSPACE;
+  const ReconLayout l = recon_layout(rs->batch);
+  if (!scratch || scratch_bytes < l.total) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char* sc = (char*)scratch;
+  const int64_t B = rs->batch;
+  int64_t* subset = (int64_t*)(sc + l.subset);
+  float* rays_o = (float*)(sc + l.rays_o);
+  float* rays_d = (float*)(sc + l.rays_d);
+  float* target = (float*)(sc + l.target);
+  int st = voxe_random_subset((int64_t)rs->K * rs->H * rs->W, B, cfg->seed, cfg->rng_offset, subset, stream);
+  if (st) return st;
+  st = voxe_cast_rays_indexed(rs->H, rs->W, rs->focal, rs->poses, rs->K, subset, B, rays_o, rays_d, stream);
+  if (st) return st;
+  launch_gather_pixels(rs->images, (const long long*)rs->image_rows, (const long long*)subset, B, rs->H * rs->W, target, s);
+  VoxeRenderCfg rc[2] = {*cfg, *cfg};
+  void* ws[2] = {workspace, workspace2};
+  size_t wsb[2] = {workspace_bytes, workspace2_bytes};
+  for (int i = 0; i < nrender; ++i) {
+    rc[i].rng_offset = cfg->rng_offset + 1 + (uint64_t)i;
+    rc[i].render_diffuse = i == 1 ? 1 : cfg->render_diffuse;
+    rc[i].linear_grad = 1;                         // both renders write ONE gradient layout, whatever kernel runs
+    if (i == 1) rc[i].reuse_packed_grid = 0;       // the second workspace still holds the previous iteration's grid
+    float* colour = (float*)(sc + l.out[i]);
+    float *depth = colour + 3 * B, *acc = depth + B;
+    st = voxe_render_fwd(grid, &rc[i], rays_o, rays_d, B, nullptr, colour, depth, acc, nullptr, ws[i], wsb[i], stream);
+    if (st) return st;
+    launch_l1_loss_grad(colour, target, 3 * B, (float*)(sc + l.d_colour[i]), rs->losses + 2 * i, sc + l.partial, s);
+  }
+  for (int i = 0; i < nrender; ++i) {
+    float* colour = (float*)(sc + l.out[i]);
+    float *depth = colour + 3 * B, *acc = depth + B;
+    rc[i].ray_state_valid = 1;                     // the forward above left this render's states in ws[i]
+    rc[i].reuse_packed_grid = 1;
+    int32_t layout = VOXE_GRAD_ANY;
+    st = voxe_render_bwd_acc_into(grid, &rc[i], rays_o, rays_d, B, nullptr, colour, depth, acc, (const float*)(sc + l.d_colour[i]),
+                                  nullptr, nullptr, rs->exp_avg_densities != nullptr, rs->exp_avg_features != nullptr,
+                                  /*zero_first=*/(i == 0 && rs->zero_gradient_first) ? 1 : 0, &layout, ws[i], wsb[i], i == 0 ? nullptr : workspace,
+                                  i == 0 ? 0 : workspace_bytes, stream);
+    if (st) return st;
+    if (layout != VOXE_GRAD_LINEAR) return VOXE_ERR_UNSUPPORTED;
+  }
+  return voxe_grid_adam_step(grid, VOXE_GRAD_LINEAR, 0, grid->X, nullptr, nullptr, rs->exp_avg_densities,
+                             rs->exp_avg_sq_densities, rs->exp_avg_features, rs->exp_avg_sq_features, rs->lr, rs->beta1,
+                             rs->beta2, rs->eps, rs->step_densities, rs->step_features, workspace, workspace_bytes, stream);
+}
+
 int voxe_clock_probe(int32_t spin, double* shader_hz, void* stream) {
   if (!shader_hz) return VOXE_ERR_NULL_POINTER;
   *shader_hz = run_clock_probe(spin, (hipStream_t)stream);

@@ -373,6 +373,62 @@ void launch_disparity_bwd(const float* depth, const float* acc, const float* d_d
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pieces of the fused reconstruction iteration (voxe_recon_step; modules/trainers.py:288-351): target pixels of a random
+// batch gathered straight from the image stack, and torch.nn.functional.l1_loss (+ its gradient, + the MSE the trainer
+// logs as PSNR) in one pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_pixels_kernel(const float* __restrict__ images, const long long* __restrict__ image_rows,
+                                                            const long long* __restrict__ subset, long long B, int per,
+                                                            float* __restrict__ out) {
+  // images [N, 3, H, W]; subset: flat (camera, y, x) indices over the K cached cameras; out [B, 3]
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const long long f = subset[i];
+  const long long cam = f / per, rem = f - cam * per;
+  const long long row = image_rows ? image_rows[cam] : cam;
+  const float* __restrict__ src = images + row * 3 * (long long)per + rem;
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) out[i * 3 + ch] = src[(long long)ch * per];
+}
+
+// mean |a - b| over n elements and its gradient w.r.t. a (sign(a - b) / n: torch's l1_loss backward, sign(0) = 0), plus
+// the mean squared difference; per-block partial sums in double, folded in a fixed order by l1_finalize_kernel
+__global__ __launch_bounds__(256) void l1_loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                           float inv_n, float* __restrict__ d_a, double* __restrict__ partial) {
+  double s[2] = {0, 0};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float df = a[i] - b[i];
+    s[0] += fabsf(df);
+    s[1] += (double)df * (double)df;
+    d_a[i] = sgnf(df) * inv_n;
+  }
+  block_sum<2>(s, partial + (long long)blockIdx.x * 2);
+}
+__global__ __launch_bounds__(256) void l1_finalize_kernel(const double* __restrict__ partial, int nblocks, double n,
+                                                          float* __restrict__ out2) {
+  double s[2] = {0, 0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s[0] += partial[2 * i]; s[1] += partial[2 * i + 1]; }
+  __shared__ double tot[2];
+  block_sum<2>(s, tot);
+  __syncthreads();
+  if (threadIdx.x == 0) { out2[0] = (float)(tot[0] / n); out2[1] = (float)(tot[1] / n); }
+}
+
+void launch_gather_pixels(const float* images, const long long* image_rows, const long long* subset, long long B, int per,
+                          float* out, hipStream_t st) {
+  if (B <= 0) return;
+  gather_pixels_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>(images, image_rows, subset, B, per, out);
+}
+size_t l1_scratch_bytes() { return sizeof(double) * (kRedBlocks * 2 + 8); }
+void launch_l1_loss_grad(const float* a, const float* b, long long n, float* d_a, float* out2, void* scratch, hipStream_t st) {
+  double* partial = (double*)scratch;
+  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  l1_loss_grad_kernel<<<nb, 256, 0, st>>>(a, b, n, (float)(1.0 / (double)n), d_a, partial);
+  l1_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, (double)n, out2);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sustained shader clock (measurement aid of bench.py: the issue-rate ceilings of the render kernels are quoted in shader
 // clocks, so the clock has to be MEASURED under load, not assumed).  s_memtime counts shader clocks, s_memrealtime a
 // constant reference clock (hipDeviceAttributeWallClockRate, 100 MHz); every block of a chip-filling launch that keeps

@@ -98,6 +98,10 @@ void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, i
                      hipStream_t st);
 void launch_disparity_bwd(const float* depth, const float* acc, const float* d_disp, const float* d_depth_in,
                           const float* d_acc_in, float* d_depth_out, float* d_acc_out, long long R, hipStream_t st);
+void launch_gather_pixels(const float* images, const long long* image_rows, const long long* subset, long long B, int per,
+                          float* out, hipStream_t st);
+size_t l1_scratch_bytes();
+void launch_l1_loss_grad(const float* a, const float* b, long long n, float* d_a, float* out2, void* scratch, hipStream_t st);
 double run_clock_probe(int spin, hipStream_t st);   // sustained shader clock in Hz (blocking; 0 on failure)
 
 

@@ -361,7 +361,6 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
       for (int ch = 0; ch < COUT; ++ch) csum[ch] = csum[ch] + sigmoidf(rad[ch]) * w;
       asum = asum + w;
       dsum = dsum + z * w;
-      if (c.term_eps > 0.0f && T < c.term_eps) break;
     }
   }
   while (nextb <= nbound) { save_state(nextb); ++nextb; }  // boundaries behind the last sample: final state
@@ -407,7 +406,7 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
 // in its own thread (8x more waves), and render_fwd_combine_kernel folds the segments front to back:
 //   T_start(s) = prod_{s' < s} Tseg(s'),  colour = sum_s T_start(s) csum(s), ...
 // The combine pass also emits the per-ray segment-start states the segmented backward consumes.
-// (Used when term_eps == 0: early termination is inherently sequential.)
+// (The forward integrates every sample whatever term_eps says: the switch only truncates gradients, see voxe.h.)
 // segbuf layout: [segment][component][ray], components (Tseg, csum[COUT], asum, dsum).
 // ------------------------------------------------------------------------------------------------
 template <int COUT, int NCM, int NCU>
@@ -845,7 +844,9 @@ static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hi
   // is 40 blocks; at 400x400 the finer split hides the gather latency better): with the segment-major block order
   // one 32-sample segment per task is fastest at every image size (400x400, mean of three cameras: fseg 1 / 2 / 4 / 8
   // = 0.273 / 0.286 / 0.291 / 0.326 ms).
-  if (a.segbuf && nseg > 1 && !(c.term_eps > 0.0f)) {
+  // (term_eps never changes a forward -- since r03 it only truncates the BACKWARD: samples behind a transmittance below
+  //  it receive no gradient -- so the segmented forward runs whatever its value)
+  if (a.segbuf && nseg > 1) {
     static const int env_fseg = [] { const char* e = getenv("VOXE_FSEG"); return e ? atoi(e) : 0; }();
     int fseg = 1;
     if (env_fseg > 0) fseg = env_fseg;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void render_bwd_packed_scatter_kernel(
     for (int ch = 0; ch < COUT; ++ch) suf_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
     suf_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
     suf_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
-    if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
+    if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // gradient truncation: nothing behind T < term_eps receives a gradient
   }
 
   float gc[COUT], gsum = 0.0f;

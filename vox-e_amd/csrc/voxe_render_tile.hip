@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_T
       for (int ch = 0; ch < COUT; ++ch) suf_c[ch] = ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
       suf_a = ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
       suf_d = ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
-      if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // the forward stopped earlier
+      if (c.term_eps > 0.0f && T < c.term_eps) { has = false; k_hi = k_lo - 1; }  // gradient truncation: nothing behind T < term_eps receives a gradient
     }
     const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
     const int kmax = wave_max_i32(has ? k_hi : -1);
@@ -980,6 +980,11 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
       else VOXE_TBWD(false, true, 0, KL, nb, 0, 1);                             \
     } while (0)
     if (kl == 10) VOXE_TBWD_KL(10);
+#ifdef VOXE_TILE_KL_EXPERIMENTS   // (A/B builds only: every extra window width is three more ~1 k-line kernels per grid kind)
+    else if (kl == 9 && COUT == 3 && NCM == 1 && a.want_d && a.want_f) VOXE_TBWD(true, true, 0, 9, nb, 0, 1);
+    else if (kl == 12 && COUT == 3 && NCM == 1 && a.want_d && a.want_f) VOXE_TBWD(true, true, 0, 12, nb, 0, 1);
+    else if (kl == 16 && COUT == 3 && NCM == 1 && a.want_d && a.want_f) VOXE_TBWD(true, true, 0, 16, nb, 0, 1);
+#endif
     else VOXE_TBWD_KL(8);
 #undef VOXE_TBWD_KL
   }

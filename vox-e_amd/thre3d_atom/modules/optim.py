@@ -129,6 +129,43 @@ class FusedGridAdam(torch.optim.Optimizer):
         return state
 
     @torch.no_grad()
+    def reconstruction_step(self, render_params, height: int, width: int, focal: float, poses, image_rows, images,
+                            batch: int, diffuse_regularisation: bool, losses, rng) -> None:
+        """One whole iteration of the reconstruction loop (modules/trainers.py:288-351) in ONE library call
+        (voxe_recon_step): random pixel batch over the cameras `poses` -> specular [+ diffuse] render -> L1 loss(es) ->
+        backward -> this optimiser's Adam step.  State, step counters and the current learning rate are this
+        optimiser's (schedulers and checkpoints see nothing unusual); `losses` [4] (device) receives L1 / MSE of the
+        specular render and L1 / MSE of the diffuse one."""
+        if self.kind != "sh":
+            raise RuntimeError("reconstruction_step optimises the (densities, features) of an SH grid")
+        d = self.workspace.deferred
+        if d is None:
+            raise RuntimeError("reconstruction_step after detach()")
+        if d.dirty:
+            raise RuntimeError("reconstruction_step: an accumulated render gradient is waiting for step()")
+        group = self.param_groups[0]
+        beta1, beta2 = group["betas"]
+        train_d, train_f = self._train
+        st_d = self._state_of(self._dens) if train_d else None
+        st_f = self._state_of(self._feat) if train_f else None
+        for st in (st_d, st_f):
+            if st is not None:
+                st["step"] += 1
+        step_d = st_d["step"] if st_d is not None else st_f["step"]
+        step_f = st_f["step"] if st_f is not None else step_d
+        ws = self.workspace
+        if ws.sibling is None:
+            ws.sibling = _ops.Workspace()
+        fresh = ws.buf is None or d.clean_ptr != ws.buf.data_ptr()
+        _ops.recon_step_(self.spec, render_params, self._dens, self._feat, ws, ws.sibling, height, width, focal, poses,
+                         image_rows, images, batch, diffuse_regularisation,
+                         None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
+                         None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]), step_d, step_f, group["lr"],
+                         losses, rng, beta1=beta1, beta2=beta2, eps=group["eps"], zero_gradient_first=fresh)
+        d.clean_ptr = ws.buf.data_ptr()
+        d.dirty, d.layout = False, _ops.abi.GRAD_ANY
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:

@@ -18,13 +18,14 @@ from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam
 from thre3d_atom.modules.testers import test_sh_vox_grid_vol_mod_with_posed_images
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import sample_random_rays_and_pixels_from_cameras
-from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid
+from thre3d_atom.thre3d_reprs.renderers import _render_params, render_sh_voxel_grid
 from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, scale_voxel_grid_with_required_output_size
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
 from thre3d_atom.utils.imaging_utils import CameraPose, to8b
 from thre3d_atom.utils.logging import log
 from thre3d_atom.utils.metric_utils import mse2psnr
 from thre3d_atom.utils.misc import compute_thre3d_grid_sizes
+from voxe_hip.ops import _next_rng
 
 
 def train_sh_vox_grid_vol_mod_with_posed_images(
@@ -53,6 +54,8 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     fast_debug_mode: bool = False,
     lpips_weight: float = 0.0,
     fused_grid_step: bool = True,      # addition of this build: FusedGridAdam (gradient stays in the kernels' workspace)
+    fused_iteration: bool = True,      # addition of this build: the whole iteration (batch, 2 renders, L1, backward, Adam) as
+                                       # ONE library call (voxe_recon_step) -- needs fused_grid_step; same arithmetic
 ) -> VolumetricModel:
     if not isinstance(vol_mod.thre3d_repr, VoxelGrid) or vol_mod.render_procedure != render_sh_voxel_grid:
         raise AssertionError("this train procedure needs an SH-based VoxelGrid volumetric model")
@@ -101,6 +104,9 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         else:
             optimizer = VoxeAdam([{"params": vol_mod.thre3d_repr.parameters(), "lr": lr}], betas=(0.9, 0.999))
         scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_decay_gamma_per_stage)
+        # (the one-call iteration reads RGB targets straight from the image stack)
+        one_call = fused_grid_step and fused_iteration and data.images.shape[1] == 3 and data.images.is_contiguous()
+        fused_losses = torch.zeros(4, dtype=torch.float32, device=device)
         log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
         try:
             for it in range(1, num_iterations_per_stage + 1):
@@ -108,24 +114,37 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
                 # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
                 # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
                 picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
-                rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
-                    intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks,
-                    # (sorting the batch by (camera, row, column) helps the ray-ordered gather of small batches; batches of 16384+
-                    #  rays take the space-binned render, which does not care about the order: skip the sort)
-                    memory_order=ray_batch_size < 16384, fast_subset=True)
-
-                specular = vol_mod.render_rays(rays_batch).colour
-                loss = torch.nn.functional.l1_loss(specular, pixels_batch)
-                psnr = mse2psnr(torch.nn.functional.mse_loss(specular.detach(), pixels_batch))
-                if apply_diffuse_render_regularization:
-                    diffuse = vol_mod.render_rays(rays_batch, render_diffuse=True).colour
-                    loss = loss + torch.nn.functional.l1_loss(diffuse, pixels_batch)
-                optimizer.zero_grad()
-                loss.backward()
-                optimizer.step()
+                if one_call:
+                    # ONE library call: random pixel batch over the picked cameras -> specular (+ diffuse) render -> L1 ->
+                    # backward -> Adam with this optimiser's state and learning rate (voxe_recon_step).  The loss values stay
+                    # on the device until they are logged.
+                    optimizer.reconstruction_step(
+                        _render_params(vol_mod.thre3d_repr, None, vol_mod.render_config, attn=False), intr.height, intr.width,
+                        float(intr.focal), data.poses[picks].contiguous(), picks, data.images,
+                        min(ray_batch_size, picks.numel() * intr.height * intr.width), apply_diffuse_render_regularization,
+                        fused_losses, _next_rng())
+                else:
+                    rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
+                        intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks,
+                        # (sorting the batch by (camera, row, column) helps the ray-ordered gather of small batches; batches of
+                        #  16384+ rays take the space-binned render, which does not care about the order: skip the sort)
+                        memory_order=ray_batch_size < 16384, fast_subset=True)
+                    specular = vol_mod.render_rays(rays_batch).colour
+                    loss = torch.nn.functional.l1_loss(specular, pixels_batch)
+                    psnr = mse2psnr(torch.nn.functional.mse_loss(specular.detach(), pixels_batch))
+                    if apply_diffuse_render_regularization:
+                        diffuse = vol_mod.render_rays(rays_batch, render_diffuse=True).colour
+                        loss = loss + torch.nn.functional.l1_loss(diffuse, pixels_batch)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
                 global_step += 1
                 trained += time.perf_counter() - t0
                 if global_step % summary_freq == 0 or it in (1, num_iterations_per_stage):
+                    if one_call:
+                        l1_spec, mse_spec, l1_diff, _ = fused_losses.tolist()
+                        loss = torch.tensor(l1_spec + (l1_diff if apply_diffuse_render_regularization else 0.0))
+                        psnr = mse2psnr(torch.tensor(mse_spec))
                     log.info(f"Stage: {stage} Global Iteration: {global_step} Stage Iteration: {it} "
                              f"loss: {float(loss.detach()): .3f} psnr: {float(psnr): .3f}")
                 if it % lr_decay_steps_per_stage == 0:

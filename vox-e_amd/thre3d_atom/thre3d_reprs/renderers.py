@@ -31,6 +31,8 @@ _TERM_EPS = 0.0
 
 
 def set_early_termination(eps: float) -> None:
+    """gradient truncation of the HIP renderer (VoxeRenderCfg::term_eps; not in the reference, 0 = off): the backward stops
+    marching a ray once its transmittance is below `eps`; forward outputs are never affected"""
     global _TERM_EPS
     _TERM_EPS = float(eps)
 
@@ -62,18 +64,18 @@ def _sh_degree_of(voxel_grid: VoxelGrid) -> int:
     return degree
 
 
-def _render_params(voxel_grid: VoxelGrid, rays: Rays, cfg: SHVoxGridRenderConfig, attn: bool) -> _ops.RenderParams:
+def _render_params(voxel_grid: VoxelGrid, rays: Optional[Rays], cfg: SHVoxGridRenderConfig, attn: bool) -> _ops.RenderParams:
     if cfg.density2occupancy is not density2occupancy_pb:
         raise VoxeError("only density2occupancy_pb has a HIP path")
     if cfg.radiance_hdr_tone_map is not torch.sigmoid:
         raise VoxeError("only torch.sigmoid tone mapping has a HIP path")
     if cfg.stochastic_density_noise_std != 0.0:
         raise VoxeError("stochastic_density_noise_std != 0 is not supported by the HIP renderer")
-    num_rays = rays.origins.shape[0]
+    num_rays = rays.origins.shape[0] if rays is not None else 0     # (rays None: parameters of an unordered batch)
     # image-ordered rays: one image (R == H * W) or a multi-view batch of K images of that shape, one after the other
     # (collate_rays of flattened cameras that all carry the same image_shape): ONE launch, 2-D pixel tiles per camera
     width = height = 0
-    if rays.image_shape is not None and num_rays > 0:
+    if rays is not None and rays.image_shape is not None and num_rays > 0:
         per_image = int(rays.image_shape[0]) * int(rays.image_shape[1])
         if per_image > 0 and num_rays % per_image == 0:
             width = int(rays.image_shape[1])

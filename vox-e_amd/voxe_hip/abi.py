@@ -82,6 +82,19 @@ class VoxeProfile(C.Structure):
     ]
 
 
+class VoxeReconStep(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32), ("W", C.c_int32), ("focal", C.c_float),
+        ("poses", C.c_void_p), ("image_rows", C.c_void_p), ("images", C.c_void_p),
+        ("K", C.c_int32), ("batch", C.c_int64), ("diffuse_regularisation", C.c_int32),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("step_densities", C.c_int64), ("step_features", C.c_int64),
+        ("exp_avg_densities", C.c_void_p), ("exp_avg_sq_densities", C.c_void_p),
+        ("exp_avg_features", C.c_void_p), ("exp_avg_sq_features", C.c_void_p),
+        ("losses", C.c_void_p), ("zero_gradient_first", C.c_int32),
+    ]
+
+
 _P = C.c_void_p
 _GD = C.POINTER(VoxeGridDesc)
 _RC = C.POINTER(VoxeRenderCfg)
@@ -137,6 +150,8 @@ HIP_ONLY = {
     "disparity_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "clock_probe": (C.c_int, [C.c_int32, C.POINTER(C.c_double), _P]),
     "region_debug_layout": (C.c_int, [_GD, _RC, C.c_int64, C.POINTER(C.c_int64)]),
+    "recon_scratch_bytes": (C.c_size_t, [C.c_int64]),
+    "recon_step": (C.c_int, [_GD, _RC, C.POINTER(VoxeReconStep), _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "graphcut_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

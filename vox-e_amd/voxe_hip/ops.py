@@ -625,6 +625,69 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
 
 
 @torch.no_grad()
+def recon_step_(spec: GridSpec, params: RenderParams, densities, features, workspace: Workspace, workspace2: Workspace,
+                height: int, width: int, focal: float, poses: torch.Tensor, image_rows: Optional[torch.Tensor],
+                images: torch.Tensor, batch: int, diffuse_regularisation: bool, state_densities, state_features,
+                step_densities: int, step_features: int, lr: float, losses: torch.Tensor, rng: Tuple[int, int],
+                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_gradient_first: bool = True,
+                scratch_holder: Optional[dict] = None) -> None:
+    """voxe_recon_step: one reconstruction iteration (random pixel batch over the K cameras `poses` -> specular
+    [+ diffuse] render -> L1 loss(es) against `images` -> backward -> Adam on both grid tensors) in ONE library call.
+    `losses` [4] float32 on the device receives (L1 specular, MSE specular, L1 diffuse, MSE diffuse).  The jitter /
+    subset streams derive from `rng` (subset: offset, specular: offset + 1, diffuse: offset + 2).  Afterwards
+    `workspace` holds the updated grid packed and a cleared gradient region."""
+    device = densities.device
+    ensure_gfx950(device)
+    for nm, t in (("densities", densities), ("features", features), ("poses", poses), ("images", images), ("losses", losses)):
+        require_device(t, f"recon_step_ ({nm})")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise VoxeError(f"recon_step_: {nm} must be contiguous float32")
+    if images.dim() != 4 or images.shape[1] != 3 or tuple(images.shape[2:]) != (height, width):
+        raise VoxeError(f"recon_step_: images must be [N,3,{height},{width}], got {tuple(images.shape)}")
+    if poses.dim() != 3 or tuple(poses.shape[1:]) != (3, 4) or losses.numel() < 4:
+        raise VoxeError("recon_step_: poses must be [K,3,4] and losses hold 4 floats")
+    if image_rows is not None and (image_rows.dtype != torch.int64 or image_rows.numel() != poses.shape[0] or not image_rows.is_cuda):
+        raise VoxeError("recon_step_: image_rows must be int64 [K] on the device")
+    L = lib()
+    key = _pack_key(spec, densities, features)
+    p = dataclasses.replace(params, linear_grad=True, image_width=0, image_height=0)
+    g, c = _descs(spec, p, densities, features, rng[0], rng[1], workspace.key == key)
+    rs = abi.VoxeReconStep()
+    rs.H, rs.W, rs.focal = int(height), int(width), float(focal)
+    rs.poses, rs.images, rs.image_rows = ptr(poses), ptr(images), ptr(image_rows)
+    rs.K, rs.batch, rs.diffuse_regularisation = int(poses.shape[0]), int(batch), int(bool(diffuse_regularisation))
+    rs.lr, rs.beta1, rs.beta2, rs.eps = float(lr), float(beta1), float(beta2), float(eps)
+    rs.step_densities, rs.step_features = int(step_densities), int(step_features)
+    m_d, v_d = state_densities if state_densities is not None else (None, None)
+    m_f, v_f = state_features if state_features is not None else (None, None)
+    rs.exp_avg_densities, rs.exp_avg_sq_densities = ptr(m_d), ptr(v_d)
+    rs.exp_avg_features, rs.exp_avg_sq_features = ptr(m_f), ptr(v_f)
+    rs.losses = ptr(losses)
+    holder = scratch_holder if scratch_holder is not None else workspace.__dict__.setdefault("_recon_scratch", {})
+    with torch.cuda.device(device):
+        nbytes = L.voxe_workspace_bytes(C.byref(g), C.byref(c), int(batch))
+        had = workspace.buf
+        ws = workspace.ensure(nbytes, device)
+        # (a buffer this call allocated holds whatever torch.empty returned in its gradient region)
+        rs.zero_gradient_first = int(bool(zero_gradient_first) or ws is not had)
+        c.reuse_packed_grid = int(workspace.key == key)
+        ws2 = workspace2.ensure(nbytes, device) if diffuse_regularisation else None
+        need = L.voxe_recon_scratch_bytes(int(batch))
+        sc = holder.get("buf")
+        if sc is None or sc.numel() < need or sc.device != ws.device:
+            sc = holder["buf"] = torch.empty(need, dtype=torch.uint8, device=device)
+        check(L.voxe_recon_step(C.byref(g), C.byref(c), C.byref(rs), ptr(ws), ws.numel(), ptr(ws2),
+                                0 if ws2 is None else ws2.numel(), ptr(sc), sc.numel(), stream_ptr(device)), "voxe_recon_step")
+    for t in (densities, features, m_d, v_d, m_f, v_f):
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+    workspace.key = _pack_key(spec, densities, features)   # the workspace holds the updated grid packed
+    workspace.state_key = None
+    workspace2.key = None                                  # (its packed grid is the previous iteration's)
+    workspace2.state_key = None
+
+
+@torch.no_grad()
 def upsample_trilinear(src: torch.Tensor, out_size: Sequence[int]) -> torch.Tensor:
     """[X,Y,Z,C] -> [X2,Y2,Z2,C], F.interpolate(trilinear, align_corners=False) semantics
     (thre3d_atom/thre3d_reprs/voxels.py:409-447)."""
