@@ -338,12 +338,14 @@ def _region_env(monkeypatch, image_too=False):
 
 
 @pytest.mark.parametrize("case", ["sh0_jitter", "sh0_clip_lindisp", "attn", "diffuse_sh1", "tiny_grid", "image_ordered",
-                                  "density_only", "features_only", "jitter_tensor"])
+                                  "density_only", "features_only", "jitter_tensor", "sh1", "sh2", "sh1_density_only",
+                                  "sh2_features_only"])
 def test_region_backward_variants_vs_oracle(case, monkeypatch):
     _region_env(monkeypatch, image_too=(case == "image_ordered"))
     rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)   # (not hash(): salted per process)
     dims = (5, 6, 7) if case == "tiny_grid" else (40, 33, 48)
-    nfeat = 12 if case == "diffuse_sh1" else (1 if case == "attn" else 3)
+    # (sh1 / sh2: view-dependent grids -- whole texels in LDS, two-phase backward; r03)
+    nfeat = 12 if case in ("diffuse_sh1", "sh1", "sh1_density_only") else (27 if case in ("sh2", "sh2_features_only") else (1 if case == "attn" else 3))
     dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
     feat = rng.uniform(-1, 1, (*dims, nfeat)).astype(np.float32)
     grid = vo.Grid(dens, feat, [(-1.5, 1.5), (-1.2, 1.3), (-1.5, 1.4)], 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS,
@@ -361,6 +363,10 @@ def test_region_backward_variants_vs_oracle(case, monkeypatch):
         kw.update(aabb_clip=True)
     if case == "diffuse_sh1":
         kw.update(sh_degree=1, render_diffuse=True)
+    if case in ("sh1", "sh1_density_only"):
+        kw.update(sh_degree=1, perturb=True, seed=5, rng_offset=9)
+    if case in ("sh2", "sh2_features_only"):
+        kw.update(sh_degree=2)
     if case == "jitter_tensor":
         kw.update(perturb=True)
         jit = rng.random((o.shape[0], 70)).astype(np.float32)
@@ -375,13 +381,13 @@ def test_region_backward_variants_vs_oracle(case, monkeypatch):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, jitter=jit, rng=(5, 9), **over)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, jitter=jit)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (case, rel_l2(gd, rd), rel_l2(gf, rf))
-    if case in ("density_only", "features_only"):
+    if case in ("density_only", "features_only", "sh1_density_only", "sh2_features_only"):
         # one tensor frozen: the other's gradient is unchanged
         from voxe_hip import ops
-        dt, ft = gh.t(grid.densities, case == "density_only"), gh.t(grid.features, case == "features_only")
+        dt, ft = gh.t(grid.densities, case.endswith("density_only")), gh.t(grid.features, case.endswith("features_only"))
         c, dep, _, _ = ops.render(gh.spec_of(grid), gh.params_of(cfg), dt, ft, gh.t(o), gh.t(d), None, rng=(5, 9))
         ((c * gh.t(gc)).sum() + (dep[:, 0] * gh.t(gdep)).sum()).backward()
-        got, ref = (gh.n(dt.grad), rd) if case == "density_only" else (gh.n(ft.grad), rf)
+        got, ref = (gh.n(dt.grad), rd) if case.endswith("density_only") else (gh.n(ft.grad), rf)
         assert rel_l2(got, ref) < GRAD_TOL
 
 

@@ -148,7 +148,9 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
       make_dev(g, c, R, v, &dg, &dc);
       const bool tiled = tile_bwd_supported(dc, c->sh_degree);
       l.region = region_bwd_supported(dg, dc, c->sh_degree, c->render_diffuse, tiled);
-      if (l.region) l.total_with_src += region_scratch_bytes(g->X, g->Y, g->Z, R, c->num_samples);
+      if (l.region)
+        l.total_with_src += region_scratch_bytes(g->X, g->Y, g->Z, R, c->num_samples,
+                                                 g->feature_kind != VOXE_FEAT_ATTN && c->sh_degree > 0 && !c->render_diffuse);
     }
   }
   return l;

@@ -71,7 +71,7 @@ void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, int deg, int d
 // voxe_render_region.hip: space-binned render (segments of rays grouped by 8x8x8-cell region; texels and the gradient
 // window of a region live in LDS)
 bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffuse, bool tiled);
-size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S);
+size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S, bool full_sh);   // full_sh: SH degree 1 / 2, not diffuse
 void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
                        hipStream_t st);   // segment tables + forward; leaves the per-segment states in `scratch`
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,

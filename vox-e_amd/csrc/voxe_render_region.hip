@@ -94,6 +94,19 @@ struct BinScratch {
 __device__ __forceinline__ size_t slot_of(size_t lane, unsigned j, long long nlanes) { return (size_t)j * (size_t)nlanes + lane; }
 
 // ---- ray context of a segment lane: origin, direction, depth generator (no sample range, no SH basis) ----------------------
+// LDS stride (floats) of a full view-dependent texel: 13 -> 16, 28 -> 32 (16-byte aligned rows for ds_read_b128)
+__host__ __device__ constexpr int tex_stride(int cm) { return (cm + 3) / 4 * 4; }
+
+template <int NCU>
+__device__ __forceinline__ void ray_basis(const float (&d)[3], float dnorm, float (&basis)[NCU]) {
+  if constexpr (NCU > 1) {
+    const float v[3] = {d[0] / dnorm, d[1] / dnorm, d[2] / dnorm};   // (as RayCtx::init)
+    sh_basis<NCU>(v, basis);
+  } else {
+    basis[0] = kC0;
+  }
+}
+
 struct SegRay {
   float o[3], d[3], dnorm;
   DepthGen dg;
@@ -286,6 +299,46 @@ __device__ __forceinline__ void gather_lds(const float* __restrict__ tex, int id
   }
 }
 
+// View-dependent grids (SH degree 1 / 2: 13 / 28-channel texels): the WHOLE texel of every window voxel in LDS, rows of
+// CP = tex_stride(CM) floats; a corner is contracted with the ray's basis first (gather<>() of voxe_render_common.hpp:
+// same products, same order), so COUT accumulators stay live.
+template <int CM>
+__device__ __forceinline__ void load_window_full(const DevGrid& g, const float* __restrict__ packed, float* __restrict__ tex,
+                                                 int ox, int oy, int oz, int tid) {
+  constexpr int CP = tex_stride(CM);
+  for (int e = tid; e < kRWin * CM; e += VOXE_REGION_BLOCK) {
+    const int v = e / CM, ch = e - v * CM;
+    const int x = ox + v / (kRWY * kRWZ), y = oy + (v / kRWZ) % kRWY, z = oz + v % kRWZ;
+    const bool in = x < g.X && y < g.Y && z < g.Z;
+    tex[v * CP + ch] = in ? packed[(((long long)x * g.Y + y) * g.Z + z) * CM + ch] : 0.0f;
+  }
+}
+template <int COUT, int NCM, int NCU>
+__device__ __forceinline__ void gather_lds_sh(const float* __restrict__ tex, int idx0, const Cell& cell,
+                                              const float (&basis)[NCU], float& v, float (&rad)[COUT]) {
+  constexpr int CM = COUT * NCM + 1, CP = tex_stride(CM);
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) rad[ch] = 0.0f;
+  v = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = (cell.w[0][k & 1] * cell.w[1][(k >> 1) & 1]) * cell.w[2][k >> 2];
+    const float4* __restrict__ t4 =
+        reinterpret_cast<const float4*>(tex + (idx0 + (k & 1) * (kRWY * kRWZ) + ((k >> 1) & 1) * kRWZ + (k >> 2)) * CP);
+    float t[CP];
+#pragma unroll
+    for (int q = 0; q < CP / 4; ++q) { const float4 x = t4[q]; t[4 * q] = x.x; t[4 * q + 1] = x.y; t[4 * q + 2] = x.z; t[4 * q + 3] = x.w; }
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) {
+      float r = basis[0] * t[ch * NCM];
+#pragma unroll
+      for (int j = 1; j < NCU; ++j) r = fmaf(basis[j], t[ch * NCM + j], r);
+      rad[ch] = fmaf(r, w, rad[ch]);
+    }
+    v = fmaf(t[CM - 1], w, v);
+  }
+}
+
 struct RegionBlock {
   int ox, oy, oz;   // window origin (voxels)
   bool generic;     // the generic bin: texels from global memory, global atomics
@@ -302,23 +355,29 @@ __device__ __forceinline__ RegionBlock region_block(const DevGrid& g, unsigned r
 }
 
 // ---- pass 3: forward, one block per region -----------------------------------------------------------------------------------
-template <int COUT, int NCM>
+template <int COUT, int NCM, int NCU>
 __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
                                                                        const float* __restrict__ rays_o,
                                                                        const float* __restrict__ rays_d,
                                                                        const float* __restrict__ jitter, BinScratch bs,
                                                                        const int nreg) {
   constexpr int C = COUT + 1;
-  __shared__ float tex[kRWin * C];
+  // single-group renders (SH-0 / diffuse / attention) stage (coefficient 0 of every colour, density); view-dependent ones
+  // the whole texel (dynamic LDS: 46.6 KB at degree 1, 81.6 KB at degree 2)
+  __shared__ float tex_small[NCU == 1 ? kRWin * C : 1];
+  extern __shared__ float4 tex_dyn[];
+  float* const tex = NCU == 1 ? tex_small : reinterpret_cast<float*>(tex_dyn);
   const int tid = threadIdx.x;
   const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
   const unsigned first = bs.start[region * kLenClasses];
   const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
   if (n == 0) return;                       // block-uniform
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
-  if (!rb.generic) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+  if (!rb.generic) {
+    if constexpr (NCU == 1) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+    else load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+  }
   __syncthreads();
-  const float basis0[1] = {kC0};
   const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
   const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
   for (unsigned i = i_begin; i < n; i += i_step) {
@@ -327,6 +386,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
     const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
     SegRay ray;
     ray.init(g, c, r, rays_o, rays_d, jitter);
+    float basis[NCU];
+    ray_basis<NCU>(ray.d, ray.dnorm, basis);
     float csum[3] = {0.0f, 0.0f, 0.0f};
     float asum = 0.0f, dsum = 0.0f, T = 1.0f;
     float z_next = ray.dg.z(k0);
@@ -343,11 +404,12 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
       make_cell_fast(g, fp, cell);
       float v, rad[COUT];
       if (rb.generic) {
-        gather<COUT, NCM, 1>(g, packed, cell, basis0, v, rad);
+        gather<COUT, NCM, NCU>(g, packed, cell, basis, v, rad);
       } else {
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
         if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
-        gather_lds<COUT>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, v, rad);
+        if constexpr (NCU == 1) gather_lds<COUT>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, v, rad);
+        else gather_lds_sh<COUT, NCM, NCU>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, basis, v, rad);
       }
       const float sigma = post_activate(g.post_act, v);
       const float dl = last ? kInfinity : (z_next - z);
@@ -618,6 +680,211 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   }
 }
 
+// ---- pass 5', view-dependent grids (SH degree 1 / 2): two-phase backward ---------------------------------------------------------
+// d rad_c / d coef_cj = basis_j(ray) is a per-ray constant, so a sample has only FOUR gradient sources (d rad_0..2, d v),
+// exactly like SH-0, and every gradient channel is one of them times a constant.
+//   phase 1  region_bwd_src_kernel   one block per region, the region's WHOLE texels in LDS: the march of
+//            region_bwd_kernel up to the 4 sources of every sample -> src[ray * S + k] (16 bytes per sample);
+//   phase 2  region_bwd_dep_kernel   one block per (region, group of 4 gradient channels): footprints only (no gather),
+//            sources x basis -> the same 9x9x9 double window as SH-0, one dense flush per (region, group).
+template <int NCM, int NCU>
+__global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
+    DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ jitter, const float* __restrict__ d_colour, const float* __restrict__ d_depth,
+    const float* __restrict__ d_acc, const int want_d, const int want_f, BinScratch bs, const int nreg,
+    float4* __restrict__ src) {
+  constexpr int COUT = 3;
+  extern __shared__ float4 tex_dyn[];
+  float* const tex = reinterpret_cast<float*>(tex_dyn);
+  const int tid = threadIdx.x;
+  const unsigned region = min(blockIdx.x, (unsigned)nreg);
+  const unsigned first = bs.start[region * kLenClasses];
+  const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
+  if (n == 0) return;
+  const RegionBlock rb = region_block(g, blockIdx.x, nreg);
+  if (!rb.generic) load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+  __syncthreads();
+  const bool white = c.white && !c.attn;
+  const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
+  const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
+  for (unsigned i = i_begin; i < n; i += i_step) {
+    const uint4 rec = bs.sorted[first + i];
+    const long long r = rec.x;
+    const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
+    SegRay ray;
+    ray.init(g, c, r, rays_o, rays_d, jitter);
+    float basis[NCU];
+    ray_basis<NCU>(ray.d, ray.dnorm, basis);
+    const size_t pi = rec.z;
+    const float4 sa = bs.state[2 * pi], sb = bs.state[2 * pi + 1];
+    float T = sa.x;
+    float gc[COUT], gsum = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) { gc[ch] = d_colour[r * COUT + ch]; gsum += gc[ch]; }
+    const float gdep = d_depth ? d_depth[r] : 0.0f;
+    const float gacc = d_acc ? d_acc[r] : 0.0f;
+    float suffix0 = gdep * sb.y + gacc * sb.x + gc[0] * sa.y + gc[1] * sa.z + gc[2] * sa.w;
+    if (white) suffix0 -= gsum * sb.x;
+    suffix0 *= T;
+    float run = 0.0f;
+    float z_next = ray.dg.z(k0);
+    for (int k = k0; k <= k1; ++k) {
+      const float z = z_next;
+      const bool last = (k == c.S - 1);
+      if (!last) z_next = ray.dg.z(k + 1);
+      float p[3];
+      ray.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      if (!fp.inside) continue;
+      Cell cell;
+      make_cell_fast(g, fp, cell);
+      float v, rad[COUT];
+      if (rb.generic) {
+        gather<COUT, NCM, NCU>(g, packed, cell, basis, v, rad);
+      } else {
+        const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
+        if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
+        gather_lds_sh<COUT, NCM, NCU>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, basis, v, rad);
+      }
+      float sigma, dpost;
+      post_activate_vg(g.post_act, v, sigma, dpost);
+      const float dl = last ? kInfinity : (z_next - z);
+      const float delta = dl * ray.dnorm;
+      const float e = fast_exp(-(sigma * delta));
+      const float alpha = 1.0f - e;
+      const float om = 1.0f - alpha;
+      const float wk = alpha * T;
+      float col[COUT], dldw = fmaf(gdep, z, gacc);
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
+      if (white) dldw -= gsum;
+      run = fmaf(dldw, wk, run);
+      const float suffix = last ? 0.0f : (suffix0 - run);
+      const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+      const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+      float4 o4;
+      o4.x = want_f ? (wk * gc[0]) * (col[0] * (1.0f - col[0])) : 0.0f;
+      o4.y = want_f ? (wk * gc[1]) * (col[1] * (1.0f - col[1])) : 0.0f;
+      o4.z = want_f ? (wk * gc[2]) * (col[2] * (1.0f - col[2])) : 0.0f;
+      o4.w = want_d ? dsig * dpost : 0.0f;
+      src[r * c.S + k] = o4;
+      T = T * om;
+    }
+  }
+}
+
+template <int NCM, int NCU>
+__global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_dep_kernel(
+    DevGrid g, DevCfg c, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ jitter,
+    float* __restrict__ gpacked, BinScratch bs, const int nreg, const float4* __restrict__ src, const int grp_begin) {
+  constexpr int COUT = 3, CM = COUT * NCM + 1, NG = COUT * NCU + 1, WC = 4;
+  __shared__ double win[WC * kRPlane];
+  const int tid = threadIdx.x;
+  const unsigned region = min(blockIdx.x, (unsigned)nreg);
+  const unsigned first = bs.start[region * kLenClasses];
+  const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
+  if (n == 0) return;
+  const RegionBlock rb = region_block(g, blockIdx.x, nreg);
+  const int grp = grp_begin + (int)blockIdx.y;
+  // window channel s <-> gradient channel q = grp * 4 + s: coefficient j of colour ch (texel channel ch * NCM + j, factor
+  // basis_j of the ray) or, last, the density (texel channel CM - 1, factor 1); -1: unused slot of the last group
+  int chsel[WC], jsel[WC], memch[WC];
+#pragma unroll
+  for (int sidx = 0; sidx < WC; ++sidx) {
+    const int q = grp * WC + sidx;
+    if (q >= NG) { chsel[sidx] = -1; jsel[sidx] = 0; memch[sidx] = 0; }
+    else if (q == NG - 1) { chsel[sidx] = COUT; jsel[sidx] = 0; memch[sidx] = CM - 1; }
+    else { chsel[sidx] = q / NCU; jsel[sidx] = q - chsel[sidx] * NCU; memch[sidx] = chsel[sidx] * NCM + jsel[sidx]; }
+  }
+  if (!rb.generic)
+    for (int i = tid; i < WC * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
+  __syncthreads();
+  const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
+  const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
+  for (unsigned i = i_begin; i < n; i += i_step) {
+    const uint4 rec = bs.sorted[first + i];
+    const long long r = rec.x;
+    const int k0 = (int)(rec.y & 0xFFFFu), k1 = (int)(rec.y >> 16);
+    SegRay ray;
+    ray.init(g, c, r, rays_o, rays_d, jitter);
+    float basis[NCU];
+    ray_basis<NCU>(ray.d, ray.dnorm, basis);
+    float mult[WC];
+#pragma unroll
+    for (int sidx = 0; sidx < WC; ++sidx) {
+      float b = basis[0];
+#pragma unroll
+      for (int t = 1; t < NCU; ++t) b = (jsel[sidx] == t) ? basis[t] : b;
+      mult[sidx] = chsel[sidx] < 0 ? 0.0f : (chsel[sidx] == COUT ? 1.0f : b);
+    }
+    for (int k = k0; k <= k1; ++k) {
+      const float z = ray.dg.z(k);
+      float p[3];
+      ray.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      if (!fp.inside) continue;
+      Cell cell;
+      make_cell_fast(g, fp, cell);
+      int idx0 = 0;
+      if (!rb.generic) {
+        const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
+        if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
+        idx0 = (lx * kRWY + ly) * kRWZ + lz;
+      }
+      const float4 s4 = src[r * c.S + k];
+      float gch[WC];
+      bool any = false;
+#pragma unroll
+      for (int sidx = 0; sidx < WC; ++sidx) {
+        const float x = chsel[sidx] == 0 ? s4.x : (chsel[sidx] == 1 ? s4.y : (chsel[sidx] == 2 ? s4.z : s4.w));
+        gch[sidx] = x * mult[sidx];
+        any = any || (gch[sidx] != 0.0f);
+      }
+      if (!any) continue;
+      if (rb.generic) {
+        const CellAddr ad = cell_addr(g, cell);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float w = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
+          if (w == 0.0f) continue;
+          float* __restrict__ texel =
+              gpacked + (long long)(ad.base + (j & 1) * ad.sx + ((j >> 1) & 1) * ad.sy + (j >> 2) * ad.sz) * CM;
+#pragma unroll
+          for (int sidx = 0; sidx < WC; ++sidx)
+            if (gch[sidx] != 0.0f) atomicAdd(texel + memch[sidx], gch[sidx] * w);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float w = (cell.w[0][j & 1] * cell.w[1][(j >> 1) & 1]) * cell.w[2][j >> 2];
+          const int idx = idx0 + (j & 1) * (kRWY * kRWZ) + ((j >> 1) & 1) * kRWZ + (j >> 2);
+#pragma unroll
+          for (int sidx = 0; sidx < WC; ++sidx)
+            if (chsel[sidx] >= 0)   // (block-uniform: the last group of 13 / 28 channels holds 1 / 4 used slots)
+              __hip_atomic_fetch_add(&win[sidx * kRPlane + idx], (double)(gch[sidx] * w), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+  }
+  if (rb.generic) return;
+  __syncthreads();
+  for (int e = tid; e < kRWin * WC; e += VOXE_REGION_BLOCK) {
+    const int vl = e / WC, sidx = e - vl * WC;
+    const double val = win[sidx * kRPlane + vl];
+    if (val == 0.0) continue;
+    const int x = rb.ox + vl / (kRWY * kRWZ), y = rb.oy + (vl / kRWZ) % kRWY, zz = rb.oz + vl % kRWZ;
+    if (x >= g.X || y >= g.Y || zz >= g.Z) continue;
+    const long long vox = ((long long)x * g.Y + y) * g.Z + zz;
+    int mc = memch[0];
+#pragma unroll
+    for (int t = 1; t < WC; ++t) mc = (sidx == t) ? memch[t] : mc;
+    atomicAdd(gpacked + vox * CM + mc, (float)val);
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 static long long region_min_rays() {
   const char* e = getenv("VOXE_REGION_MIN_RAYS");   // read per launch (tests / A-B runs flip it); < 0 disables the path
@@ -627,7 +894,9 @@ static long long region_min_rays() {
 bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffuse, bool tiled) {
   const long long min_rays = region_min_rays();
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
-  if (!(c.attn || deg == 0 || diffuse)) return false;          // one channel group (SH-0 / diffuse / attention)
+  if (!(c.attn || deg <= 2 || diffuse)) return false;          // SH-0 / diffuse / attention: one channel group; SH degree 1 / 2:
+                                                               // whole texels in LDS + two-phase backward (degree 3: 49-channel
+                                                               // texels do not fit)
   if (num_segments(c.S, c.seg_len) > 256) return false;       // (the lanes of a ray meet in one block's LDS: region_fold_kernel)
   if (c.R > (1ll << 19) || c.S >= 65536) return false;         // segment records hold 32-bit rays / 16-bit sample indices;
                                                                // the tables take ~12 KB per ray (S = 256): capped at 512 k rays (6 GB) per launch
@@ -642,8 +911,8 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
 }
 
 static inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
-struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, total; long long nslots, nlanes; int nreg; };
-static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
+struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, src, total; long long nslots, nlanes; int nreg; };
+static RegionLayout region_layout(int X, int Y, int Z, long long R, int S, bool full_sh = false) {
   RegionLayout l;
   const int nseg = num_segments(S, seg_len_for(R));
   l.nslots = R * nseg * kSlotsPerLane;
@@ -658,12 +927,14 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S) {
   l.state = off; off += up256((size_t)l.nslots * 2 * sizeof(float4));
   l.lane_n = off; off += up256((size_t)l.nlanes * sizeof(unsigned));
   l.counters = off; off += 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned));   // count | start
+  // view-dependent grids: the 4 gradient sources of every sample between the two phases of the backward
+  l.src = off; off += full_sh ? up256((size_t)R * (size_t)S * sizeof(float4)) : 0;
   l.total = off;
   return l;
 }
-size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S) {
+size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S, bool full_sh) {
   if (R <= 0 || S <= 0) return 0;
-  return region_layout(X, Y, Z, R, S).total;
+  return region_layout(X, Y, Z, R, S, full_sh).total;
 }
 static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
   char* base = (char*)scratch;
@@ -681,7 +952,7 @@ static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
 }
 
 void region_debug_layout(int X, int Y, int Z, long long R, int S, long long out[16]) {
-  const RegionLayout l = region_layout(X, Y, Z, R, S);
+  const RegionLayout l = region_layout(X, Y, Z, R, S);   // (the tables come first: same offsets with or without the source buffer)
   const size_t start_off = l.counters + up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned));
   const long long v[16] = {(long long)l.slot_region, (long long)l.slot_pos, (long long)l.slot_seg, (long long)l.sorted,
                            (long long)l.lane_n, (long long)l.counters, (long long)start_off, l.nslots, l.nlanes, l.nreg,
@@ -689,9 +960,17 @@ void region_debug_layout(int X, int Y, int Z, long long R, int S, long long out[
   for (int i = 0; i < 16; ++i) out[i] = v[i];
 }
 
-template <int COUT, int NCM>
+// dynamic LDS of the kernels that stage whole texels (above 64 KB the function attribute has to allow it)
+template <typename K>
+static size_t full_tex_lds(K kernel, int cm) {
+  const size_t bytes = (size_t)kRWin * tex_stride(cm) * sizeof(float);
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+
+template <int COUT, int NCM, int NCU>
 static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st) {
-  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
+  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, NCU > 1);
   const BinScratch bs = bin_scratch(l, scratch);
   (void)hipMemsetAsync(bs.count, 0, 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)), st);
   const int nseg = num_segments(c.S, c.seg_len);
@@ -699,40 +978,52 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
   region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes);
-  region_fwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  const size_t lds = NCU > 1 ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;
+  region_fwd_kernel<COUT, NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   const int rays_per_block = 256 / nseg;        // (nseg <= 256: region_bwd_supported)
   region_fold_kernel<COUT><<<(int)((c.R + rays_per_block - 1) / rays_per_block), 256, 0, st>>>(
       c, bs, a.colour, a.depth, a.acc, a.disparity, rays_per_block);
 }
 
-template <int COUT, int NCM>
+template <int COUT, int NCM, int NCU>
 static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, void* scratch, hipStream_t st) {
-  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S);
+  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, NCU > 1);
   const BinScratch bs = bin_scratch(l, scratch);
-  region_bwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
-      g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
-      a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+  if constexpr (NCU == 1) {
+    region_bwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
+        g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
+        a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+  } else {
+    float4* src = (float4*)((char*)scratch + l.src);
+    const size_t lds = full_tex_lds(region_bwd_src_kernel<NCM, NCU>, COUT * NCM + 1);
+    region_bwd_src_kernel<NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(
+        g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.d_colour, a.d_depth, a.d_acc, a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs,
+        l.nreg, src);
+    // channel groups of 4: all of them for a feature gradient, only the one holding the density channel (the last) otherwise
+    constexpr int NGRP = (COUT * NCU + 1 + 3) / 4;
+    const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
+    region_bwd_dep_kernel<NCM, NCU><<<dim3((unsigned)(l.nreg + kGenericBlocks), (unsigned)ngrp), VOXE_REGION_BLOCK, 0, st>>>(
+        g, c, a.rays_o, a.rays_d, a.jitter, a.gpacked, bs, l.nreg, src, grp_begin);
+  }
 }
 
-#define VOXE_REGION_DISPATCH(FN, ...)                            \
-  do {                                                           \
-    if (c.attn) FN<1, 1>(__VA_ARGS__);                           \
-    else if (deg == 0) FN<3, 1>(__VA_ARGS__);                    \
-    else if (deg == 1) FN<3, 4>(__VA_ARGS__);                    \
-    else if (deg == 2) FN<3, 9>(__VA_ARGS__);                    \
-    else FN<3, 16>(__VA_ARGS__);                                 \
+#define VOXE_REGION_DISPATCH(FN, ...)                                                    \
+  do {                                                                                   \
+    if (c.attn) FN<1, 1, 1>(__VA_ARGS__);                                                \
+    else if (deg == 0) FN<3, 1, 1>(__VA_ARGS__);                                         \
+    else if (deg == 1) { if (diffuse) FN<3, 4, 1>(__VA_ARGS__); else FN<3, 4, 4>(__VA_ARGS__); }   \
+    else if (deg == 2) { if (diffuse) FN<3, 9, 1>(__VA_ARGS__); else FN<3, 9, 9>(__VA_ARGS__); }   \
+    else FN<3, 16, 1>(__VA_ARGS__);   /* (degree 3: diffuse only, region_bwd_supported) */ \
   } while (0)
 
 // forward of the space-binned path: fills the segment tables + per-segment states in `scratch` (the backward reuses them
 // when the caller says they belong to this call: VoxeRenderCfg::ray_state_valid) and the outputs that are not null
 void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
                        hipStream_t st) {
-  (void)diffuse;
   VOXE_REGION_DISPATCH(launch_fwd_region_t, g, c, a, scratch, st);
 }
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
                        hipStream_t st) {
-  (void)diffuse;
   VOXE_REGION_DISPATCH(launch_bwd_region_t, g, c, a, scratch, st);
 }
 
