@@ -136,14 +136,26 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
                                                         const float* __restrict__ rays_d, const float* __restrict__ jitter,
                                                         BinScratch bs, const int nreg) {
   const int lane = threadIdx.x;
-  const int nt = (int)((c.R + 63) / 64);
   const int nseg = num_segments(c.S, c.seg_len);
   const int nrb = gridDim.x / nseg;
   const int seg = blockIdx.x / nrb;
-  const int logical = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, 1, nt);
-  if (logical < 0) return;
-  const long long r = (long long)logical * 64 + lane;
-  if (r >= c.R) return;
+  // image-ordered launches (sparse / multi-view images): a wave is an 8x8 pixel tile, so its lanes cross the same regions
+  // at about the same samples and can share their counting atomics (below); unordered rays: 64 consecutive rays
+  const bool coherent = c.image_width > 0;
+  long long r;
+  if (coherent) {
+    const int ntx = (c.image_width + 7) >> 3, nty = (int)tile_rows_total(c, 8);
+    const int t = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, ntx, nty);
+    if (t < 0) return;
+    const int ty = t / ntx, tx = t - ty * ntx;
+    if (!tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r)) return;
+  } else {
+    const int nt = (int)((c.R + 63) / 64);
+    const int logical = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, 1, nt);
+    if (logical < 0) return;
+    r = (long long)logical * 64 + lane;
+    if (r >= c.R) return;
+  }
   RayCtx<3, 1, 1> rc;   // (origin, direction, depth generator, conservative in-AABB sample range)
   rc.init(g, c, r, rays_o, rays_d, jitter);
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
@@ -160,7 +172,34 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     const size_t sl = slot_of((size_t)lane_id, (unsigned)nslots, nlanes);
     bs.slot_region[sl] = cur | (cls << 24);
     bs.slot_seg[sl] = make_uint2((unsigned)r, (unsigned)k0 | ((unsigned)k_end << 16));
-    bs.slot_pos[sl] = atomicAdd(bs.count + cur * kLenClasses + cls, 1u);   // rank inside (region, class)
+    const unsigned key = cur * kLenClasses + cls;
+    unsigned pos;
+    if (coherent) {
+      // wave-aggregated ranking: the lanes that close a segment in the same loop trip group by counter; one returning
+      // atomic per group (its first lane) instead of one per lane -- the memory side retires ~20 G atomic requests/s and
+      // this pass is bound by exactly that (2.3 M segments on the 8-camera launch)
+      unsigned long long todo = __ballot(1);
+      int leader = lane;
+      unsigned rank = 0, size = 1;
+      while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)key, l);
+        const unsigned long long m = __ballot(key == key_l) & todo;
+        if (key == key_l) {
+          leader = l;
+          rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+          size = (unsigned)__popcll(m);
+        }
+        todo &= ~m;
+      }
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(bs.count + key, size);
+      base = (unsigned)__shfl((int)base, leader, 64);
+      pos = base + rank;
+    } else {
+      pos = atomicAdd(bs.count + key, 1u);   // rank inside (region, class)
+    }
+    bs.slot_pos[sl] = pos;
     ++nslots;
   };
   for (int k = k_lo; k <= k_hi; ++k) {
@@ -974,7 +1013,8 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   const BinScratch bs = bin_scratch(l, scratch);
   (void)hipMemsetAsync(bs.count, 0, 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)), st);
   const int nseg = num_segments(c.S, c.seg_len);
-  const int nb = blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64) * nseg;
+  const int nb = (c.image_width > 0 ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
+                                    : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64)) * nseg;
   region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
   region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes);
