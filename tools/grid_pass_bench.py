@@ -1,7 +1,10 @@
 """Whole-grid streaming passes of the SDS loop at BASELINE size ("judged directly against 8 TB/s"):
-density-correlation loss + gradient, TV loss + gradient, trilinear up-sampling, Adam, pack / fused grid step.
-Bytes = what the pass must move once (reads + writes of its operands); time = HIP-event mean over `reps` calls through
-the C ABI (the autograd wrappers of voxe_hip.ops included).   gpurun -- python tools/grid_pass_bench.py [side]"""
+density-correlation loss + gradient, TV loss + gradient, trilinear up-sampling, Adam.
+Bytes = what the pass must move once (reads + writes of its operands); time = HIP-event mean over `reps` back-to-back calls
+of the C ABI entry point with pre-allocated buffers (so the queue never runs dry: device time, not launch overhead; the
+rocprofv3 kernel stats of this script are in profiles/rNN_grid_kernel_stats.csv).
+    gpurun -- python tools/grid_pass_bench.py [side]"""
+import ctypes as C
 import os
 import sys
 
@@ -10,12 +13,13 @@ sys.path[:0] = [os.path.join(ROOT, "vox-e_amd"), ROOT]
 import torch  # noqa: E402
 
 from voxe_hip import ops  # noqa: E402
+from voxe_hip.runtime import check, lib, ptr, stream_ptr  # noqa: E402
 from voxe_hip.workload import random_grid  # noqa: E402
 
 PEAK = 8000.0
 
 
-def timed(fn, reps=30, warm=5):
+def timed(fn, reps=200, warm=10):
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,30 +37,41 @@ def main():
     dev = torch.device("cuda:0")
     dens, feat = (t.to(dev) for t in random_grid(side))
     n = side ** 3
+    L = lib()
+    st = stream_ptr(dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     rows = []
     # DCL (modules/sds_trainer.py:507-524): moments pass reads a, b; gradient pass reads a, b, writes d_a
-    a = dens.clone().requires_grad_(True)
     ref = dens.clone() * 0.9 + 0.05
-    rows.append(("dcl_moments + dcl_grad (loss + d/d sds_density)", 5 * n * 4, timed(lambda: ops.density_correlation_loss(a, ref))))
+    d_a = torch.empty_like(dens)
+    sc = torch.empty(L.voxe_dcl_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    rows.append(("dcl_moments + dcl_grad (loss + d/d sds_density)", 5 * n * 4,
+                 timed(lambda: check(L.voxe_dcl_fwd_bwd(ptr(dens), ptr(ref), n, 1.0, ptr(loss), ptr(d_a), 0, ptr(sc), sc.numel(), st), "dcl"))))
     # TV (modules/sds_trainer.py:563-567): reads the grid once (neighbours from cache), writes the gradient
-    for name, g in (("tv_kernel on densities [X,Y,Z,1]", dens), ("tv_kernel on features [X,Y,Z,3]", feat)):
-        gg = g.clone().requires_grad_(True)
-        rows.append((name + " (loss + gradient)", 2 * gg.numel() * 4, timed(lambda gg=gg: ops.tv_loss_on_grid(gg))))
+    for name, g in (("tv_kernel on densities / an attention grid [X,Y,Z,1]", dens), ("tv_kernel on features [X,Y,Z,3]", feat)):
+        d_g = torch.empty_like(g)
+        Cn = int(g.shape[-1])
+        sc2 = torch.empty(L.voxe_tv_scratch_bytes(side, side, side, Cn), dtype=torch.uint8, device=dev)
+        rows.append((name + " (loss + gradient)", 2 * g.numel() * 4,
+                     timed(lambda g=g, d_g=d_g, Cn=Cn, sc2=sc2: check(L.voxe_tv_fwd_bwd(ptr(g), side, side, side, Cn, 1.0, ptr(loss), ptr(d_g), 0,
+                                                                                        ptr(sc2), sc2.numel(), st), "tv"))))
     # coarse-to-fine up-sampling (thre3d_reprs/voxels.py:409-447): side/2 -> side
     half = side // 2
-    src_d, src_f = dens[:half, :half, :half].contiguous(), feat[:half, :half, :half].contiguous()
-    rows.append((f"upsample_kernel densities {half}^3 -> {side}^3", (half ** 3 + n) * 4, timed(lambda: ops.upsample_trilinear(src_d, (side,) * 3))))
-    rows.append((f"upsample_kernel features {half}^3 -> {side}^3", (half ** 3 + n) * 3 * 4, timed(lambda: ops.upsample_trilinear(src_f, (side,) * 3))))
+    for name, src in (("densities", dens[:half, :half, :half].contiguous()), ("features", feat[:half, :half, :half].contiguous())):
+        Cn = int(src.shape[-1])
+        dst = torch.empty((side, side, side, Cn), dtype=torch.float32, device=dev)
+        rows.append((f"upsample_kernel {name} {half}^3 -> {side}^3", (half ** 3 + n) * Cn * 4,
+                     timed(lambda src=src, dst=dst, Cn=Cn: check(L.voxe_upsample_trilinear(ptr(src), half, half, half, Cn, ptr(dst), side, side, side, st), "up"))))
     # Adam on the features tensor (modules/sds_trainer.py:200-203): RMW of param, m, v + read of the gradient
     p, g, m, v = feat.clone(), torch.randn_like(feat) * 1e-3, torch.zeros_like(feat), torch.zeros_like(feat)
     step = [0]
 
     def adam():
         step[0] += 1
-        ops.adam_step_(p, g, m, v, step[0], 1e-4)
+        check(L.voxe_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), 1e-4, 0.9, 0.999, 1e-8, step[0], st), "adam")
 
     rows.append(("adam_kernel on features", 7 * p.numel() * 4, timed(adam)))
-    print(f"# whole-grid passes at {side}^3 on {torch.cuda.get_device_name(0)}; peak {PEAK:.0f} GB/s (HBM3E spec)")
+    print(f"# whole-grid passes at {side}^3 on {torch.cuda.get_device_name(0)}; peak {PEAK:.0f} GB/s (HBM3E spec); device time per call")
     print(f"{'pass':62s} {'MB':>8s} {'ms':>8s} {'GB/s':>8s} {'of peak':>8s}")
     for name, nbytes, ms in rows:
         gbs = nbytes / (ms * 1e-3) / 1e9

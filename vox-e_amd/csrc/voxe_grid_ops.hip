@@ -222,6 +222,65 @@ __global__ __launch_bounds__(256) void tv_kernel(const float* __restrict__ grid,
   block_sum<3>(s, partial + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 3);
 }
 
+// The same pass with FOUR consecutive elements per thread (rows of Z * C floats that are a multiple of 4: 16-byte aligned
+// vectors that never straddle a y-row): 7 vector loads per 4 elements (the element vector, its x / y neighbours, the next
+// and the previous vector of the row for the z neighbours) instead of 28 scalar ones.  C = 1 (densities, attention grids)
+// and C = 3 (SH-0 features); everything else takes tv_kernel.  Same per-element arithmetic.
+template <int C>
+__global__ __launch_bounds__(256) void tv_kernel_v4(const float* __restrict__ grid, int X, int Y, int Z, float gx, float gy,
+                                                    float gz, double* __restrict__ partial, float* __restrict__ d_grid,
+                                                    int accumulate) {
+  static_assert(C == 1 || C == 3, "vector TV pass: 1 or 3 channels");
+  const unsigned sy = (unsigned)Z * C, plane = (unsigned)Y * sy, sy4 = sy >> 2, plane4 = plane >> 2;
+  double s[3] = {0, 0, 0};
+  for (unsigned x = blockIdx.y; x < (unsigned)X; x += gridDim.y) {
+    const float4* __restrict__ base4 = reinterpret_cast<const float4*>(grid + (long long)x * plane);
+    for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < plane4; q += gridDim.x * 256u) {
+      const unsigned y = q / sy4, zq = q - y * sy4;            // zq: vector index inside the row
+      const float4 c4 = base4[q];
+      const float v[4] = {c4.x, c4.y, c4.z, c4.w};
+      float xp[4] = {0, 0, 0, 0}, xm[4] = {0, 0, 0, 0}, yp[4] = {0, 0, 0, 0}, ym[4] = {0, 0, 0, 0};
+      const bool hxp = x + 1 < (unsigned)X, hxm = x > 0, hyp = y + 1 < (unsigned)Y, hym = y > 0;
+      if (hxp) { const float4 t = base4[q + plane4]; xp[0] = t.x; xp[1] = t.y; xp[2] = t.z; xp[3] = t.w; }
+      if (hxm) { const float4 t = (base4 - plane4)[q]; xm[0] = t.x; xm[1] = t.y; xm[2] = t.z; xm[3] = t.w; }
+      if (hyp) { const float4 t = base4[q + sy4]; yp[0] = t.x; yp[1] = t.y; yp[2] = t.z; yp[3] = t.w; }
+      if (hym) { const float4 t = base4[q - sy4]; ym[0] = t.x; ym[1] = t.y; ym[2] = t.z; ym[3] = t.w; }
+      float4 nx = make_float4(0, 0, 0, 0), pv = make_float4(0, 0, 0, 0);
+      if (zq + 1 < sy4) nx = base4[q + 1];
+      if (zq > 0) pv = base4[q - 1];
+      // element j's z neighbours are j +- C floats away
+      float zp[4], zm[4];
+      if (C == 1) {
+        zp[0] = v[1]; zp[1] = v[2]; zp[2] = v[3]; zp[3] = nx.x;
+        zm[0] = pv.w; zm[1] = v[0]; zm[2] = v[1]; zm[3] = v[2];
+      } else {
+        zp[0] = v[3]; zp[1] = nx.x; zp[2] = nx.y; zp[3] = nx.z;
+        zm[0] = pv.y; zm[1] = pv.z; zm[2] = pv.w; zm[3] = v[0];
+      }
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned z = (zq * 4u + (unsigned)j) / (unsigned)C;
+        float gj = 0.0f;
+        if (hxp) { const float df = xp[j] - v[j]; s[0] += fabsf(df); gj -= sgnf(df) * gx; }
+        if (hxm) { const float df = v[j] - xm[j]; gj += sgnf(df) * gx; }
+        if (hyp) { const float df = yp[j] - v[j]; s[1] += fabsf(df); gj -= sgnf(df) * gy; }
+        if (hym) { const float df = v[j] - ym[j]; gj += sgnf(df) * gy; }
+        if (z + 1 < (unsigned)Z) { const float df = zp[j] - v[j]; s[2] += fabsf(df); gj -= sgnf(df) * gz; }
+        if (z > 0) { const float df = v[j] - zm[j]; gj += sgnf(df) * gz; }
+        g[j] = gj;
+      }
+      if (d_grid) {
+        float4* __restrict__ out4 = reinterpret_cast<float4*>(d_grid + (long long)x * plane) + q;
+        float4 o = make_float4(g[0], g[1], g[2], g[3]);
+        if (accumulate) { const float4 old = *out4; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *out4 = o;
+      }
+    }
+  }
+  block_sum<3>(s, partial + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * 3);
+}
+
 __global__ __launch_bounds__(256) void tv_finalize_kernel(const double* __restrict__ partial,
                                                           int nblocks, double cx, double cy, double cz,
                                                           float* __restrict__ loss_out) {
@@ -238,7 +297,7 @@ __global__ __launch_bounds__(256) void tv_finalize_kernel(const double* __restri
 
 // (r03: 16384 blocks instead of 1024 -- with 47 dependent-latency iterations per thread the pass ran at 0.9 TB/s; the
 //  partial sums stay per block and are folded in a fixed order: the loss is bit-reproducible)
-constexpr int kTvBlocks = 16384;
+constexpr int kTvBlocks = 8192;
 size_t tv_scratch_bytes(int, int, int, int) { return sizeof(double) * (kTvBlocks * 3 + 8); }
 
 void launch_tv(const float* grid, int X, int Y, int Z, int C, float grad_scale, float* loss_out,
@@ -255,6 +314,15 @@ void launch_tv(const float* grid, int X, int Y, int Z, int C, float grad_scale, 
   const long long plane = (long long)Y * Z * C;
   const int bx = (int)((plane + 255) / 256 < 128 ? (plane + 255) / 256 : 128);
   const int by = X < kTvBlocks / bx ? X : kTvBlocks / bx;
+  if ((C == 1 || C == 3) && ((long long)Z * C) % 4 == 0 && ((uintptr_t)grid % 16) == 0 && (!d_grid || ((uintptr_t)d_grid % 16) == 0)) {
+    const long long plane4 = plane / 4;
+    const int vx = (int)((plane4 + 255) / 256 < 64 ? (plane4 + 255) / 256 : 64);
+    const int vy = X < kTvBlocks / vx ? X : kTvBlocks / vx;
+    if (C == 1) tv_kernel_v4<1><<<dim3(vx, vy), 256, 0, st>>>(grid, X, Y, Z, gx, gy, gz, partial, d_grid, accumulate);
+    else tv_kernel_v4<3><<<dim3(vx, vy), 256, 0, st>>>(grid, X, Y, Z, gx, gy, gz, partial, d_grid, accumulate);
+    tv_finalize_kernel<<<1, 256, 0, st>>>(partial, vx * vy, cx, cy, cz, loss_out);
+    return;
+  }
   const dim3 gridsz(bx, by);
   if (C == 1) tv_kernel<1><<<gridsz, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
   else if (C == 3) tv_kernel<3><<<gridsz, 256, 0, st>>>(grid, X, Y, Z, C, gx, gy, gz, partial, d_grid, accumulate);
