@@ -379,34 +379,45 @@ __device__ __forceinline__ void up_axis(int out_i, int in_n, int out_n, int& i0,
   l0 = 1.0f - l1;
 }
 
-// Thread mapping like tv_kernel: blockIdx.y = output x-plane, the Y2 * Z2 * C elements of the plane (contiguous) over
-// blockIdx.x / threadIdx.x; 32-bit index arithmetic (64-bit div / mod chains kept this pass at 0.6 TB/s before, r03).
+// Thread mapping: blockIdx.y = output x-plane, blockIdx.x / threadIdx.x = the Y2 * Z2 voxels of the plane; one thread per
+// output VOXEL computes the three axis interpolations once and loops over the C channels (contiguous per corner) -- the
+// index math (float ops + 64-bit div / mod per ELEMENT before r03) was what bounded this pass, not its bytes.
+template <int CT>   // channel count known at compile time (1, 3) or 0: run-time C
 __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__ src, int X, int Y,
-                                                       int Z, int C, float* __restrict__ dst, int X2,
+                                                       int Z, int C_rt, float* __restrict__ dst, int X2,
                                                        int Y2, int Z2) {
-  const unsigned sy2 = (unsigned)Z2 * (unsigned)C, plane2 = (unsigned)Y2 * sy2;
+  const int C = CT > 0 ? CT : C_rt;
+  const unsigned plane2 = (unsigned)Y2 * (unsigned)Z2;
   const unsigned e = blockIdx.x * 256u + threadIdx.x;
   if (e >= plane2) return;
   const int x = blockIdx.y;
-  const unsigned yq = e / sy2, zc = e - yq * sy2, zq = zc / (unsigned)C;
-  const int y = (int)yq, z = (int)zq, ch = (int)(zc - zq * (unsigned)C);
+  const int y = (int)(e / (unsigned)Z2), z = (int)(e - (unsigned)y * (unsigned)Z2);
   int x0, x1, y0, y1, z0, z1;
   float lx0, lx1, ly0, ly1, lz0, lz1;
   up_axis(x, X, X2, x0, x1, lx0, lx1);
   up_axis(y, Y, Y2, y0, y1, ly0, ly1);
   up_axis(z, Z, Z2, z0, z1, lz0, lz1);
-  auto S = [&](int ix, int iy, int iz) { return src[(((long long)ix * Y + iy) * Z + iz) * C + ch]; };
-  const float v = lx0 * (ly0 * (lz0 * S(x0, y0, z0) + lz1 * S(x0, y0, z1)) +
-                         ly1 * (lz0 * S(x0, y1, z0) + lz1 * S(x0, y1, z1))) +
-                  lx1 * (ly0 * (lz0 * S(x1, y0, z0) + lz1 * S(x1, y0, z1)) +
-                         ly1 * (lz0 * S(x1, y1, z0) + lz1 * S(x1, y1, z1)));
-  dst[(long long)x * plane2 + e] = v;
+  auto at = [&](int ix, int iy, int iz) { return src + (((long long)ix * Y + iy) * Z + iz) * C; };
+  const float* __restrict__ p000 = at(x0, y0, z0); const float* __restrict__ p001 = at(x0, y0, z1);
+  const float* __restrict__ p010 = at(x0, y1, z0); const float* __restrict__ p011 = at(x0, y1, z1);
+  const float* __restrict__ p100 = at(x1, y0, z0); const float* __restrict__ p101 = at(x1, y0, z1);
+  const float* __restrict__ p110 = at(x1, y1, z0); const float* __restrict__ p111 = at(x1, y1, z1);
+  float* __restrict__ out = dst + ((long long)x * plane2 + e) * C;
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) {
+    // (the same expression as before, operand for operand)
+    out[ch] = lx0 * (ly0 * (lz0 * p000[ch] + lz1 * p001[ch]) + ly1 * (lz0 * p010[ch] + lz1 * p011[ch])) +
+              lx1 * (ly0 * (lz0 * p100[ch] + lz1 * p101[ch]) + ly1 * (lz0 * p110[ch] + lz1 * p111[ch]));
+  }
 }
 
 void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, int X2, int Y2, int Z2,
                      hipStream_t st) {
-  const long long plane2 = (long long)Y2 * Z2 * C;
-  upsample_kernel<<<dim3((unsigned)((plane2 + 255) / 256), (unsigned)X2), 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
+  const long long plane2 = (long long)Y2 * Z2;
+  const dim3 gridsz((unsigned)((plane2 + 255) / 256), (unsigned)X2);
+  if (C == 1) upsample_kernel<1><<<gridsz, 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
+  else if (C == 3) upsample_kernel<3><<<gridsz, 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
+  else upsample_kernel<0><<<gridsz, 256, 0, st>>>(src, X, Y, Z, C, dst, X2, Y2, Z2);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -494,10 +494,14 @@ __global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch b
   const unsigned n = live ? bs.lane_n[lane] : 0u;
   float4 pa[kSlotsPerLane];
   float2 pb[kSlotsPerLane];
+  // slots no lane of the wave uses (mean use: 4 of 16) are skipped with a wave-uniform test: they are the identity of the
+  // fold (T = 1, P = 0), so every loop below may pass over them
+  unsigned long long used[kSlotsPerLane];
 #pragma unroll
   for (int j = 0; j < kSlotsPerLane; ++j) {
     pa[j] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     pb[j] = make_float2(0.0f, 0.0f);
+    used[j] = __ballot((unsigned)j < n);
     if ((unsigned)j < n) {
       const size_t sl = slot_of((size_t)lane, (unsigned)j, nlanes);
       pa[j] = bs.part[2 * sl];
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch b
   float Tl = 1.0f, U[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int j = kSlotsPerLane - 1; j >= 0; --j) {
+    if (used[j] == 0ull) continue;
     U[0] = fmaf(pa[j].x, U[0], pa[j].y);
     U[1] = fmaf(pa[j].x, U[1], pa[j].z);
     U[2] = fmaf(pa[j].x, U[2], pa[j].w);
@@ -537,11 +542,12 @@ __global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch b
   {
     float t = T;
 #pragma unroll
-    for (int j = 0; j < kSlotsPerLane; ++j) { Tfront[j] = t; t = t * pa[j].x; }
+    for (int j = 0; j < kSlotsPerLane; ++j) { Tfront[j] = t; if (used[j] != 0ull) t = t * pa[j].x; }
   }
   float V[5] = {B[0], B[1], B[2], B[3], B[4]};
 #pragma unroll
   for (int j = kSlotsPerLane - 1; j >= 0; --j) {
+    if (used[j] == 0ull) continue;
     V[0] = fmaf(pa[j].x, V[0], pa[j].y);
     V[1] = fmaf(pa[j].x, V[1], pa[j].z);
     V[2] = fmaf(pa[j].x, V[2], pa[j].w);
