@@ -176,7 +176,10 @@ template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE, int KL
 #ifndef VOXE_TILE_LB
 #define VOXE_TILE_LB 3
 #endif
-__global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL > 8) ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
+#ifndef VOXE_TILE_WIDE_FROM
+#define VOXE_TILE_WIDE_FROM 9     // windows at least this wide get the relaxed register budget (2 waves per SIMD)
+#endif
+__global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE_FROM) ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
