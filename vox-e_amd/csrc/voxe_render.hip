@@ -407,6 +407,10 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(DevGrid g, DevCfg c,
 //   T_start(s) = prod_{s' < s} Tseg(s'),  colour = sum_s T_start(s) csum(s), ...
 // The combine pass also emits the per-ray segment-start states the segmented backward consumes.
 // (The forward integrates every sample whatever term_eps says: the switch only truncates gradients, see voxe.h.)
+// Tried and measured as nulls (r03, 400x400: 0.246 ms either way): two samples per loop trip with both gathers (16 texel
+// loads) in flight before either sample's arithmetic -- the kernel is not short of memory-level parallelism inside a wave;
+// fewer registers for more resident waves (launch bounds 6 / 8: 0.284 / 0.438 ms, spills).  PMC: VALU issue 0.47, 3.4 of 5
+// possible waves per SIMD resident on average (12 k non-empty one-wave blocks = 2.3 rounds), waves wait 64 % of their time.
 // segbuf layout: [segment][component][ray], components (Tseg, csum[COUT], asum, dsum).
 // ------------------------------------------------------------------------------------------------
 template <int COUT, int NCM, int NCU>

@@ -158,6 +158,31 @@ struct RayCtx {
   }
 };
 
+// The 4-channel texel path of gather<>() in two halves, so that a kernel can put the loads of TWO samples in flight before
+// it interpolates either (render_fwd_seg_kernel): the 8 corner texels (16 bytes each) and their interpolation --
+// (r, g) and (b, sigma) pairs through v_pk_fma_f32 (2 FMAs per issue slot), corner order k = x + 2 y + 4 z.
+__device__ __forceinline__ void load_texels4(const float* __restrict__ packed, const CellAddr& ad, float4 (&t)[8]) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    t[k] = reinterpret_cast<const float4*>(packed)[ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz];
+}
+__device__ __forceinline__ void interp_texels4(const float4 (&t)[8], const Cell& cell, float& f0, float& f1, float& f2, float& v) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  float wxy[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) wxy[k] = cell.w[0][k & 1] * cell.w[1][k >> 1];
+  v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = wxy[k & 3] * cell.w[2][k >> 2];
+    const v2f ww = {w, w};
+    const v2f a = {t[k].x, t[k].y}, b = {t[k].z, t[k].w};
+    rg = __builtin_elementwise_fma(a, ww, rg);
+    bs = __builtin_elementwise_fma(b, ww, bs);
+  }
+  f0 = rg.x; f1 = rg.y; f2 = bs.x; v = bs.y;
+}
+
 // Interpolate density + features at the 8 corners of a Cell and evaluate
 // v = interp(pre-activated density), rad_c = sum_j basis_j * interp(coef_cj)   (process.py:45-78, voxels.py:307-332).
 // Values are interpolated with FMAs (only the index math has to round like the reference).
@@ -174,22 +199,9 @@ __device__ __forceinline__ void gather(const DevGrid& g, const float* __restrict
   for (int i = 0; i < COUT * NCU; ++i) f[i] = 0.0f;
   v = 0.0f;
   if constexpr (C == 4) {
-    // packed math: (r,g) and (b,sigma) pairs go through v_pk_fma_f32 (2 FMAs per issue slot)
-    typedef float v2f __attribute__((ext_vector_type(2)));
     float4 t[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k)
-      t[k] = reinterpret_cast<const float4*>(packed)[ad.base + (k & 1) * ad.sx + ((k >> 1) & 1) * ad.sy + (k >> 2) * ad.sz];
-    v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float w = wxy[k & 3] * cell.w[2][k >> 2];
-      const v2f ww = {w, w};
-      const v2f a = {t[k].x, t[k].y}, b = {t[k].z, t[k].w};
-      rg = __builtin_elementwise_fma(a, ww, rg);
-      bs = __builtin_elementwise_fma(b, ww, bs);
-    }
-    f[0] = rg.x; f[1] = rg.y; f[2] = bs.x; v = bs.y;
+    load_texels4(packed, ad, t);
+    interp_texels4(t, cell, f[0], f[1], f[2], v);
   } else if constexpr (C == 2) {
     float2 t[8];
 #pragma unroll
