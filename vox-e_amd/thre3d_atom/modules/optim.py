@@ -148,11 +148,9 @@ class FusedGridAdam(torch.optim.Optimizer):
         train_d, train_f = self._train
         st_d = self._state_of(self._dens) if train_d else None
         st_f = self._state_of(self._feat) if train_f else None
-        for st in (st_d, st_f):
-            if st is not None:
-                st["step"] += 1
-        step_d = st_d["step"] if st_d is not None else st_f["step"]
-        step_f = st_f["step"] if st_f is not None else step_d
+        # (the counters move only once the call went through: a raised VoxeError leaves the optimiser as it was)
+        step_d = (st_d["step"] if st_d is not None else st_f["step"]) + 1
+        step_f = (st_f["step"] if st_f is not None else step_d - 1) + 1
         ws = self.workspace
         if ws.sibling is None:
             ws.sibling = _ops.Workspace()
@@ -162,6 +160,9 @@ class FusedGridAdam(torch.optim.Optimizer):
                          None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
                          None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]), step_d, step_f, group["lr"],
                          losses, rng, beta1=beta1, beta2=beta2, eps=group["eps"], zero_gradient_first=fresh)
+        for st in (st_d, st_f):
+            if st is not None:
+                st["step"] += 1
         d.clean_ptr = ws.buf.data_ptr()
         d.dirty, d.layout = False, _ops.abi.GRAD_ANY
 

@@ -70,6 +70,7 @@ class Workspace:
         # deferred-gradient mode (FusedGridAdam): backward passes of renders through this workspace (or its sibling)
         # LEAVE the grid gradient in this workspace's gradient region instead of returning .grad tensors
         self.deferred: Optional["DeferredGrad"] = None
+        self.recon_scratch: dict = {}   # device scratch of recon_step_ (rays, targets, outputs of one fused iteration)
 
     def for_differentiable_forward(self, version=None) -> "Workspace":
         """the workspace a differentiable forward should run in.  A pending forward whose backward never came (the caller
@@ -663,7 +664,7 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
     rs.exp_avg_densities, rs.exp_avg_sq_densities = ptr(m_d), ptr(v_d)
     rs.exp_avg_features, rs.exp_avg_sq_features = ptr(m_f), ptr(v_f)
     rs.losses = ptr(losses)
-    holder = scratch_holder if scratch_holder is not None else workspace.__dict__.setdefault("_recon_scratch", {})
+    holder = scratch_holder if scratch_holder is not None else workspace.recon_scratch
     with torch.cuda.device(device):
         nbytes = L.voxe_workspace_bytes(C.byref(g), C.byref(c), int(batch))
         had = workspace.buf
