@@ -272,3 +272,45 @@ def test_fused_grid_adam_counts_steps_per_parameter():
         assert opt.state[fg.densities]["step"] == 4 and opt.state[fg.features]["step"] == 3
     torch.testing.assert_close(fg.densities.detach(), rg.densities.detach(), rtol=1e-4, atol=2e-6)
     torch.testing.assert_close(fg.features.detach(), rg.features.detach(), rtol=1e-4, atol=2e-6)
+
+
+def test_render_route_and_clock_probe(monkeypatch):
+    """voxe_render_route names the kernels a render resolves to (it is part of the ray-state key: forward and backward must
+    agree), also when a tuning switch flips between the two calls; voxe_clock_probe returns a plausible shader clock"""
+    import ctypes as C
+
+    from voxe_hip.runtime import lib
+
+    grid = _grid(32)
+    spec = gh.spec_of(grid)
+    dens, feat = gh.t(grid.densities), gh.t(grid.features)
+
+    def route(R, **over):
+        cfg = make_render_cfg(64, NEAR, FAR, white_bkgd=True)
+        g, c = ops._descs(spec, gh.params_of(cfg, **over), dens, feat, 0, 0, False)
+        return lib().voxe_render_route(C.byref(g), C.byref(c), R)
+
+    assert route(96 * 96, image_width=96) == abi.ROUTE_TILE
+    assert route(20000) == abi.ROUTE_REGION
+    assert route(3000) == abi.ROUTE_PACKED_SCATTER
+    assert route(96 * 96, image_width=96, deterministic=True) == abi.ROUTE_DETERMINISTIC
+    assert route(0) == abi.ROUTE_NONE
+    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
+    assert route(20000) == abi.ROUTE_PACKED_SCATTER
+    # the switch flipped between a forward and its backward: the states of the other route are NOT taken for valid -- the
+    # backward re-marches and the gradients still equal the oracle's
+    monkeypatch.delenv("VOXE_REGION_MIN_RAYS")
+    o, d = _rays(150, 5)
+    sel = np.random.default_rng(1).permutation(o.shape[0])[:17000]
+    o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
+    cfg = make_render_cfg(64, NEAR, FAR, white_bkgd=True)
+    dt, ft = gh.t(grid.densities, True), gh.t(grid.features, True)
+    colour = ops.render(spec, gh.params_of(cfg), dt, ft, gh.t(o), gh.t(d))[0]          # forward: space-binned route
+    gc_ = np.random.default_rng(2).standard_normal((o.shape[0], 3)).astype(np.float32)
+    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")                                  # backward: line-dense scatter
+    (colour * gh.t(gc_)).sum().backward()
+    torch.cuda.synchronize()
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc_)
+    assert rel_l2(gh.n(dt.grad), rd) < 1e-4 and rel_l2(gh.n(ft.grad), rf) < 1e-4
+    hz = ops.clock_probe(gh.DEV)
+    assert 1.0e9 < hz < 3.0e9, hz
