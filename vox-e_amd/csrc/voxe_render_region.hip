@@ -62,6 +62,11 @@ constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient win
 #define VOXE_REGION_SLOTS 16
 #endif
 constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, depth segment)
+#ifndef VOXE_REGION_SH_WC
+#define VOXE_REGION_SH_WC 7        // gradient channels per deposit pass of a view-dependent grid (window: WC x 5.9 KB of LDS).
+                                   // Swept (32 400 random rays, backward ms, SH-1 / SH-2): 4 -> 1.21 / 2.56, 7 -> 1.10 / 2.48 (13 = 2 / 4
+                                   // passes instead of 4 / 7: fewer footprint re-computations), 13 -> 1.22 / 3.27 (77 KB: 2 blocks per CU)
+#endif
 #ifndef VOXE_REGION_BWD_TEX
 #define VOXE_REGION_BWD_TEX 1      // backward: stage the region's texels in LDS too (0: gather them from L1 / L2)
 #endif
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
 // exactly like SH-0, and every gradient channel is one of them times a constant.
 //   phase 1  region_bwd_src_kernel   one block per region, the region's WHOLE texels in LDS: the march of
 //            region_bwd_kernel up to the 4 sources of every sample -> src[ray * S + k] (16 bytes per sample);
-//   phase 2  region_bwd_dep_kernel   one block per (region, group of 4 gradient channels): footprints only (no gather),
+//   phase 2  region_bwd_dep_kernel   one block per (region, group of 7 gradient channels): footprints only (no gather),
 //            sources x basis -> the same 9x9x9 double window as SH-0, one dense flush per (region, group).
 template <int NCM, int NCU>
 __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
@@ -823,7 +828,7 @@ template <int NCM, int NCU>
 __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_dep_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ jitter,
     float* __restrict__ gpacked, BinScratch bs, const int nreg, const float4* __restrict__ src, const int grp_begin) {
-  constexpr int COUT = 3, CM = COUT * NCM + 1, NG = COUT * NCU + 1, WC = 4;
+  constexpr int COUT = 3, CM = COUT * NCM + 1, NG = COUT * NCU + 1, WC = VOXE_REGION_SH_WC;
   __shared__ double win[WC * kRPlane];
   const int tid = threadIdx.x;
   const unsigned region = min(blockIdx.x, (unsigned)nreg);
@@ -1045,8 +1050,8 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
     region_bwd_src_kernel<NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(
         g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.d_colour, a.d_depth, a.d_acc, a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs,
         l.nreg, src);
-    // channel groups of 4: all of them for a feature gradient, only the one holding the density channel (the last) otherwise
-    constexpr int NGRP = (COUT * NCU + 1 + 3) / 4;
+    // channel groups of VOXE_REGION_SH_WC: all of them for a feature gradient, only the one holding the density channel (the last) otherwise
+    constexpr int NGRP = (COUT * NCU + 1 + VOXE_REGION_SH_WC - 1) / VOXE_REGION_SH_WC;
     const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
     region_bwd_dep_kernel<NCM, NCU><<<dim3((unsigned)(l.nreg + kGenericBlocks), (unsigned)ngrp), VOXE_REGION_BLOCK, 0, st>>>(
         g, c, a.rays_o, a.rays_d, a.jitter, a.gpacked, bs, l.nreg, src, grp_begin);
