@@ -389,3 +389,22 @@ def test_nerf_blender_converter_round_trip(tmp_path):
     assert abs(ds.camera_bounds.near - 1.8) < 1e-6 and abs(ds.camera_bounds.far - 6.6) < 1e-6
     for i in range(3):
         np.testing.assert_allclose(ds.poses[i].numpy(), poses[i][:3, :4].astype(np.float32), atol=1e-6)
+
+
+def test_newest_pmc_summary_belongs_to_these_kernel_sources():
+    """bench.py combines counter values only with timings of the kernels they were collected on: the newest committed
+    profiles/*_pmc_summary.json must carry the hash of THIS tree's vox-e_amd/csrc/* + include/voxe.h (tools/pmc_to_json.py
+    stamps it; a kernel edit without a fresh PMC run makes the bench line say "stale" -- and fails here)"""
+    import json
+    import re
+
+    from voxe_hip.build import source_hash
+
+    h = source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and h == source_hash()
+    prof = os.path.join(ROOT, "profiles")
+    newest = sorted(f for f in os.listdir(prof) if f.endswith("_pmc_summary.json"))[-1]
+    summary = json.load(open(os.path.join(prof, newest)))
+    assert summary.get("source_hash") == h, f"{newest} was collected on other kernel sources: re-run tools/gpu_pmc.sh + tools/pmc_to_json.py"
+    key = [k for k in summary["kernels"] if k.startswith("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0, 8")]
+    assert key and {"FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE"} <= set(summary["kernels"][key[0]])
