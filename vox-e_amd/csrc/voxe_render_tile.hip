@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
     const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit, const int grp_begin,
     const int ngrp, float4* __restrict__ sample_src, unsigned long long* __restrict__ gdet = nullptr,
-    float* __restrict__ det_scale = nullptr, const int det_phase = 0) {
+    float* __restrict__ det_scale = nullptr, const int det_phase = 0, const float fit_m = 5.5f) {
   // DET: det_phase 0 measures max |contribution| per channel class into det_scale[0..1] (features, density) as
   // float bits (atomicMax: order independent); det_phase 1 deposits with the power-of-two scales det_scale[2..3].
   static_assert(!DET || MODE == 0, "the deterministic mode is the single-kernel backward");
@@ -247,18 +247,39 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
       const int N[3] = {g.X, g.Y, g.Z};
       const float zref = readlane_f32(rc.dg.zlin(ke), 0);
-      float full = 0.0f, halfx = 0.0f, halfy = 0.0f;  // lateral extent (voxels) of the tile / of its halves
+      // Extent of the tile against the window (r03: the march axis has its own bound).  The window is a ring of kRing layers
+      // along the march axis m; laterally it is KL wide.  A pass fits when (i) its lateral extent leaves room for the 2-wide
+      // footprints (KL - 2.5) and (ii) the lanes' spread ALONG m at one sample index fits the ring next to the two layers of a
+      // footprint and the jitter: `fit_m` layers.  r01 / r02 held all three axes against KL - 2.5: oblique views overflowed the
+      // 6-layer ring -- 5 - 11 % of their samples took the 32 global atomics of the fallback at 128 - 266 pixels (0.78 vs
+      // 0.31 ms for the same 200x200 image from two cameras).  Splitting an oblique tile costs blocks instead; which is cheaper
+      // depends on how full the chip is, so the host picks fit_m by launch size (launch_bwd_tile_t; profiles/r03_ab_fit_m.txt).
+      float d0[3], ex3[3], ey3[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         const float s = g.scale[a] * 0.5f * (float)N[a];
-        const float d0 = readlane_f32(rc.d[a], 0), dx = readlane_f32(rc.d[a], 1) - d0, dy = readlane_f32(rc.d[a], 8) - d0;
-        const float k = fabsf(s) * zref, ex = fabsf(dx) * k, ey = fabsf(dy) * k;
-        full = fmaxf(full, 7.0f * (ex + ey));
-        halfx = fmaxf(halfx, 3.0f * ex + 7.0f * ey);
-        halfy = fmaxf(halfy, 7.0f * ex + 3.0f * ey);
+        const float da = readlane_f32(rc.d[a], 0);
+        d0[a] = fabsf(da * s);
+        ex3[a] = fabsf((readlane_f32(rc.d[a], 1) - da) * s * zref);
+        ey3[a] = fabsf((readlane_f32(rc.d[a], 8) - da) * s * zref);
       }
-      constexpr float kFit = (float)KL - 2.5f;   // lateral extent (voxels) a pass may have: 5.5 for the 8-wide window
-      if (full > kFit) split = (fminf(halfx, halfy) <= kFit) ? (halfx <= halfy ? 1 : 2) : 3;
+      const int m = (d0[0] >= d0[1] && d0[0] >= d0[2]) ? 0 : ((d0[1] >= d0[2]) ? 1 : 2);
+      constexpr float kFit = (float)KL - 2.5f;              // lateral extent (voxels) a pass may have: 5.5 for the 8-wide window
+      auto fits_pass = [&](float wx, float wy) {            // a pass of (wx + 1) x (wy + 1) pixels
+        float lat = 0.0f, alongm = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float e = wx * ex3[a] + wy * ey3[a];
+          if (a == m) alongm = e; else lat = fmaxf(lat, e);
+        }
+        return lat <= kFit && alongm <= fit_m;
+      };
+      if (!fits_pass(7.0f, 7.0f)) {
+        const bool hx = fits_pass(3.0f, 7.0f), hy = fits_pass(7.0f, 3.0f);
+        const float sx = ex3[0] + ex3[1] + ex3[2], sy = ey3[0] + ey3[1] + ey3[2];
+        if (hx && hy) split = (sx >= sy) ? 1 : 2;           // halve along the pixel axis that spreads the tile more
+        else split = hx ? 1 : (hy ? 2 : 3);
+      }
     }
   }
   auto run_pass = [&](const bool alive_q, const int centre_lane) {
@@ -938,10 +959,20 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   const long long tiles = ntx8 * nty8 * num_segments(c.S, c.seg_len) * ngrp;
   const int qsplit = env_q ? (env_q == 4 ? 4 : 1) : (tiles <= 11000 ? 4 : 1);
   const int nb = blocks_for_tiles(c.map_mode, ntx8, nty8) * num_segments(c.S, c.seg_len) * qsplit * ngrp;
+  // Bound on a pass's spread along the march axis (layers; the kernel's split decision).  5.5 = the r02 behaviour (never split
+  // because of the ring).  Swept over five cameras (tools/ab_cam_lib.sh, profiles/r03_ab_fit_m.txt): while the parts of a tile
+  // run as sibling blocks on an under-filled chip, splitting oblique tiles beats their ring overflows by up to 1.7x (4.0
+  // best at 266 px, 4.5 - 5.0 at 128 - 200 px in the 10-wide window); mid-size launches 4.5; a full chip (400x400: 20 000
+  // tile-segments) prefers the overflow of ~1 % of the samples to 1.5x the blocks.
+  static const float env_fit_m = [] { const char* e = getenv("VOXE_TILE_FIT_M"); return e ? (float)atof(e) : 0.0f; }();
+  const long long tile_segs = ntx8 * nty8 * num_segments(c.S, c.seg_len);
+  const int side_for_kl = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
+  const bool wide = (float)side_for_kl >= 0.75f * (float)c.image_width;
+  const float fit_m = env_fit_m > 0.0f ? env_fit_m : (qsplit == 4 ? (wide ? 4.5f : 4.0f) : (tile_segs <= 16000 ? 4.5f : 5.5f));
 #define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
   render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE, KL><<<NB, 64, 0, st>>>(                    \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src))
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src), nullptr, nullptr, 0, fit_m)
   if constexpr (NGRP == 1) {
     if (a.gdet) {   // deterministic mode: measure the maxima, derive the scales, deposit in fixed point, convert
       const long long n = (long long)g.X * g.Y * g.Z * (COUT * NCM + 1);
@@ -949,7 +980,7 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
       for (int phase = 0; phase < 2; ++phase) {
         render_bwd_tile_kernel<COUT, NCM, NCU, true, true, 0, 8, true><<<nb, 64, 0, st>>>(
             g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc,
-            a.ray_state, a.gpacked, qsplit, 0, 1, nullptr, a.gdet, a.det_scale, phase);
+            a.ray_state, a.gpacked, qsplit, 0, 1, nullptr, a.gdet, a.det_scale, phase, fit_m);
         if (phase == 0) det_scale_kernel<<<1, 1, 0, st>>>(a.det_scale);
       }
       det_finalize_kernel<<<4096, 256, 0, st>>>(a.gdet, a.gpacked, n, COUT * NCM + 1, a.det_scale);
