@@ -211,6 +211,116 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
   }
 }
 
+// C == 4, linear gradient layout, 4 consecutive voxels per thread: every access is a 16-byte one (the 3-float features of
+// 4 voxels are 3 float4; the per-voxel kernel above reads and writes them as nine 4-byte accesses of stride 12).  Same
+// arithmetic per element.
+#ifndef VOXE_GA_V4
+#define VOXE_GA_V4 1
+#endif
+#ifndef VOXE_GA_FLIP
+#define VOXE_GA_FLIP 1
+#endif
+#ifndef VOXE_GA_NT
+#define VOXE_GA_NT 0
+#endif
+__device__ __forceinline__ float4 ga_ld(const float4* p) {
+#if VOXE_GA_NT
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void ga_st(float4* p, float4 x) {
+#if VOXE_GA_NT
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 t; t.x = x.x; t.y = x.y; t.z = x.z; t.w = x.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
+#else
+  *p = x;
+#endif
+}
+__global__ __launch_bounds__(256) void grid_adam_v4_kernel(float4* __restrict__ gpacked, float4* __restrict__ dens,
+                                                           float4* __restrict__ feat, const float4* __restrict__ extra_d,
+                                                           const float4* __restrict__ extra_f, float4* __restrict__ m_d,
+                                                           float4* __restrict__ v_d, float4* __restrict__ m_f,
+                                                           float4* __restrict__ v_f, float4* __restrict__ packed,
+                                                           long long q_begin, long long q_end, float scale, int pre_act,
+                                                           AdamHyper h_d, AdamHyper h_f, int flip) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long q0 = q_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < q_end; q0 += stride) {
+    const long long q = flip ? q_begin + q_end - 1 - q0 : q0;
+    float g[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 t = gpacked[q * 4 + k];
+      g[k][0] = t.x; g[k][1] = t.y; g[k][2] = t.z; g[k][3] = t.w;
+    }
+    float p[12], d[4];
+    {
+      const float4 a = ga_ld(&feat[q * 3]), b = ga_ld(&feat[q * 3 + 1]), c = ga_ld(&feat[q * 3 + 2]);
+      p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
+      p[8] = c.x; p[9] = c.y; p[10] = c.z; p[11] = c.w;
+      const float4 dd = ga_ld(&dens[q]);
+      d[0] = dd.x; d[1] = dd.y; d[2] = dd.z; d[3] = dd.w;
+    }
+    if (m_f) {
+      float m[12], v[12], e[12];
+      const float4 ma = ga_ld(&m_f[q * 3]), mb = ga_ld(&m_f[q * 3 + 1]), mc = ga_ld(&m_f[q * 3 + 2]);
+      const float4 va = ga_ld(&v_f[q * 3]), vb = ga_ld(&v_f[q * 3 + 1]), vc = ga_ld(&v_f[q * 3 + 2]);
+      m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w; m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
+      m[8] = mc.x; m[9] = mc.y; m[10] = mc.z; m[11] = mc.w;
+      v[0] = va.x; v[1] = va.y; v[2] = va.z; v[3] = va.w; v[4] = vb.x; v[5] = vb.y; v[6] = vb.z; v[7] = vb.w;
+      v[8] = vc.x; v[9] = vc.y; v[10] = vc.z; v[11] = vc.w;
+      if (extra_f) {
+        const float4 ea = extra_f[q * 3], eb = extra_f[q * 3 + 1], ec = extra_f[q * 3 + 2];
+        e[0] = ea.x; e[1] = ea.y; e[2] = ea.z; e[3] = ea.w; e[4] = eb.x; e[5] = eb.y; e[6] = eb.z; e[7] = eb.w;
+        e[8] = ec.x; e[9] = ec.y; e[10] = ec.z; e[11] = ec.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const float gj = g[j / 3][j % 3];
+        const float gi = extra_f ? gj + e[j] : gj;
+        p[j] = adam_update(p[j], gi, m[j], v[j], h_f);
+      }
+      ga_st(&feat[q * 3], make_float4(p[0], p[1], p[2], p[3]));
+      ga_st(&feat[q * 3 + 1], make_float4(p[4], p[5], p[6], p[7]));
+      ga_st(&feat[q * 3 + 2], make_float4(p[8], p[9], p[10], p[11]));
+      ga_st(&m_f[q * 3], make_float4(m[0], m[1], m[2], m[3]));
+      ga_st(&m_f[q * 3 + 1], make_float4(m[4], m[5], m[6], m[7]));
+      ga_st(&m_f[q * 3 + 2], make_float4(m[8], m[9], m[10], m[11]));
+      ga_st(&v_f[q * 3], make_float4(v[0], v[1], v[2], v[3]));
+      ga_st(&v_f[q * 3 + 1], make_float4(v[4], v[5], v[6], v[7]));
+      ga_st(&v_f[q * 3 + 2], make_float4(v[8], v[9], v[10], v[11]));
+    }
+    if (m_d) {
+      float m[4], v[4], e[4];
+      const float4 mm = ga_ld(&m_d[q]), vv = ga_ld(&v_d[q]);
+      m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
+      v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
+      if (extra_d) {
+        const float4 ee = extra_d[q];
+        e[0] = ee.x; e[1] = ee.y; e[2] = ee.z; e[3] = ee.w;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gd = g[k][3] * pre_activate_grad(pre_act, d[k], scale);
+        const float gi = extra_d ? gd + e[k] : gd;
+        d[k] = adam_update(d[k], gi, m[k], v[k], h_d);
+      }
+      ga_st(&dens[q], make_float4(d[0], d[1], d[2], d[3]));
+      ga_st(&m_d[q], make_float4(m[0], m[1], m[2], m[3]));
+      ga_st(&v_d[q], make_float4(v[0], v[1], v[2], v[3]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gpacked[q * 4 + k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      packed[q * 4 + k] = make_float4(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], pre_activate(pre_act, d[k], scale));
+    }
+  }
+}
+
 // the same step with one thread per ELEMENT of the packed arrays (wide texels, see pack_grid_wide_kernel)
 template <int C>
 __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__ gpacked, float* __restrict__ dens,
@@ -258,7 +368,7 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
 template <int C>
 static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d,
                                const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h_d,
-                               AdamHyper h_f, float* packed_out, hipStream_t st) {
+                               AdamHyper h_f, float* packed_out, hipStream_t st, int flip) {
   const long long plane = (long long)gd->Y * gd->Z, nvox = (x_end - x_begin) * plane;
   if constexpr (C > 4) {
     const long long n = nvox * C;
@@ -268,6 +378,22 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
                                                   x_end * plane, gd->density_scale, gd->density_pre_act, bricked ? 1 : 0, gd->Y,
                                                   gd->Z, h_d, h_f);
     return;
+  }
+  if constexpr (C == 4 && VOXE_GA_V4) {
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const long long vb = x_begin * plane, ve = x_end * plane;
+    if (!bricked && vb % 4 == 0 && ve % 4 == 0 && al16(gpacked) && al16(gd->densities) && al16(gd->features) && al16(extra_d) &&
+        al16(extra_f) && al16(m_d) && al16(v_d) && al16(m_f) && al16(v_f) && al16(packed_out)) {
+      const long long nq = (ve - vb) / 4;
+      const int nbq = (int)((nq + 255) / 256 < VOXE_GA_BLOCKS ? (nq + 255) / 256 : VOXE_GA_BLOCKS);
+      grid_adam_v4_kernel<<<nbq, 256, 0, st>>>(
+          reinterpret_cast<float4*>(gpacked), reinterpret_cast<float4*>(const_cast<float*>(gd->densities)),
+          reinterpret_cast<float4*>(const_cast<float*>(gd->features)), reinterpret_cast<const float4*>(extra_d),
+          reinterpret_cast<const float4*>(extra_f), reinterpret_cast<float4*>(m_d), reinterpret_cast<float4*>(v_d),
+          reinterpret_cast<float4*>(m_f), reinterpret_cast<float4*>(v_f), reinterpret_cast<float4*>(packed_out), vb / 4, ve / 4,
+          gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0);
+      return;
+    }
   }
   const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
   grid_adam_kernel<C><<<nb, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
@@ -286,12 +412,13 @@ bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_e
     return AdamHyper{(float)((double)lr / bc1), (float)sqrt(bc2), beta1, beta2, eps};
   };
   const AdamHyper h_d = hyper(step_d), h_f = hyper(step_f);
+  const int flip = (int)(step_d & 1);   // alternate sweep direction: the tail of one step's sweep is the head of the next (Infinity Cache)
   switch (gd->F + 1) {
-    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
-    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
-    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
-    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
-    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st); return true;
+    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
+    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
+    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
+    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
+    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
   }
   return false;
 }
