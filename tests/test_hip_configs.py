@@ -426,7 +426,8 @@ def test_region_render_generic_bin_vs_oracle(monkeypatch):
 
 
 # ---- LDS-staged forward (render_fwd_tile_kernel) against the ray-ordered forward: bit-identical outputs -------------------
-@pytest.mark.parametrize("case", ["400", "266_oblique", "100_sparse", "multi_view", "clip_jitter_tensor", "lindisp", "tiny_grid"])
+@pytest.mark.parametrize("case", ["400", "266_oblique", "100_sparse", "multi_view", "clip_jitter_tensor", "lindisp", "tiny_grid",
+                                  "x_march", "z_march", "z_dominant_default"])
 def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, monkeypatch):
     """same interpolation arithmetic, texels from the LDS window instead of L1 / L2 (or from the global fallback for
     footprints outside the window: sparse pixels, oblique tiles, tiny grids): every output bit equal, and equal to the
@@ -442,14 +443,18 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, mo
     else:
         grid = _grid(160, "random" if case in ("400", "multi_view") else "sphere")
         hw, cam = {"400": (400, 3), "266_oblique": (266, 40), "100_sparse": (100, 7), "multi_view": (200, 9),
-                   "clip_jitter_tensor": (240, 11), "lindisp": (320, 21)}[case]
+                   "clip_jitter_tensor": (240, 11), "lindisp": (320, 21),
+                   # camera 77 looks along x, camera 12 mostly along z (ray by ray by default; VOXE_FWD_TILE_ZDOM < 0 marches z)
+                   "x_march": (320, 77), "z_march": (320, 12), "z_dominant_default": (320, 12)}[case]
+    if case == "z_march":
+        monkeypatch.setenv("VOXE_FWD_TILE_ZDOM", "-1.0")
     o, d = _rays(hw, cam)
     if case == "multi_view":
         o2, d2 = _rays(hw, cam + 30)
         o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
         over["image_height"] = hw
     S_ = 64 if case == "tiny_grid" else S
-    if case in ("400", "multi_view", "100_sparse"):
+    if case in ("400", "multi_view", "100_sparse", "x_march", "z_march", "z_dominant_default"):
         kw.update(perturb=True, seed=4, rng_offset=2)
     if case == "clip_jitter_tensor":
         kw.update(perturb=True, aabb_clip=True)

@@ -703,19 +703,209 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
 // (oblique tile borders, pixels more than ~0.7 voxel apart) take the global gather: results never depend on the window.
 // Interpolation: the same products and FMA order as gather<3,1,1>() -- bit-identical outputs to render_fwd_seg_kernel.
 // ------------------------------------------------------------------------------------------------------------------------
-constexpr int kTexRing = 6;
-__device__ __forceinline__ int tex_slot(int key) {
-  const int m = key % kTexRing;
-  return m < 0 ? m + kTexRing : m;
+#ifndef VOXE_FWD_TILE_DEFER
+#define VOXE_FWD_TILE_DEFER 1
+#endif
+#ifndef VOXE_FWD_TILE_LB
+#define VOXE_FWD_TILE_LB 4
+#endif
+constexpr int kTexRing = 8;     // layers of the texel ring (a power of two: ring slot = key & 7)
+constexpr int kOrgTable = 128;  // layer origins precomputed per block (keys key0 .. key0 + 127; a 32-sample segment spans < 70 layers)
+
+// The march of one (tile, depth segment) with the march axis M as a COMPILE-TIME constant (r03): the corner -> (layer, lateral
+// offset) mapping, the texel strides and the picks of the cell's (m, u, v) indices fold into immediates.  r02's kernel took
+// the axes from registers: 360 VALU instructions per wave-sample against 170 of the ray-ordered forward, and was VALU bound.
+template <int M>
+__device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg& c, const float* __restrict__ packed,
+                                                 RayCtx<3, 1, 1>& rc, const int lane, const bool has, const int k_lo,
+                                                 const int k_hi, const int kmin, const int kmax, const int ref,
+                                                 float4* __restrict__ tex, int2* __restrict__ org, int* __restrict__ vbase, float (&csum)[3],
+                                                 float& asum, float& dsum, float& T) {
+  constexpr int COUT = 3;
+  constexpr int U = (M == 0) ? 1 : 0, V = (M == 2) ? 1 : 2;   // lateral axes (v = z whenever m != z: coalesced layer reads)
+  constexpr int kCtr = Lat<8>::kCentre;
+  // ---- window geometry from the reference ray (as in render_bwd_tile_kernel) ----
+  const int N[3] = {g.X, g.Y, g.Z};
+  float U0[3], DU[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
+    const float half = 0.5f * (float)N[a];
+    U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
+    DU[a] = rd * g.scale[a] * half;
+  }
+  const int sgn = (DU[M] < 0.0f) ? -1 : 1;
+  const float inv = (DU[M] != 0.0f) ? 1.0f / DU[M] : 0.0f;
+  const float Bu = DU[U] * inv, Au = U0[U] - Bu * U0[M];
+  const float Bv = DU[V] * inv, Av = U0[V] - Bv * U0[M];
+  const int sx = g.Y * g.Z, sy = g.Z;
+  const int stride_m = (M == 0) ? sx : ((M == 1) ? sy : 1);
+  const int stride_u = (U == 0) ? sx : sy;
+  const int stride_v = (V == 1) ? sy : 1;
+  const int Nm = N[M], Nu = N[U], Nv = N[V];
+  auto minkey = [&](int pm) { return sgn > 0 ? pm : -(pm + 1); };
+
+  float z_cur = 0.0f;
+  Footprint fp_cur;
+  fp_cur.inside = false;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
+  int first_key = INT_MAX;
+  if (has) {
+    z_cur = rc.dg.z(k_lo);
+    float p[3];
+    rc.point(z_cur, p);
+    footprint(g, p, fp_cur);
+    first_key = minkey(fp_cur.i0[M]);
+  }
+  const int key0 = wave_min_i32(first_key);
+  // lateral origin + voxel offset of that origin for every layer this block can meet, once: lane i -> layers key0 + i, key0 + 64 + i
+#pragma unroll
+  for (int j = 0; j < kOrgTable / 64; ++j) {
+    const int im = sgn * (key0 + j * 64 + lane);
+    const int ou = (int)floorf(Au + Bu * (float)im) - kCtr, ov = (int)floorf(Av + Bv * (float)im) - kCtr;
+    org[j * 64 + lane] = make_int2(ou, ov);
+    vbase[j * 64 + lane] = im * stride_m + ou * stride_u + ov * stride_v;   // (grids below 2^31 voxels; used only when in range)
+  }
+  __syncthreads();
+  const int la = lane >> 3, lb8 = lane & 7;
+  const int lane_off = la * stride_u + lb8 * stride_v;
+  // one coalesced read per layer: lane (a, b) fetches voxel (im, off_u + a, off_v + b)
+  auto fetch_layer = [&](int key) -> float4 {
+    const int idx = key - key0;                       // wave-uniform
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (idx < kOrgTable) {
+      const int2 o = org[idx];
+      const int vb = vbase[idx];
+      const int im = sgn * key;
+      if ((unsigned)im < (unsigned)Nm && (unsigned)(o.x + la) < (unsigned)Nu && (unsigned)(o.y + lb8) < (unsigned)Nv)
+        t = reinterpret_cast<const float4*>(packed)[vb + lane_off];
+    }
+    return t;
+  };
+  auto load_layer = [&](int key) { tex[(key & (kTexRing - 1)) * 64 + lane] = fetch_layer(key); };
+  int base = key0;
+  int avail = kTexRing;      // layers base .. base + avail - 1 are in LDS (the newest ones of a slide land one sample later)
+  float4 pend[2];
+  int pend_key = 0, npend = 0;   // wave-uniform
+#pragma unroll
+  for (int i = 0; i < kTexRing; ++i) load_layer(base + i);
+  __syncthreads();
+  for (int k = kmin; k <= kmax; ++k) {
+    const bool on = has && (k >= k_lo) && (k <= k_hi);
+    if (on) {
+      const float z = z_cur;
+      const Footprint fp = fp_cur;
+      const bool last = (k == c.S - 1);
+      float z_next = z;
+      if (!last) {
+        z_next = rc.dg.z(k + 1);
+        float pn[3];
+        rc.point(z_next, pn);
+        footprint(g, pn, fp_cur);
+        z_cur = z_next;
+      }
+      if (fp.inside) {
+        Cell cell;
+        make_cell_fast(g, fp, cell);
+        const int pm = cell.i[M], pu = cell.i[U], pv = cell.i[V];
+        const int kl = minkey(pm);                       // lower key of the footprint's two layers; the other is kl + 1
+        const int il = kl - key0;
+        const int ilc = min(max(il, 0), kOrgTable - 2);
+        const int2 ol = org[ilc], oh = org[ilc + 1];
+        const int2 o0 = sgn > 0 ? ol : oh, o1 = sgn > 0 ? oh : ol;   // origins of layers pm, pm + 1
+        const int a0 = pu - o0.x, b0 = pv - o0.y, a1 = pu - o1.x, b1 = pv - o1.y;
+        const bool fits = ((unsigned)(kl - base) < (unsigned)(avail - 1)) && (il == ilc) && ((unsigned)a0 < 7u) &&
+                          ((unsigned)b0 < 7u) && ((unsigned)a1 < 7u) && ((unsigned)b1 < 7u);
+        float v, rad[COUT];
+        if (fits) {
+          const int k0 = sgn > 0 ? kl : kl + 1;           // key of layer pm (k1: layer pm + 1)
+          const int k1 = sgn > 0 ? kl + 1 : kl;
+          const float4* __restrict__ t0 = tex + ((k0 & (kTexRing - 1)) * 64 + a0 * 8 + b0);
+          const float4* __restrict__ t1 = tex + ((k1 & (kTexRing - 1)) * 64 + a1 * 8 + b1);
+          // gather<3,1,1>() with the eight texels read from the window: corner q = (x + (q & 1), y + ((q >> 1) & 1), z + (q >> 2));
+          // the same products and FMA order
+          typedef float v2f __attribute__((ext_vector_type(2)));
+          float wxy[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) wxy[q] = cell.w[0][q & 1] * cell.w[1][q >> 1];
+          float4 t[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int dm = (q >> M) & 1, du = (q >> U) & 1, dv = (q >> V) & 1;   // compile-time after unrolling
+            t[q] = (dm ? t1 : t0)[du * 8 + dv];
+          }
+          v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float wq = wxy[q & 3] * cell.w[2][q >> 2];
+            const v2f ww = {wq, wq};
+            const v2f a = {t[q].x, t[q].y}, b = {t[q].z, t[q].w};
+            rg = __builtin_elementwise_fma(a, ww, rg);
+            bs = __builtin_elementwise_fma(b, ww, bs);
+          }
+          rad[0] = rc.basis[0] * rg.x; rad[1] = rc.basis[0] * rg.y; rad[2] = rc.basis[0] * bs.x; v = bs.y;
+        } else {
+          gather<3, 1, 1>(g, packed, cell, rc.basis, v, rad);
+        }
+        const float sigma = post_activate(g.post_act, v);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float wgt = alpha * T;
+        T = T * om;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), wgt, csum[ch]);
+        asum = asum + wgt;
+        dsum = fmaf(z, wgt, dsum);
+      }
+    }
+    // ---- slide the window: bring in the layers the march reaches next ----
+    int lb = INT_MAX;
+    if (has) {
+      if (k + 1 < k_lo) lb = first_key;
+      else if (k + 1 <= k_hi) lb = minkey(fp_cur.i0[M]);
+    }
+    const int newbase = wave_min_i32(lb);
+    // the layers fetched at the previous slide have had this sample's time to arrive: into the ring now
+    if (npend > 0) {                              // wave-uniform
+      __syncthreads();
+      tex[(pend_key & (kTexRing - 1)) * 64 + lane] = pend[0];
+      if (npend > 1) tex[((pend_key + 1) & (kTexRing - 1)) * 64 + lane] = pend[1];
+      npend = 0;
+      avail = kTexRing;
+      __syncthreads();
+    }
+    if (newbase > base && newbase != INT_MAX) {   // wave-uniform
+      const int from = max(base + kTexRing, newbase), need = newbase + kTexRing - from;
+      if (need <= 2 && VOXE_FWD_TILE_DEFER) {     // usual case: fetch now, store after the next sample (its footprints are behind these layers)
+        pend_key = from;
+        npend = need;
+        pend[0] = fetch_layer(from);
+        if (need > 1) pend[1] = fetch_layer(from + 1);
+        avail = from - newbase;
+      } else {
+        __syncthreads();
+        for (int key = from; key < newbase + kTexRing; ++key) load_layer(key);
+        __syncthreads();
+      }
+      base = newbase;
+    }
+  }
 }
 
-__global__ __launch_bounds__(64, 4) void render_fwd_tile_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
+__global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
                                                                 const float* __restrict__ rays_o,
                                                                 const float* __restrict__ rays_d,
                                                                 const float* __restrict__ jitter,
-                                                                float* __restrict__ segbuf) {
+                                                                float* __restrict__ segbuf, const float fit_lat,
+                                                                const float fit_m, const float zdom) {
   constexpr int COUT = 3, NC = COUT + 3;
   __shared__ float4 tex[kTexRing * 64];
+  __shared__ int2 org[kOrgTable];
+  __shared__ int vbase[kOrgTable];
   const int lane = threadIdx.x;
   const int nseg = num_segments(c.S, c.seg_len);
   const int nrb = gridDim.x / nseg;                    // tile slots (segment-major block order, like render_fwd_seg_kernel)
@@ -738,149 +928,72 @@ __global__ __launch_bounds__(64, 4) void render_fwd_tile_kernel(DevGrid g, DevCf
   const int kmax = wave_max_i32(has ? k_hi : -1);
   float csum[COUT] = {0.0f, 0.0f, 0.0f};
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
-  if (kmin <= kmax) {   // wave-uniform
-    // ---- window geometry from the reference ray (as in render_bwd_tile_kernel) ----
-    Window w;
-    w.ctr = Lat<8>::kCentre;
-    {
-      const unsigned long long hm = __ballot(has);
-      const int ref = ((hm >> 27) & 1ull) ? 27 : (__ffsll((long long)hm) - 1);
+  // Per tile (wave-uniform): march through the texel window, or ray by ray (the loop of render_fwd_seg_kernel)?
+  //  * march axis m = the dominant axis of the reference ray -- when that is x or y.  Tiles whose rays run mostly along z march
+  //    ray by ray: a layer normal to z is 64 texels in 64 different cache lines (z runs fastest in memory; a layer normal to
+  //    x or y is eight 128-byte runs), and marching such a view along x or y instead shears the window by more than a voxel
+  //    per layer -- measured (profiles/r03_ab_fwd_window.txt): z-dominant views gain nothing either way, 256^3 / 800x800 loses 9 %;
+  //  * the tile has to fit the window -- the measure of the backward's split decision: lateral extent of the 8x8 pixels at the
+  //    far end of the segment against the 8-wide layers, spread along m against the ring.  Tiles that do not fit (coarse
+  //    images, very oblique tiles) would send most lanes through the global gather AND pay the window.
+  int m = -1;   // -1: ray by ray
+  int ref = 0;
+  if (kmin <= kmax) {
+    const unsigned long long hm = __ballot(has);
+    ref = ((hm >> 27) & 1ull) ? 27 : (__ffsll((long long)hm) - 1);
+    const unsigned long long am = __ballot(alive);
+    if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
       const int N[3] = {g.X, g.Y, g.Z};
-      float U0[3], DU[3];
+      const float zref = readlane_f32(rc.dg.zlin(ke), 0);
+      float ad[3], e3[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
-        const float half = 0.5f * (float)N[a];
-        U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
-        DU[a] = rd * g.scale[a] * half;
+        const float sc = g.scale[a] * 0.5f * (float)N[a];
+        const float da = readlane_f32(rc.d[a], 0);
+        ad[a] = fabsf(readlane_f32(rc.d[a], ref) * sc);
+        e3[a] = 7.0f * (fabsf((readlane_f32(rc.d[a], 1) - da) * sc * zref) + fabsf((readlane_f32(rc.d[a], 8) - da) * sc * zref));
       }
-      const float ax = fabsf(DU[0]), ay = fabsf(DU[1]), az = fabsf(DU[2]);
-      w.m = (ax >= ay && ax >= az) ? 0 : ((ay >= az) ? 1 : 2);
-      w.u = (w.m == 0) ? 1 : 0;
-      w.v = (w.m == 2) ? 1 : 2;
-      const float DUm = (w.m == 0) ? DU[0] : ((w.m == 1) ? DU[1] : DU[2]);
-      const float U0m = (w.m == 0) ? U0[0] : ((w.m == 1) ? U0[1] : U0[2]);
-      const float DUu = (w.u == 0) ? DU[0] : DU[1], U0u = (w.u == 0) ? U0[0] : U0[1];
-      const float DUv = (w.v == 1) ? DU[1] : DU[2], U0v = (w.v == 1) ? U0[1] : U0[2];
-      w.sgn = (DUm < 0.0f) ? -1 : 1;
-      const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
-      w.Bu = DUu * inv; w.Au = U0u - w.Bu * U0m;
-      w.Bv = DUv * inv; w.Av = U0v - w.Bv * U0m;
-      const int sx = g.Y * g.Z, sy = g.Z;
-      w.stride_m = (w.m == 0) ? sx : ((w.m == 1) ? sy : 1);
-      w.stride_u = (w.u == 0) ? sx : sy;
-      w.stride_v = (w.v == 1) ? sy : 1;
-    }
-    const int Nm = (w.m == 0) ? g.X : ((w.m == 1) ? g.Y : g.Z);
-    const int Nu = (w.u == 0) ? g.X : g.Y, Nv = (w.v == 1) ? g.Y : g.Z;
-    auto pick = [&](const int (&t)[3], int axis) { return axis == 0 ? t[0] : (axis == 1 ? t[1] : t[2]); };
-    auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
-    // one coalesced read per layer: lane (a, b) fetches voxel (im, off_u + a, off_v + b) -- b runs along z whenever z is lateral
-    auto load_layer = [&](int key) {
-      const int im = w.sgn * key;
-      const int iu = w.off_u(im) + (lane >> 3), iv = w.off_v(im) + (lane & 7);
-      float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if ((unsigned)im < (unsigned)Nm && (unsigned)iu < (unsigned)Nu && (unsigned)iv < (unsigned)Nv)
-        t = reinterpret_cast<const float4*>(packed)[(long long)im * w.stride_m + (long long)iu * w.stride_u +
-                                                   (long long)iv * w.stride_v];
-      tex[tex_slot(key) * 64 + lane] = t;
-    };
-    float z_cur = 0.0f;
-    Footprint fp_cur;
-    fp_cur.inside = false;
+      const int mxy = ad[0] >= ad[1] ? 0 : 1;
+      const int mm = (ad[2] >= fabsf(zdom) * ad[mxy]) ? 2 : mxy;
+      float lat = 0.0f, alongm = 0.0f;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
-    int first_key = INT_MAX;
-    if (has) {
-      z_cur = rc.dg.z(k_lo);
-      float p[3];
-      rc.point(z_cur, p);
-      footprint(g, p, fp_cur);
-      first_key = minkey(pick(fp_cur.i0, w.m));
-    }
-    w.base = wave_min_i32(first_key);
-    for (int i = 0; i < kTexRing; ++i) load_layer(w.base + i);
-    __syncthreads();
-    for (int k = kmin; k <= kmax; ++k) {
-      const bool on = has && (k >= k_lo) && (k <= k_hi);
-      if (on) {
-        const float z = z_cur;
-        const Footprint fp = fp_cur;
-        const bool last = (k == c.S - 1);
-        float z_next = z;
-        if (!last) {
-          z_next = rc.dg.z(k + 1);
-          float pn[3];
-          rc.point(z_next, pn);
-          footprint(g, pn, fp_cur);
-          z_cur = z_next;
-        }
-        if (fp.inside) {
-          Cell cell;
-          make_cell_fast(g, fp, cell);
-          const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
-          int lofs[2], ab0[2];
-          bool fits = true;
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int im = pm + s, key = w.sgn * im;
-            const int a0 = pu - w.off_u(im), b0 = pv - w.off_v(im);
-            fits = fits && ((unsigned)(key - w.base) < (unsigned)kTexRing) && ((unsigned)a0 < 7u) && ((unsigned)b0 < 7u);
-            lofs[s] = tex_slot(key) * 64;
-            ab0[s] = a0 * 8 + b0;
-          }
-          float v, rad[COUT];
-          if (fits) {
-            // gather<3,1,1>() with the eight texels read from the window: corner k = (x + (k & 1), y + ((k >> 1) & 1), z + (k >> 2))
-            typedef float v2f __attribute__((ext_vector_type(2)));
-            float wxy[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wxy[q] = cell.w[0][q & 1] * cell.w[1][q >> 1];
-            v2f rg = {0.0f, 0.0f}, bs = {0.0f, 0.0f};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int dm = (q >> w.m) & 1, du = (q >> w.u) & 1, dv = (q >> w.v) & 1;   // wave-uniform shifts
-              const float4 t = tex[(dm ? lofs[1] : lofs[0]) + (dm ? ab0[1] : ab0[0]) + du * 8 + dv];
-              const float wq = wxy[q & 3] * cell.w[2][q >> 2];
-              const v2f ww = {wq, wq};
-              const v2f a = {t.x, t.y}, b = {t.z, t.w};
-              rg = __builtin_elementwise_fma(a, ww, rg);
-              bs = __builtin_elementwise_fma(b, ww, bs);
-            }
-            rad[0] = rc.basis[0] * rg.x; rad[1] = rc.basis[0] * rg.y; rad[2] = rc.basis[0] * bs.x; v = bs.y;
-          } else {
-            gather<3, 1, 1>(g, packed, cell, rc.basis, v, rad);
-          }
-          const float sigma = post_activate(g.post_act, v);
-          const float dl = last ? kInfinity : (z_next - z);
-          const float delta = dl * rc.dnorm;
-          const float e = fast_exp(-(sigma * delta));
-          const float alpha = 1.0f - e;
-          const float om = 1.0f - alpha;
-          const float wgt = alpha * T;
-          T = T * om;
-#pragma unroll
-          for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), wgt, csum[ch]);
-          asum = asum + wgt;
-          dsum = fmaf(z, wgt, dsum);
-        }
-      }
-      // ---- slide the window: bring in the layers the march reaches next ----
-      int lb = INT_MAX;
-      if (has) {
-        if (k + 1 < k_lo) lb = first_key;
-        else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
-      }
-      const int newbase = wave_min_i32(lb);
-      if (newbase > w.base && newbase != INT_MAX) {   // wave-uniform
-        __syncthreads();
-        const int from = max(w.base + kTexRing, newbase);
-        for (int key = from; key < newbase + kTexRing; ++key) load_layer(key);
-        w.base = newbase;
-        __syncthreads();
-      }
+      for (int a = 0; a < 3; ++a) { if (a == mm) alongm = e3[a]; else lat = fmaxf(lat, e3[a]); }
+      if (lat <= fit_lat && alongm <= fit_m && (mm != 2 || zdom < 0.0f)) m = mm;   // (zdom < 0: experiment, march along z too)
     }
   }
+  if (m < 0) {
+    if (has) {
+      float z_next = rc.dg.z(k_lo);
+      for (int k = k_lo; k <= k_hi; ++k) {
+        const float z = z_next;
+        const bool last = (k == c.S - 1);
+        if (!last) z_next = rc.dg.z(k + 1);
+        float p[3];
+        rc.point(z, p);
+        Footprint fp;
+        footprint(g, p, fp);
+        if (!fp.inside) continue;
+        Cell cell;
+        make_cell_fast(g, fp, cell);
+        float v, rad[COUT];
+        gather<3, 1, 1>(g, packed, cell, rc.basis, v, rad);
+        const float sigma = post_activate(g.post_act, v);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float wgt = alpha * T;
+        T = T * om;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), wgt, csum[ch]);
+        asum = asum + wgt;
+        dsum = fmaf(z, wgt, dsum);
+      }
+    }
+  } else if (m == 0) fwd_window_march<0>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, vbase, csum, asum, dsum, T);
+  else if (m == 1) fwd_window_march<1>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, vbase, csum, asum, dsum, T);
+  else fwd_window_march<2>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, vbase, csum, asum, dsum, T);
   if (!alive) return;
   const long long base = (long long)seg * NC;
   segbuf[(base + 0) * c.R + r] = T;
@@ -890,21 +1003,27 @@ __global__ __launch_bounds__(64, 4) void render_fwd_tile_kernel(DevGrid g, DevCf
   segbuf[(base + 2 + COUT) * c.R + r] = dsum;
 }
 
-// The LDS-staged forward is OFF by default: measured on MI355X it is 12 % SLOWER than the ray-ordered forward (400x400 on
-// 160^3: 0.273 vs 0.243 ms; 266x266: 0.164 vs 0.142; 800x800 on 256^3: 1.03 vs 0.89 -- profiles/r02_ab_fwd_tile.txt): L1
-// already captures the texel reuse of a tile, and the lock-step march + window bookkeeping cost more issue slots than the
-// LDS reads save.  Kept as an A/B switch (VOXE_FWD_TILE = 1, read per launch) and as a bit-exactness cross-check of the
-// forward (tests/test_hip_configs.py::test_lds_staged_forward_*).
+// The window forward is the default for image-ordered SH-0 renders since r03 (VOXE_FWD_TILE=0 switches it off, read per launch):
+// r02's version (march axis in registers, 360 VALU instructions per wave-sample) was 12 % slower than the ray-ordered forward;
+// with the march axis as a template parameter, layer origins / voxel offsets tabulated once per block, the stores of a slide
+// deferred by one sample and a per-tile choice between window and ray-by-ray march it is 8 - 20 % faster for views that run
+// along x or y (profiles/r03_ab_fwd_window.txt) and equal otherwise.  Outputs are bit-identical either way
+// (tests/test_hip_configs.py::test_lds_staged_forward_*).
 bool fwd_tile_supported(const DevGrid& g, const DevCfg& c, int cout, int ncm) {
   (void)g;
-  if (cout != 3 || ncm != 1 || c.image_width <= 0 || c.term_eps > 0.0f) return false;
+  if (cout != 3 || ncm != 1 || c.image_width <= 0) return false;
   const char* e = getenv("VOXE_FWD_TILE");
-  return e && e[0] == '1';
+  return !(e && e[0] == '0');
 }
 void launch_fwd_tile(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
-  render_fwd_tile_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
+  // (A-B switches, read per launch)
+  const char* el = getenv("VOXE_FWD_TILE_FIT_LAT");
+  const char* em = getenv("VOXE_FWD_TILE_FIT_M");
+  const char* ez = getenv("VOXE_FWD_TILE_ZDOM");
+  const float fit_lat = el ? (float)atof(el) : 5.5f, fit_m = em ? (float)atof(em) : 4.5f, zdom = ez ? (float)atof(ez) : 1.0f;
+  render_fwd_tile_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf, fit_lat, fit_m, zdom);
 }
 
 // Images of a few thousand rays leave the chip empty whatever the kernel and usually have pixels far apart (little to
