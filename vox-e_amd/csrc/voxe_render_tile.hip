@@ -127,32 +127,41 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
                                             unsigned long long* __restrict__ gdet = nullptr) {
   constexpr int C = WC;
   constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots, kPlane = Lat<KL>::kPlane;
-  const int im = w.sgn * key;
-  const int offu = w.off_u(im), offv = w.off_v(im);
-  const int lbase = ring_slot(key) * kLayerSlots;
   constexpr int kPerInstr = 64 / C;  // voxels per wave instruction (C == 4 -> 16, C == 2 -> 32)
+  constexpr int NJ = (kLayerSlots + kPerInstr - 1) / kPerInstr;
+  const int im = w.sgn * key;
+  // r03: the layer's origin voxel is wave-uniform -- scalar registers, 64-bit scalar arithmetic -- and a lane adds its lateral
+  // offset with 24-bit multiplies (full rate; 32 / 64-bit integer multiplies are quarter rate: three 64-bit ones per slot took
+  // ~15 % of the kernel's VALU time); the NJ window reads of a layer are issued together (one LDS round trip instead of NJ)
+  const int offu = __builtin_amdgcn_readfirstlane(w.off_u(im)), offv = __builtin_amdgcn_readfirstlane(w.off_v(im));
+  const long long vox0 = (long long)im * w.stride_m + (long long)offu * w.stride_u + (long long)offv * w.stride_v;
+  const int lbase = ring_slot(key) * kLayerSlots;
+  const int ch = lane % C;
+  int idx[NJ];
+  double val[NJ];
 #pragma unroll
-  for (int j = 0; j < (kLayerSlots + kPerInstr - 1) / kPerInstr; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int ab = j * kPerInstr + lane / C;  // lateral cell: a = ab / KL, b = ab % KL (b is the z-run)
-    if (kLayerSlots % kPerInstr != 0 && ab >= kLayerSlots) continue;
-    const int ch = lane % C;
-    const int idx = ch * kPlane + lbase + Lat<KL>::pos(key, ab);
+    idx[j] = ch * kPlane + lbase + Lat<KL>::pos(key, ab);
+    const bool live = (kLayerSlots % kPerInstr == 0) || ab < kLayerSlots;
+    val[j] = live ? win[idx[j]] : 0.0;        // (DET: the same 64 bits, read as a double only to be tested against zero)
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int ab = j * kPerInstr + lane / C;
     if constexpr (DET) {
-      const unsigned long long q = reinterpret_cast<unsigned long long*>(win)[idx];
+      const unsigned long long q = (unsigned long long)__double_as_longlong(val[j]);
       if (q != 0ull) {
-        reinterpret_cast<unsigned long long*>(win)[idx] = 0ull;
-        const int iu = ab / kLat + offu, iv = ab % kLat + offv;
-        const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
+        reinterpret_cast<unsigned long long*>(win)[idx[j]] = 0ull;
+        const long long vox = vox0 + (long long)(__mul24(ab / kLat, w.stride_u) + __mul24(ab % kLat, w.stride_v));
         atomicAdd(gdet + vox * CM + memch, q);
       }
       continue;
     }
-    const double val = win[idx];
-    if (val != 0.0) {
-      win[idx] = 0.0;
-      const int iu = ab / kLat + offu, iv = ab % kLat + offv;
-      const long long vox = (long long)im * w.stride_m + (long long)iu * w.stride_u + (long long)iv * w.stride_v;
-      atomicAdd(gpacked + vox * CM + memch, (float)val);
+    if (val[j] != 0.0) {
+      win[idx[j]] = 0.0;
+      const long long vox = vox0 + (long long)(__mul24(ab / kLat, w.stride_u) + __mul24(ab % kLat, w.stride_v));
+      atomicAdd(gpacked + vox * CM + memch, (float)val[j]);
     }
   }
 }
