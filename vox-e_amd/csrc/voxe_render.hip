@@ -321,6 +321,115 @@ __global__ __launch_bounds__(256) void grid_adam_v4_kernel(float4* __restrict__ 
   }
 }
 
+// C == 4, linear gradient layout, every global access a fully coalesced wave instruction (r03): a wave takes 256 consecutive
+// voxels; lane l owns voxels base + l + 64 k (k = 0..3), so the float4 streams (packed gradient, packed grid) and the per-voxel
+// scalars (density, its moments) are contiguous across the lanes of every instruction; the [N,3] streams (features, their
+// moments) are read as three contiguous float4 instructions per wave and handed to their voxels' lanes through a wave-private
+// LDS buffer (stride-3 reads: conflict free), and written back the same way.  grid_adam_v4_kernel's 16-byte chunks at 48 / 64
+// byte lane strides wrote 20 % more bytes than the streams hold (partial lines, PMC WRITE_SIZE).  Same arithmetic per element.
+#ifndef VOXE_GA_V5
+#define VOXE_GA_V5 1
+#endif
+__device__ __forceinline__ void wave_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ gpacked, float* __restrict__ dens,
+                                                           float4* __restrict__ feat, const float* __restrict__ extra_d,
+                                                           const float4* __restrict__ extra_f, float* __restrict__ m_d,
+                                                           float* __restrict__ v_d, float4* __restrict__ m_f,
+                                                           float4* __restrict__ v_f, float4* __restrict__ packed,
+                                                           long long vox_begin, int nchunks, float scale, int pre_act,
+                                                           AdamHyper h_d, AdamHyper h_f, int flip) {
+  __shared__ float4 lds4[4][3][192];   // [wave][buffer][256 voxels x 3 floats]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * 4;
+  for (int c0 = blockIdx.x * 4 + wave; c0 < nchunks; c0 += nwaves) {
+    const int c = flip ? nchunks - 1 - c0 : c0;
+    const long long vb = vox_begin + (long long)c * 256;      // first voxel of the chunk (a multiple of 4)
+    const long long f4 = vb * 3 / 4;                           // first float4 of the chunk in an [N,3] stream
+    float4 g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = gpacked[vb + k * 64 + lane];
+    // [N,3] streams -> LDS (three coalesced float4 instructions each)
+    float4 (*buf)[192] = lds4[wave];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) buf[0][k * 64 + lane] = feat[f4 + k * 64 + lane];
+    if (m_f) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { buf[1][k * 64 + lane] = m_f[f4 + k * 64 + lane]; buf[2][k * 64 + lane] = v_f[f4 + k * 64 + lane]; }
+    }
+    float d[4], md[4], vd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      d[k] = dens[vb + k * 64 + lane];
+      if (m_d) { md[k] = m_d[vb + k * 64 + lane]; vd[k] = v_d[vb + k * 64 + lane]; }
+    }
+    wave_lds_order();
+    float p[12], m[12], v[12];
+    const float* b0 = reinterpret_cast<const float*>(buf[0]);
+    const float* b1 = reinterpret_cast<const float*>(buf[1]);
+    const float* b2 = reinterpret_cast<const float*>(buf[2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int f = 0; f < 3; ++f) {
+        const int i = (k * 64 + lane) * 3 + f;
+        p[k * 3 + f] = b0[i];
+        if (m_f) { m[k * 3 + f] = b1[i]; v[k * 3 + f] = b2[i]; }
+      }
+    wave_lds_order();
+    if (m_f) {
+      if (extra_f) {   // regulariser gradient of the features (rare path): through buffer 0
+#pragma unroll
+        for (int k = 0; k < 3; ++k) buf[0][k * 64 + lane] = extra_f[f4 + k * 64 + lane];
+        wave_lds_order();
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          const float gj = f == 0 ? g[k].x : (f == 1 ? g[k].y : g[k].z);
+          const float gi = extra_f ? gj + b0[(k * 64 + lane) * 3 + f] : gj;
+          p[k * 3 + f] = adam_update(p[k * 3 + f], gi, m[k * 3 + f], v[k * 3 + f], h_f);
+        }
+      wave_lds_order();
+      // back through LDS: every lane writes its 12 values of each stream, the wave stores three float4 instructions
+      float* w0 = reinterpret_cast<float*>(buf[0]);
+      float* w1 = reinterpret_cast<float*>(buf[1]);
+      float* w2 = reinterpret_cast<float*>(buf[2]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+          const int i = (k * 64 + lane) * 3 + f;
+          w0[i] = p[k * 3 + f]; w1[i] = m[k * 3 + f]; w2[i] = v[k * 3 + f];
+        }
+      wave_lds_order();
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        feat[f4 + k * 64 + lane] = buf[0][k * 64 + lane];
+        m_f[f4 + k * 64 + lane] = buf[1][k * 64 + lane];
+        v_f[f4 + k * 64 + lane] = buf[2][k * 64 + lane];
+      }
+      wave_lds_order();   // (the buffers are reused by the next chunk)
+    }
+    if (m_d) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gd = g[k].w * pre_activate_grad(pre_act, d[k], scale);
+        const float gi = extra_d ? gd + extra_d[vb + k * 64 + lane] : gd;
+        d[k] = adam_update(d[k], gi, md[k], vd[k], h_d);
+        dens[vb + k * 64 + lane] = d[k];
+        m_d[vb + k * 64 + lane] = md[k];
+        v_d[vb + k * 64 + lane] = vd[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      gpacked[vb + k * 64 + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      packed[vb + k * 64 + lane] = make_float4(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], pre_activate(pre_act, d[k], scale));
+    }
+  }
+}
+
 // the same step with one thread per ELEMENT of the packed arrays (wide texels, see pack_grid_wide_kernel)
 template <int C>
 __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__ gpacked, float* __restrict__ dens,
@@ -384,6 +493,20 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
     const long long vb = x_begin * plane, ve = x_end * plane;
     if (!bricked && vb % 4 == 0 && ve % 4 == 0 && al16(gpacked) && al16(gd->densities) && al16(gd->features) && al16(extra_d) &&
         al16(extra_f) && al16(m_d) && al16(v_d) && al16(m_f) && al16(v_f) && al16(packed_out)) {
+      if (VOXE_GA_V5 && (ve - vb) >= 256) {
+        const long long nchunks = (ve - vb) / 256, tail = vb + nchunks * 256;
+        const int nb5 = (int)((nchunks + 3) / 4 < VOXE_GA_BLOCKS ? (nchunks + 3) / 4 : VOXE_GA_BLOCKS);
+        grid_adam_v5_kernel<<<nb5, 256, 0, st>>>(
+            reinterpret_cast<float4*>(gpacked), const_cast<float*>(gd->densities),
+            reinterpret_cast<float4*>(const_cast<float*>(gd->features)), extra_d, reinterpret_cast<const float4*>(extra_f), m_d, v_d,
+            reinterpret_cast<float4*>(m_f), reinterpret_cast<float4*>(v_f), reinterpret_cast<float4*>(packed_out), vb, (int)nchunks,
+            gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0);
+        if (tail < ve)   // fewer than 256 voxels left: the per-voxel kernel
+          grid_adam_kernel<C><<<1, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features), extra_d,
+                                                 extra_f, m_d, v_d, m_f, v_f, packed_out, tail, ve, gd->density_scale,
+                                                 gd->density_pre_act, 0, gd->Y, gd->Z, h_d, h_f);
+        return;
+      }
       const long long nq = (ve - vb) / 4;
       const int nbq = (int)((nq + 255) / 256 < VOXE_GA_BLOCKS ? (nq + 255) / 256 : VOXE_GA_BLOCKS);
       grid_adam_v4_kernel<<<nbq, 256, 0, st>>>(
