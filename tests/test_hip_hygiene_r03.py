@@ -131,7 +131,7 @@ def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, mon
     owned = np.zeros(inside.shape, dtype=np.int32)
     used_slots, generic_samples = 0, 0
     for lane in np.nonzero(lane_n)[0]:
-        r = lane // nseg
+        r = lane % R          # lane = depth segment * R + ray
         for j in range(int(lane_n[lane])):
             ray, kk = int(seg[lane, j, 0]), int(seg[lane, j, 1])
             k0, k1 = kk & 0xFFFF, kk >> 16

@@ -97,6 +97,11 @@ struct BinScratch {
 };
 
 __device__ __forceinline__ size_t slot_of(size_t lane, unsigned j, long long nlanes) { return (size_t)j * (size_t)nlanes + lane; }
+// Lane numbering: (ray r, depth segment s) is lane s * R + r (r03; r02: r * nseg + s).  region_seg_kernel's waves hold 64 rays of
+// ONE depth segment: segment-major ids make their table writes contiguous runs (8 rays of an image tile = one 32-byte sector
+// of a 4-byte table) instead of one 4-byte word per sector (PMC: 293 MB written for 40 MB of records); the fold kernel's
+// threads (8 rays x nseg segments per wave) still read whole 256-byte runs of the 32-byte segment records.
+__device__ __forceinline__ long long lane_of(long long r, int seg, long long R) { return (long long)seg * R + r; }
 
 // ---- ray context of a segment lane: origin, direction, depth generator (no sample range, no SH basis) ----------------------
 // LDS stride (floats) of a full view-dependent texel: 13 -> 16, 28 -> 32 (16-byte aligned rows for ds_read_b128)
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
   rc.init(g, c, r, rays_o, rays_d, jitter);
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
   const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
-  const long long nlanes = c.R * nseg, lane_id = r * nseg + seg;
+  const long long nlanes = c.R * nseg, lane_id = lane_of(r, seg, c.R);
   if (k_lo > k_hi) { bs.lane_n[lane_id] = 0u; return; }   // (every lane writes its count: no memset of the table)
   const int nry = regions_along(g.Y, kRBY), nrz = regions_along(g.Z, kRBZ);
   int nslots = 0;
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch b
   const int lr = threadIdx.x / nseg, s = threadIdx.x - lr * nseg;          // ray of the block, depth segment
   const long long r = (long long)blockIdx.x * rays_per_block + lr;
   const bool live = lr < rays_per_block && r < c.R;
-  const long long lane = live ? r * nseg + s : 0;
+  const long long lane = live ? lane_of(r, s, c.R) : 0;
   const unsigned n = live ? bs.lane_n[lane] : 0u;
   float4 pa[kSlotsPerLane];
   float2 pb[kSlotsPerLane];
