@@ -257,6 +257,9 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the launch stream, voxe_profile_*) -------------
     ms_fwd = prof["ms_fwd"] / max(prof["n_fwd"], 1)
     ms_bwd = prof["ms_bwd"] / max(prof["n_bwd"], 1)
+    # the forward kernel of this launch: image-ordered SH-0 renders march through the LDS texel window (r03) unless switched off
+    fwd_kernel = ("voxe::render_fwd_tile_kernel" if args.ray_order == "image" and os.environ.get("VOXE_FWD_TILE", "1") != "0"
+                  else "voxe::render_fwd_seg_kernel<3, 1, 1>")
     # algorithmic bytes: per in-AABB sample 8 corners x 4 ch x 4 B = 128 B read (fwd),
     # 128 B re-read + 128 B gradient scatter (bwd); per ray 24 B rays + outputs/upstream I/O
     bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
@@ -265,7 +268,7 @@ def main():
         bwd_name = "render_bwd_tile_kernel<3,1,1,true,true,0,8,false>" if args.ray_order == "image" else "region_bwd_kernel<3,1>"
         kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
-        kname, kbytes, kms = "render_fwd_seg_kernel<3,1,1>", bytes_fwd, ms_fwd
+        kname, kbytes, kms = fwd_kernel.replace("voxe::", "").replace(", ", ","), bytes_fwd, ms_fwd
     achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     # Physical side of the picture (PMC counters cannot be read from inside this process; they are collected by
     # tools/gpu_pmc.sh -- rocprofv3 --pmc in separate passes over THIS script -- and committed as
@@ -328,7 +331,7 @@ def main():
         return len(targs) >= 7 and targs[6] == "8" and (len(targs) < 8 or targs[7] == "false")
 
     phys_bwd = physical_of("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0,", _is_headline_bwd, ms_bwd)
-    phys_fwd = physical_of("voxe::render_fwd_seg_kernel<3, 1, 1>", lambda k: True, ms_fwd)
+    phys_fwd = physical_of(fwd_kernel, lambda k: True, ms_fwd)
     physical = phys_bwd if ms_bwd >= ms_fwd else phys_fwd
     traffic = physical.get("traffic_bytes") if physical and not physical.get("stale") else None
     traffic_src = (f"{pmc_rel} (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB; source_hash {src_hash}), "

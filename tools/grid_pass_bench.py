@@ -76,7 +76,7 @@ def main():
     for name, nbytes, ms in rows:
         gbs = nbytes / (ms * 1e-3) / 1e9
         print(f"{name:62s} {nbytes / 1e6:8.1f} {ms:8.4f} {gbs:8.0f} {gbs / PEAK:8.3f}")
-    print("# (the fused grid step grid_adam_kernel<4> -- 590 MB -- is timed by bench.py: roofline.phases_ms / the step breakdown)")
+    print("# (the fused grid step grid_adam_v5_kernel -- 590 MB -- is timed in the rocprofv3 kernel statistics of bench.py: profiles/rNN_bench_kernel_stats.csv)")
 
 
 if __name__ == "__main__":
