@@ -140,6 +140,12 @@ CASES = {
     "sh0_scatter_bricked": (40, 3, 64, False, None, "sh", "identity", "softplus", {}),
     "sh0_odd_dims_bricked": (40, 3, 64, False, (37, 40, 33), "sh", "identity", "softplus", {}),
     "sh0_odd_dims_tile": (40, 3, 96, True, (37, 40, 33), "sh", "identity", "softplus", {}),
+    # 33^3 = 35 937 voxels: an odd count -- the coalesced grid step takes 140 chunks of 256, the per-voxel kernel the last 97
+    "sh0_odd_voxel_count_tile": (40, 3, 96, True, (33, 33, 33), "sh", "identity", "softplus", {}),
+    "sh0_frozen_density_tile": (40, 3, 96, True, None, "sh", "identity", "softplus", {"freeze_density": True}),
+    # 33^3 = 35 937 voxels: an odd count -- the coalesced grid step takes 140 chunks of 256, the per-voxel kernel the last 97
+    "sh0_odd_voxel_count_tile": (33, 3, 96, True, (33, 33, 33), "sh", "identity", "softplus", {}),
+    "sh0_frozen_density_tile": (40, 3, 96, True, None, "sh", "identity", "softplus", {"freeze_density": True}),
     "sh0_preact_abs_relu": (40, 3, 96, True, None, "sh", "abs", "relu", {}),
     "sh0_extras_two_renders": (40, 3, 96, True, None, "sh", "identity", "softplus", {"extras": True, "renders": 2}),
     "sh0_extras_scatter": (40, 3, 64, False, None, "sh", "identity", "softplus", {"extras": True, "renders": 2}),

@@ -211,122 +211,19 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
   }
 }
 
-// C == 4, linear gradient layout, 4 consecutive voxels per thread: every access is a 16-byte one (the 3-float features of
-// 4 voxels are 3 float4; the per-voxel kernel above reads and writes them as nine 4-byte accesses of stride 12).  Same
-// arithmetic per element.
-#ifndef VOXE_GA_V4
-#define VOXE_GA_V4 1
-#endif
 #ifndef VOXE_GA_FLIP
 #define VOXE_GA_FLIP 1
 #endif
-#ifndef VOXE_GA_NT
-#define VOXE_GA_NT 0
-#endif
-__device__ __forceinline__ float4 ga_ld(const float4* p) {
-#if VOXE_GA_NT
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  const v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4*>(p));
-  return make_float4(t.x, t.y, t.z, t.w);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void ga_st(float4* p, float4 x) {
-#if VOXE_GA_NT
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 t; t.x = x.x; t.y = x.y; t.z = x.z; t.w = x.w;
-  __builtin_nontemporal_store(t, reinterpret_cast<v4*>(p));
-#else
-  *p = x;
-#endif
-}
-__global__ __launch_bounds__(256) void grid_adam_v4_kernel(float4* __restrict__ gpacked, float4* __restrict__ dens,
-                                                           float4* __restrict__ feat, const float4* __restrict__ extra_d,
-                                                           const float4* __restrict__ extra_f, float4* __restrict__ m_d,
-                                                           float4* __restrict__ v_d, float4* __restrict__ m_f,
-                                                           float4* __restrict__ v_f, float4* __restrict__ packed,
-                                                           long long q_begin, long long q_end, float scale, int pre_act,
-                                                           AdamHyper h_d, AdamHyper h_f, int flip) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long q0 = q_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < q_end; q0 += stride) {
-    const long long q = flip ? q_begin + q_end - 1 - q0 : q0;
-    float g[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float4 t = gpacked[q * 4 + k];
-      g[k][0] = t.x; g[k][1] = t.y; g[k][2] = t.z; g[k][3] = t.w;
-    }
-    float p[12], d[4];
-    {
-      const float4 a = ga_ld(&feat[q * 3]), b = ga_ld(&feat[q * 3 + 1]), c = ga_ld(&feat[q * 3 + 2]);
-      p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
-      p[8] = c.x; p[9] = c.y; p[10] = c.z; p[11] = c.w;
-      const float4 dd = ga_ld(&dens[q]);
-      d[0] = dd.x; d[1] = dd.y; d[2] = dd.z; d[3] = dd.w;
-    }
-    if (m_f) {
-      float m[12], v[12], e[12];
-      const float4 ma = ga_ld(&m_f[q * 3]), mb = ga_ld(&m_f[q * 3 + 1]), mc = ga_ld(&m_f[q * 3 + 2]);
-      const float4 va = ga_ld(&v_f[q * 3]), vb = ga_ld(&v_f[q * 3 + 1]), vc = ga_ld(&v_f[q * 3 + 2]);
-      m[0] = ma.x; m[1] = ma.y; m[2] = ma.z; m[3] = ma.w; m[4] = mb.x; m[5] = mb.y; m[6] = mb.z; m[7] = mb.w;
-      m[8] = mc.x; m[9] = mc.y; m[10] = mc.z; m[11] = mc.w;
-      v[0] = va.x; v[1] = va.y; v[2] = va.z; v[3] = va.w; v[4] = vb.x; v[5] = vb.y; v[6] = vb.z; v[7] = vb.w;
-      v[8] = vc.x; v[9] = vc.y; v[10] = vc.z; v[11] = vc.w;
-      if (extra_f) {
-        const float4 ea = extra_f[q * 3], eb = extra_f[q * 3 + 1], ec = extra_f[q * 3 + 2];
-        e[0] = ea.x; e[1] = ea.y; e[2] = ea.z; e[3] = ea.w; e[4] = eb.x; e[5] = eb.y; e[6] = eb.z; e[7] = eb.w;
-        e[8] = ec.x; e[9] = ec.y; e[10] = ec.z; e[11] = ec.w;
-      }
-#pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        const float gj = g[j / 3][j % 3];
-        const float gi = extra_f ? gj + e[j] : gj;
-        p[j] = adam_update(p[j], gi, m[j], v[j], h_f);
-      }
-      ga_st(&feat[q * 3], make_float4(p[0], p[1], p[2], p[3]));
-      ga_st(&feat[q * 3 + 1], make_float4(p[4], p[5], p[6], p[7]));
-      ga_st(&feat[q * 3 + 2], make_float4(p[8], p[9], p[10], p[11]));
-      ga_st(&m_f[q * 3], make_float4(m[0], m[1], m[2], m[3]));
-      ga_st(&m_f[q * 3 + 1], make_float4(m[4], m[5], m[6], m[7]));
-      ga_st(&m_f[q * 3 + 2], make_float4(m[8], m[9], m[10], m[11]));
-      ga_st(&v_f[q * 3], make_float4(v[0], v[1], v[2], v[3]));
-      ga_st(&v_f[q * 3 + 1], make_float4(v[4], v[5], v[6], v[7]));
-      ga_st(&v_f[q * 3 + 2], make_float4(v[8], v[9], v[10], v[11]));
-    }
-    if (m_d) {
-      float m[4], v[4], e[4];
-      const float4 mm = ga_ld(&m_d[q]), vv = ga_ld(&v_d[q]);
-      m[0] = mm.x; m[1] = mm.y; m[2] = mm.z; m[3] = mm.w;
-      v[0] = vv.x; v[1] = vv.y; v[2] = vv.z; v[3] = vv.w;
-      if (extra_d) {
-        const float4 ee = extra_d[q];
-        e[0] = ee.x; e[1] = ee.y; e[2] = ee.z; e[3] = ee.w;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float gd = g[k][3] * pre_activate_grad(pre_act, d[k], scale);
-        const float gi = extra_d ? gd + e[k] : gd;
-        d[k] = adam_update(d[k], gi, m[k], v[k], h_d);
-      }
-      ga_st(&dens[q], make_float4(d[0], d[1], d[2], d[3]));
-      ga_st(&m_d[q], make_float4(m[0], m[1], m[2], m[3]));
-      ga_st(&v_d[q], make_float4(v[0], v[1], v[2], v[3]));
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      gpacked[q * 4 + k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      packed[q * 4 + k] = make_float4(p[k * 3], p[k * 3 + 1], p[k * 3 + 2], pre_activate(pre_act, d[k], scale));
-    }
-  }
-}
-
 // C == 4, linear gradient layout, every global access a fully coalesced wave instruction (r03): a wave takes 256 consecutive
 // voxels; lane l owns voxels base + l + 64 k (k = 0..3), so the float4 streams (packed gradient, packed grid) and the per-voxel
 // scalars (density, its moments) are contiguous across the lanes of every instruction; the [N,3] streams (features, their
 // moments) are read as three contiguous float4 instructions per wave and handed to their voxels' lanes through a wave-private
-// LDS buffer (stride-3 reads: conflict free), and written back the same way.  grid_adam_v4_kernel's 16-byte chunks at 48 / 64
-// byte lane strides wrote 20 % more bytes than the streams hold (partial lines, PMC WRITE_SIZE).  Same arithmetic per element.
+// LDS buffer (stride-3 reads: conflict free), and written back the same way.  Measured against the alternatives (same arithmetic
+// per element): one voxel per thread (nine 4-byte accesses of stride 12 for the [N,3] streams) 0.130 ms; four voxels per thread with
+// 16-byte chunks at 48 / 64-byte lane strides 0.110 - 0.118 ms and 20 % more bytes written than the streams hold (partial lines,
+// PMC WRITE_SIZE 394 MB); this kernel 0.085 ms, 328 MB written.  The sweep direction alternates with the step (the tail of one
+// step's sweep is the head of the next in the Infinity Cache: -5 % at 100x100, +-0 at 400x400); non-temporal loads / stores of
+// parameters and moments were 25 % slower (the moments live partly in the Infinity Cache from step to step).
 #ifndef VOXE_GA_V5
 #define VOXE_GA_V5 1
 #endif
@@ -488,12 +385,12 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
                                                   gd->Z, h_d, h_f);
     return;
   }
-  if constexpr (C == 4 && VOXE_GA_V4) {
+  if constexpr (C == 4 && VOXE_GA_V5) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const long long vb = x_begin * plane, ve = x_end * plane;
-    if (!bricked && vb % 4 == 0 && ve % 4 == 0 && al16(gpacked) && al16(gd->densities) && al16(gd->features) && al16(extra_d) &&
+    if (!bricked && vb % 4 == 0 && al16(gpacked) && al16(gd->densities) && al16(gd->features) && al16(extra_d) &&
         al16(extra_f) && al16(m_d) && al16(v_d) && al16(m_f) && al16(v_f) && al16(packed_out)) {
-      if (VOXE_GA_V5 && (ve - vb) >= 256) {
+      if ((ve - vb) >= 256) {
         const long long nchunks = (ve - vb) / 256, tail = vb + nchunks * 256;
         const int nb5 = (int)((nchunks + 3) / 4 < VOXE_GA_BLOCKS ? (nchunks + 3) / 4 : VOXE_GA_BLOCKS);
         grid_adam_v5_kernel<<<nb5, 256, 0, st>>>(
@@ -507,15 +404,6 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
                                                  gd->density_pre_act, 0, gd->Y, gd->Z, h_d, h_f);
         return;
       }
-      const long long nq = (ve - vb) / 4;
-      const int nbq = (int)((nq + 255) / 256 < VOXE_GA_BLOCKS ? (nq + 255) / 256 : VOXE_GA_BLOCKS);
-      grid_adam_v4_kernel<<<nbq, 256, 0, st>>>(
-          reinterpret_cast<float4*>(gpacked), reinterpret_cast<float4*>(const_cast<float*>(gd->densities)),
-          reinterpret_cast<float4*>(const_cast<float*>(gd->features)), reinterpret_cast<const float4*>(extra_d),
-          reinterpret_cast<const float4*>(extra_f), reinterpret_cast<float4*>(m_d), reinterpret_cast<float4*>(v_d),
-          reinterpret_cast<float4*>(m_f), reinterpret_cast<float4*>(v_f), reinterpret_cast<float4*>(packed_out), vb / 4, ve / 4,
-          gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0);
-      return;
     }
   }
   const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
