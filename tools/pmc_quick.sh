@@ -11,7 +11,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("/tmp/pmcq/*/*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0][-48:]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("voxe::", "")[:60]
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in agg.items():
     if "render_" in k or "region_" in k:

@@ -56,7 +56,7 @@ int validate(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, Variant* 
   if (g->X <= 0 || g->Y <= 0 || g->Z <= 0 || g->F <= 0 || R < 0 || c->num_samples <= 0)
     return VOXE_ERR_BAD_SHAPE;
   if ((long long)g->X * g->Y * g->Z * (g->F + 1) >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
-  if ((long long)g->X * g->Y >= (1LL << 24) || g->Z >= (1 << 24)) return VOXE_ERR_BAD_SHAPE;  // 24-bit index multiplies
+  if ((long long)g->X * g->Y >= (1LL << 24) || (long long)g->Y * g->Z >= (1LL << 24) || g->Z >= (1 << 24)) return VOXE_ERR_BAD_SHAPE;  // 24-bit index multiplies (cell addresses; strides in the window flush)
   if (g->feature_kind == VOXE_FEAT_ATTN) {
     if (g->F != 1) return VOXE_ERR_BAD_SHAPE;
     v->cout = 1; v->ncoef_mem = 1; v->attn = true;
@@ -643,7 +643,7 @@ int validate_grid_only(const VoxeGridDesc* g) {
   const int C = g->F + 1;
   if (C != 2 && C != 4 && C != 13 && C != 28 && C != 49) return VOXE_ERR_BAD_SHAPE;
   if ((long long)g->X * g->Y * g->Z * C >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
-  if ((long long)g->X * g->Y >= (1LL << 24) || g->Z >= (1 << 24)) return VOXE_ERR_BAD_SHAPE;
+  if ((long long)g->X * g->Y >= (1LL << 24) || (long long)g->Y * g->Z >= (1LL << 24) || g->Z >= (1 << 24)) return VOXE_ERR_BAD_SHAPE;
   if (g->density_pre_act != VOXE_ACT_IDENTITY && g->density_pre_act != VOXE_ACT_ABS) return VOXE_ERR_UNSUPPORTED;
   if (g->density_post_act != VOXE_ACT_IDENTITY && g->density_post_act != VOXE_ACT_RELU &&
       g->density_post_act != VOXE_ACT_SOFTPLUS)

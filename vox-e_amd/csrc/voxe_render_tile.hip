@@ -30,6 +30,9 @@
 
 namespace voxe {
 
+#ifndef VOXE_TILE_ORIENT_K
+#define VOXE_TILE_ORIENT_K 1.0f   // (1e30f: always along the pixel rows, the r02 mapping; 0: always down the columns)
+#endif
 #ifndef VOXE_TILE_RING
 #define VOXE_TILE_RING 6
 #endif
@@ -153,14 +156,14 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
       const unsigned long long q = (unsigned long long)__double_as_longlong(val[j]);
       if (q != 0ull) {
         reinterpret_cast<unsigned long long*>(win)[idx[j]] = 0ull;
-        const long long vox = vox0 + (long long)(__mul24(ab / kLat, w.stride_u) + __mul24(ab % kLat, w.stride_v));
+        const long long vox = vox0 + (long long)(__umul24((unsigned)(ab / kLat), (unsigned)w.stride_u) + __umul24((unsigned)(ab % kLat), (unsigned)w.stride_v));
         atomicAdd(gdet + vox * CM + memch, q);
       }
       continue;
     }
     if (val[j] != 0.0) {
       win[idx[j]] = 0.0;
-      const long long vox = vox0 + (long long)(__mul24(ab / kLat, w.stride_u) + __mul24(ab % kLat, w.stride_v));
+      const long long vox = vox0 + (long long)(__umul24((unsigned)(ab / kLat), (unsigned)w.stride_u) + __umul24((unsigned)(ab % kLat), (unsigned)w.stride_v));
       atomicAdd(gpacked + vox * CM + memch, (float)val[j]);
     }
   }
@@ -196,7 +199,8 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     const float* __restrict__ d_depth, const float* __restrict__ d_acc,
     const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit, const int grp_begin,
     const int ngrp, float4* __restrict__ sample_src, unsigned long long* __restrict__ gdet = nullptr,
-    float* __restrict__ det_scale = nullptr, const int det_phase = 0, const float fit_m = 5.5f) {
+    float* __restrict__ det_scale = nullptr, const int det_phase = 0, const float fit_m = 5.5f,
+    const float fit_lat_arg = 0.0f) {
   // DET: det_phase 0 measures max |contribution| per channel class into det_scale[0..1] (features, density) as
   // float bits (atomicMax: order independent); det_phase 1 deposits with the power-of-two scales det_scale[2..3].
   static_assert(!DET || MODE == 0, "the deterministic mode is the single-kernel backward");
@@ -238,11 +242,38 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
   const long long src_base = ((long long)tile * nseg + seg) * c.seg_len * 64 + lane - (long long)ks * 64;
   const int ty = tile / ntx, tx = tile - ty * ntx;
   long long r_px;
-  const bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
-  const long long r = alive ? r_px : 0;
+  bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  long long r = alive ? r_px : 0;
 
   RayCtx<COUT, NCM, NCU> rc;
   rc.init(g, c, r, rays_o, rays_d, jitter);
+  // Orientation of the tile in the wave (r03, wave-uniform): consecutive lanes (lane & 7) should step along the window's
+  // lateral axis u (the stride-8 index of a layer), lane >> 3 along v.  With lanes running along the pixel rows that holds for
+  // views whose image x axis maps to u; for the others (e.g. cameras above the volume whose image x is world y) the same
+  // instruction count cost 19 % more LDS cycles in bank conflicts (PMC: SQ_LDS_BANK_CONFLICT 105 M vs 80 M per launch): those
+  // tiles take their lanes down the pixel COLUMNS instead (profiles/r03_ab_orientation.txt).
+  {
+    const unsigned long long am0 = __ballot(alive);
+    if ((am0 & 1ull) && (am0 >> 1 & 1ull) && (am0 >> 8 & 1ull)) {
+      float d0[3], dx[3], dy[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float sc = g.scale[a] * (float)(a == 0 ? g.X : (a == 1 ? g.Y : g.Z));
+        const float da = readlane_f32(rc.d[a], 0);
+        d0[a] = fabsf(da * sc);
+        dx[a] = fabsf((readlane_f32(rc.d[a], 1) - da) * sc);
+        dy[a] = fabsf((readlane_f32(rc.d[a], 8) - da) * sc);
+      }
+      const int m0 = (d0[0] >= d0[1] && d0[0] >= d0[2]) ? 0 : ((d0[1] >= d0[2]) ? 1 : 2);
+      const int u0 = (m0 == 0) ? 1 : 0;
+      const float ex_u = u0 == 0 ? dx[0] : dx[1], ey_u = u0 == 0 ? dy[0] : dy[1];
+      if (ex_u * VOXE_TILE_ORIENT_K < ey_u) {   // image y moves along u more than image x does: lanes down the columns
+        alive = tile_pixel_ray(c, ty, lane & 7, (tx << 3) + (lane >> 3), 8, r_px);
+        r = alive ? r_px : 0;
+        rc.init(g, c, r, rays_o, rays_d, jitter);
+      }
+    }
+  }
 
   // ---- pixel footprint: does the 8x8 tile fit the 8x8 lateral LDS window? ------------------------------
   // Lower-resolution images have pixels farther apart; a tile whose footprint exceeds the window is processed as two
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
         ey3[a] = fabsf((readlane_f32(rc.d[a], 8) - da) * s * zref);
       }
       const int m = (d0[0] >= d0[1] && d0[0] >= d0[2]) ? 0 : ((d0[1] >= d0[2]) ? 1 : 2);
-      constexpr float kFit = (float)KL - 2.5f;              // lateral extent (voxels) a pass may have: 5.5 for the 8-wide window
+      const float fit_lat = fit_lat_arg > 0.0f ? fit_lat_arg : (float)KL - 2.5f;   // lateral extent (voxels) a pass may have: 5.5 for the 8-wide window
       auto fits_pass = [&](float wx, float wy) {            // a pass of (wx + 1) x (wy + 1) pixels
         float lat = 0.0f, alongm = 0.0f;
 #pragma unroll
@@ -281,7 +312,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
           const float e = wx * ex3[a] + wy * ey3[a];
           if (a == m) alongm = e; else lat = fmaxf(lat, e);
         }
-        return lat <= kFit && alongm <= fit_m;
+        return lat <= fit_lat && alongm <= fit_m;
       };
       if (!fits_pass(7.0f, 7.0f)) {
         const bool hx = fits_pass(3.0f, 7.0f), hy = fits_pass(7.0f, 3.0f);
@@ -1101,11 +1132,13 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   const long long tile_segs = ntx8 * nty8 * num_segments(c.S, c.seg_len);
   const int side_for_kl = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
   const bool wide = (float)side_for_kl >= 0.75f * (float)c.image_width;
+  static const float env_fit_lat = [] { const char* e = getenv("VOXE_TILE_FIT_LAT"); return e ? (float)atof(e) : 0.0f; }();
+  const float fit_lat = env_fit_lat;   // (0: the kernel's default, KL - 2.5 voxels)
   const float fit_m = env_fit_m > 0.0f ? env_fit_m : (qsplit == 4 ? (wide ? 4.5f : 4.0f) : (tile_segs <= 16000 ? 4.5f : 5.5f));
 #define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
   render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE, KL><<<NB, 64, 0, st>>>(                    \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src), nullptr, nullptr, 0, fit_m)
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src), nullptr, nullptr, 0, fit_m, fit_lat)
   if constexpr (NGRP == 1) {
     if (a.gdet) {   // deterministic mode: measure the maxima, derive the scales, deposit in fixed point, convert
       const long long n = (long long)g.X * g.Y * g.Z * (COUT * NCM + 1);
@@ -1113,7 +1146,7 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
       for (int phase = 0; phase < 2; ++phase) {
         render_bwd_tile_kernel<COUT, NCM, NCU, true, true, 0, 8, true><<<nb, 64, 0, st>>>(
             g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc,
-            a.ray_state, a.gpacked, qsplit, 0, 1, nullptr, a.gdet, a.det_scale, phase, fit_m);
+            a.ray_state, a.gpacked, qsplit, 0, 1, nullptr, a.gdet, a.det_scale, phase, fit_m, fit_lat);
         if (phase == 0) det_scale_kernel<<<1, 1, 0, st>>>(a.det_scale);
       }
       det_finalize_kernel<<<4096, 256, 0, st>>>(a.gdet, a.gpacked, n, COUT * NCM + 1, a.det_scale);
