@@ -18,6 +18,7 @@ stream through voxe_profile_*) and `cpu_baseline` (the CPU oracle timed on the h
 sample) objects described in DESIGN.md.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -221,12 +222,15 @@ def main():
     if fused:   # exchange timing of the timed region only (events on the launch stream; 0 for one process)
         opt.read_exchange_ms()
         opt.exchange_ms, opt.exchange_steps = 0.0, 0
+    gc.collect()          # like timeit: no interpreter garbage collection inside the timed steps
+    gc.disable()
     ops.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     exchange_ms = opt.read_exchange_ms() if fused else None
     prof = ops.profile_read()
     ops.profile_enable(False)
@@ -371,10 +375,12 @@ def main():
     if world == 1 and default_cfg and not args.no_secondary:
         hw2 = 100
 
-        def small_step_bench(K):
+        def small_step_bench(K, hw2=hw2, cam0=None, steps=None):
+            cam0 = args.camera if cam0 is None else cam0
+            steps = args.steps if steps is None else steps
             ros, rds = [], []
             for i in range(K):
-                p_i = pose_spherical(*synth_pose_angles(args.camera + 11 * i, 100), RADIUS)
+                p_i = pose_spherical(*synth_pose_angles(cam0 + 11 * i, 100), RADIUS)
                 a, b = ops.cast_rays(hw2, hw2, focal_for(hw2), p_i.rotation, p_i.translation, dev)
                 ros.append(a)
                 rds.append(b)
@@ -403,12 +409,15 @@ def main():
             for _ in range(args.warmup):
                 step2()
             torch.cuda.synchronize()
+            gc.collect()      # (a generation-2 collection of the interpreter inside the timed steps showed up as a 35 ms stall)
+            gc.disable()
             ops.profile_enable(True)
             t2 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 step2()
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t2
+            gc.enable()
             pr2 = ops.profile_read()
             ops.profile_enable(False)
             b2 = pr2["ms_bwd"] / max(pr2["n_bwd"], 1)
@@ -417,8 +426,8 @@ def main():
                 phys2 = physical_of("voxe::region_bwd_kernel<3, 1>", lambda k: True, b2)
             return {
                 "workload": f"same grid and step, {K} x {hw2}x{hw2} camera(s) in one launch", "cameras_per_step": K,
-                "value": round(R2 * args.steps / e2, 1), "unit": "rays/s",
-                "ms_per_step": round(1e3 * e2 / args.steps, 4), "in_aabb_samples_per_ray": round(s_in2 / R2, 2),
+                "value": round(R2 * steps / e2, 1), "unit": "rays/s",
+                "ms_per_step": round(1e3 * e2 / steps, 4), "in_aabb_samples_per_ray": round(s_in2 / R2, 2),
                 "bwd_ms": round(b2, 4), "fwd_ms": round(pr2["ms_fwd"] / max(pr2["n_fwd"], 1), 4),
                 "roofline_frac_bwd": round((s_in2 * 256 + R2 * 56) / (b2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if b2 > 0 else None,
                 "physical_bwd": phys2,
@@ -426,6 +435,16 @@ def main():
 
         secondary = small_step_bench(1)
         secondary["multi_view"] = small_step_bench(8)
+        # the headline camera looks along a grid axis; the same step from other views of the synthetic set (z-dominant, oblique):
+        # the backward's LDS window is view dependent (profiles/r03_ab_orientation.txt)
+        views = {}
+        for cam in [int(x) for x in os.environ.get("VOXE_BENCH_VIEWS", "0,12,26,40,77,90").split(",")]:
+            v = small_step_bench(1, hw2=HW, cam0=cam, steps=max(5, args.steps // 2))
+            views[str(cam)] = {k: v[k] for k in ("value", "ms_per_step", "fwd_ms", "bwd_ms", "in_aabb_samples_per_ray")}
+        mean_ms = (sum(v["ms_per_step"] for v in views.values()) + ms_per_step) / (len(views) + 1)
+        secondary["views"] = {"workload": f"the headline step from 6 other cameras of the 100-view set ({HW}x{HW})", "cameras": views,
+                              "mean_rays_per_s_incl_headline_camera": round(HW * HW / (mean_ms * 1e-3), 1),
+                              "mean_ms_per_step": round(mean_ms, 4)}
 
     # ---- same-GPU baseline: a plain PyTorch restatement of the path (the reference's execution model: ~40 ATen ops with
     # [rays x samples] temporaries + autograd + torch.optim.Adam; voxe_hip/torch_baseline.py, pinned to the reference's
