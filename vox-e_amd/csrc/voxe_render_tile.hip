@@ -999,7 +999,8 @@ __global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(D
 #pragma unroll
       for (int a = 0; a < 3; ++a) { if (a == mm) alongm = e3[a]; else lat = fmaxf(lat, e3[a]); }
       // layers the march advances per sample (coarse sampling: every sample would wait for 2 - 3 new layers -- S = 128 on 160^3
-      // 1.5 - 1.9 layers per sample: 3 - 5 % slower through the window; S = 192: 1.0 - 1.3, 3 - 8 % faster; S = 512 on 256^3: 19 % faster)
+      // 1.5 - 1.9 layers per sample: 3 - 6 % slower through the window; S = 192: 1.0 - 1.3, 3 - 8 % faster; S = 512 on 256^3: 19 % faster;
+      // 256^3 / 800x800 / S = 256 advances 1.55 and is still 9 % faster -- finer pixels, more rays per texel: the bound is 1.7)
       const float adv = ad[mm] * fabsf(readlane_f32(rc.dg.zlin(ke) - rc.dg.zlin(ke > 0 ? ke - 1 : 0), ref));
       if (lat <= fit_lat && alongm <= fit_m && adv <= max_adv && (mm != 2 || zdom < 0.0f)) m = mm;   // (zdom < 0: experiment, march along z too)
     }
@@ -1067,7 +1068,7 @@ void launch_fwd_tile(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStr
   const char* ez = getenv("VOXE_FWD_TILE_ZDOM");
   const float fit_lat = el ? (float)atof(el) : 5.5f, fit_m = em ? (float)atof(em) : 4.5f, zdom = ez ? (float)atof(ez) : 1.0f;
   const char* ea = getenv("VOXE_FWD_TILE_ADV");
-  const float max_adv = ea ? (float)atof(ea) : 1.4f;
+  const float max_adv = ea ? (float)atof(ea) : 1.7f;
   render_fwd_tile_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf, fit_lat, fit_m, zdom, max_adv);
 }
 
