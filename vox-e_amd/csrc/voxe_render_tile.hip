@@ -33,6 +33,9 @@ namespace voxe {
 #ifndef VOXE_TILE_ORIENT_K
 #define VOXE_TILE_ORIENT_K 1.0f   // (1e30f: always along the pixel rows, the r02 mapping; 0: always down the columns)
 #endif
+#ifndef VOXE_TILE_CENTRE2
+#define VOXE_TILE_CENTRE2 1
+#endif
 #ifndef VOXE_TILE_RING
 #define VOXE_TILE_RING 6
 #endif
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
       }
     }
   }
-  auto run_pass = [&](const bool alive_q, const int centre_lane) {
+  auto run_pass = [&](const bool alive_q, const int centre_lane, const int centre_lane2) {
     rc.dg.kc = INT_MIN;                        // fresh rolling depth window for this pass
     const int k_lo = max(rc.k_lo, ks);          // this lane's samples inside the segment
     int k_hi = alive_q ? min(rc.k_hi, ke) : k_lo - 1;
@@ -350,11 +353,15 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     {
       const unsigned long long hm = __ballot(has);
       const int ref = ((hm >> centre_lane) & 1ull) ? centre_lane : (__ffsll((long long)hm) - 1);
+      // r03: the window follows the CENTRE of the pass -- the mean of the two pixels around it (the centre lies between pixels) --
+      // when both have samples: a quarter voxel more slack per lateral axis than following pixel (3, 3); the model of
+      // tools/sim/lds_conflicts.py has 25 - 40 % fewer wave-samples with a lane outside the window for diagonal views
+      const int ref2 = (VOXE_TILE_CENTRE2 && ref == centre_lane && ((hm >> centre_lane2) & 1ull)) ? centre_lane2 : ref;
       const int N[3] = {g.X, g.Y, g.Z};
       float U0[3], DU[3];
   #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
+        const float ro = readlane_f32(rc.o[a], ref), rd = 0.5f * (readlane_f32(rc.d[a], ref) + readlane_f32(rc.d[a], ref2));
         const float half = 0.5f * (float)N[a];
         U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
         DU[a] = rd * g.scale[a] * half;
@@ -720,13 +727,16 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
   auto centre_of = [&](int q) {
     return split == 0 ? 27 : (split == 1 ? 26 + 4 * q : (split == 2 ? 19 + 32 * q : 18 + 4 * (q & 1) + 32 * (q >> 1)));
   };
+  auto centre2_of = [&](int q) {   // the pixel diagonally across the part's centre from centre_of(q)
+    return split == 0 ? 36 : (split == 1 ? 33 + 4 * q : (split == 2 ? 12 + 32 * q : 9 + 4 * (q & 1) + 32 * (q >> 1)));
+  };
   const int nparts = split == 0 ? 1 : (split == 3 ? 4 : 2);
   // qsplit == 4: the parts of a tile run as sibling blocks (siblings without a part have nothing to do); otherwise one
   // block walks its parts.  ONE call site: the pass is ~3.5 k instructions and would otherwise be inlined four times.
   const int q_begin = qsplit == 4 ? quad : 0;
   const int q_end = qsplit == 4 ? min(quad + 1, nparts) : nparts;
   for (int q = q_begin; q < q_end; ++q) {
-    run_pass(alive && in_part(q), centre_of(q));
+    run_pass(alive && in_part(q), centre_of(q), centre2_of(q));
     __syncthreads();
   }
 }
