@@ -52,7 +52,10 @@ def _check_forward(out, ref):
 
 
 # ---- configs[1] headline: 160^3, one 400x400 camera, every ray ---------------------------------------------------------
-@pytest.mark.parametrize("kind,cam,jitter", [("random", 3, True), ("sphere", 11, False), ("random", 58, False)])
+@pytest.mark.parametrize("kind,cam,jitter", [("random", 3, True), ("sphere", 11, False), ("random", 58, False),
+                                             # camera 26 looks down z with image x along world y (the tile's lanes run down the
+                                             # pixel columns), camera 12 is diagonal (lanes outside the window at the far depths)
+                                             ("random", 26, True), ("random", 12, True)])
 def test_cfg1_400x400_forward_backward_all_rays_vs_oracle(kind, cam, jitter):
     """the bench workload itself (camera 3, in-kernel jitter on) and two more cameras: all 160 000 rays, forward
     outputs and both gradients against the oracle; upstream gradients on colour, depth and accumulated weight"""
