@@ -95,3 +95,29 @@ def test_two_rank_sds_loop_equals_one_process():
     for r in json.loads(line)["ranks"]:
         assert r["moved"] > 1e-3
         assert r["rel_densities"] < 0.05 * r["moved"] and r["rel_features"] < 0.05 * r["moved"], r
+
+
+@pytest.mark.timeout(600)
+def test_default_bench_line_has_the_contract_fields():
+    """the driver's N = 1 command line (short): one JSON line with the contract's fields, the roofline object fed by a PMC
+    summary that belongs to these kernel sources (not stale), the CPU / same-GPU baselines and the other-views sweep"""
+    env = dict(os.environ, VOXE_BENCH_PRE_WARM="2", VOXE_BENCH_VIEWS="12,26")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--cpu-sample", "40"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=560)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["dtype"] == "f32" and out["value"] > 1e7
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["physical"].get("stale") is None and roof["traffic"] > 0
+    assert roof["physical"]["binding"] in ("lds_issue", "valu_issue", "hbm") and 0 < roof["physical"]["binding_frac"] <= 1
+    assert roof["physical_other"]["kernel"].startswith("voxe::render_fwd_tile_kernel")
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["gpu_baseline"]["value"] > 0 and out["gpu_baseline"]["speedup"] > 10
+    views = out["secondary"]["views"]
+    assert set(views["cameras"]) == {"12", "26"} and all(v["value"] > 1e7 for v in views["cameras"].values())
