@@ -742,11 +742,12 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// Forward with the tile's texels staged in LDS (SH-0 grids, image-ordered rays; r02).
+// Forward with the tile's texels staged in LDS (SH-0 grids, image-ordered rays; r02, rebuilt in r03).
 //
 // The ray-ordered forward (render_fwd_seg_kernel) fetches the 8 corner texels of every sample from L1 / L2: at 400x400 on
 // 160^3 a texel is requested ~13 times by the 64 rays of a tile within one 32-sample segment, and those requests -- not
-// the ~180 VALU instructions of a sample -- pace the kernel (VALU issue 44 % busy).  Here one wave (8x8-pixel tile, depth
+// the ~170 VALU instructions of a sample -- pace the kernel (VALU issue 47 % busy; with the gathers replaced by one
+// shared read the kernel takes 0.143 instead of 0.247 ms, profiles/r03_ab_fwd_window.txt).  Here one wave (8x8-pixel tile, depth
 // segment) keeps the same sheared, ray-aligned window as the backward -- a ring of kTexRing layers along the march axis x
 // 8 x 8 lateral voxels, but of TEXELS (float4: 6 KB) -- loads every layer ONCE with one coalesced 1 KB read when the march
 // reaches it, and serves the corner fetches with ds_read_b128.  Samples whose 2x2x2 footprint is not inside the window
@@ -759,8 +760,17 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
 #ifndef VOXE_FWD_TILE_LB
 #define VOXE_FWD_TILE_LB 4
 #endif
-constexpr int kTexRing = 8;     // layers of the texel ring (a power of two: ring slot = key & 7)
-constexpr int kOrgTable = 128;  // layer origins precomputed per block (keys key0 .. key0 + 127; a 32-sample segment spans < 70 layers)
+#ifndef VOXE_FWD_TILE_RING
+#define VOXE_FWD_TILE_RING 6
+#endif
+#ifndef VOXE_FWD_TILE_TABLE
+#define VOXE_FWD_TILE_TABLE 64
+#endif
+// ring of 6 layers (6 KB) + the per-layer table (1 KB): measured 0 - 2 % faster than 8 layers + 128 entries (9.5 KB) on 12 camera /
+// size pairs.  The kernel is occupancy sensitive (3 KB more LDS per block: +13 %), but its 121 VGPRs hold it at 4 waves per SIMD
+// whatever the LDS says; forcing 96 registers spills 51 of them (0.24 -> 0.36 ms).
+constexpr int kTexRing = VOXE_FWD_TILE_RING;     // layers of the texel ring; the ring slot of a layer comes from the per-layer table
+constexpr int kOrgTable = VOXE_FWD_TILE_TABLE;  // layers tabulated per block: keys key0 .. key0 + 63 (a window tile advances <= 1.7 layers per sample: 32 samples + ring < 64)
 
 // The march of one (tile, depth segment) with the march axis M as a COMPILE-TIME constant (r03): the corner -> (layer, lateral
 // offset) mapping, the texel strides and the picks of the cell's (m, u, v) indices fold into immediates.  r02's kernel took
@@ -769,7 +779,7 @@ template <int M>
 __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg& c, const float* __restrict__ packed,
                                                  RayCtx<3, 1, 1>& rc, const int lane, const bool has, const int k_lo,
                                                  const int k_hi, const int kmin, const int kmax, const int ref,
-                                                 float4* __restrict__ tex, int2* __restrict__ org, int* __restrict__ vbase, float (&csum)[3],
+                                                 float4* __restrict__ tex, int4* __restrict__ org, float (&csum)[3],
                                                  float& asum, float& dsum, float& T) {
   constexpr int COUT = 3;
   constexpr int U = (M == 0) ? 1 : 0, V = (M == 2) ? 1 : 2;   // lateral axes (v = z whenever m != z: coalesced layer reads)
@@ -814,8 +824,8 @@ __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg&
   for (int j = 0; j < kOrgTable / 64; ++j) {
     const int im = sgn * (key0 + j * 64 + lane);
     const int ou = (int)floorf(Au + Bu * (float)im) - kCtr, ov = (int)floorf(Av + Bv * (float)im) - kCtr;
-    org[j * 64 + lane] = make_int2(ou, ov);
-    vbase[j * 64 + lane] = im * stride_m + ou * stride_u + ov * stride_v;   // (grids below 2^31 voxels; used only when in range)
+    // (origin u, origin v, voxel offset of the origin -- grids below 2^31 voxels, used only when in range --, ring slot x 64)
+    org[j * 64 + lane] = make_int4(ou, ov, im * stride_m + ou * stride_u + ov * stride_v, ((j * 64 + lane) % kTexRing) * 64);
   }
   __syncthreads();
   const int la = lane >> 3, lb8 = lane & 7;
@@ -825,15 +835,16 @@ __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg&
     const int idx = key - key0;                       // wave-uniform
     float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (idx < kOrgTable) {
-      const int2 o = org[idx];
-      const int vb = vbase[idx];
+      const int4 o = org[idx];
+      const int vb = o.z;
       const int im = sgn * key;
       if ((unsigned)im < (unsigned)Nm && (unsigned)(o.x + la) < (unsigned)Nu && (unsigned)(o.y + lb8) < (unsigned)Nv)
         t = reinterpret_cast<const float4*>(packed)[vb + lane_off];
     }
     return t;
   };
-  auto load_layer = [&](int key) { tex[(key & (kTexRing - 1)) * 64 + lane] = fetch_layer(key); };
+  auto slot64 = [&](int key) { return ((key - key0) % kTexRing) * 64; };   // wave-uniform (scalar unit); == the table's .w
+  auto load_layer = [&](int key) { tex[slot64(key) + lane] = fetch_layer(key); };
   int base = key0;
   int avail = kTexRing;      // layers base .. base + avail - 1 are in LDS (the newest ones of a slide land one sample later)
   float4 pend[2];
@@ -862,17 +873,15 @@ __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg&
         const int kl = minkey(pm);                       // lower key of the footprint's two layers; the other is kl + 1
         const int il = kl - key0;
         const int ilc = min(max(il, 0), kOrgTable - 2);
-        const int2 ol = org[ilc], oh = org[ilc + 1];
-        const int2 o0 = sgn > 0 ? ol : oh, o1 = sgn > 0 ? oh : ol;   // origins of layers pm, pm + 1
+        const int4 ol = org[ilc], oh = org[ilc + 1];
+        const int4 o0 = sgn > 0 ? ol : oh, o1 = sgn > 0 ? oh : ol;   // origins / ring slots of layers pm, pm + 1
         const int a0 = pu - o0.x, b0 = pv - o0.y, a1 = pu - o1.x, b1 = pv - o1.y;
         const bool fits = ((unsigned)(kl - base) < (unsigned)(avail - 1)) && (il == ilc) && ((unsigned)a0 < 7u) &&
                           ((unsigned)b0 < 7u) && ((unsigned)a1 < 7u) && ((unsigned)b1 < 7u);
         float v, rad[COUT];
         if (fits) {
-          const int k0 = sgn > 0 ? kl : kl + 1;           // key of layer pm (k1: layer pm + 1)
-          const int k1 = sgn > 0 ? kl + 1 : kl;
-          const float4* __restrict__ t0 = tex + ((k0 & (kTexRing - 1)) * 64 + a0 * 8 + b0);
-          const float4* __restrict__ t1 = tex + ((k1 & (kTexRing - 1)) * 64 + a1 * 8 + b1);
+          const float4* __restrict__ t0 = tex + (o0.w + a0 * 8 + b0);
+          const float4* __restrict__ t1 = tex + (o1.w + a1 * 8 + b1);
           // gather<3,1,1>() with the eight texels read from the window: corner q = (x + (q & 1), y + ((q >> 1) & 1), z + (q >> 2));
           // the same products and FMA order
           typedef float v2f __attribute__((ext_vector_type(2)));
@@ -922,8 +931,8 @@ __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg&
     // the layers fetched at the previous slide have had this sample's time to arrive: into the ring now
     if (npend > 0) {                              // wave-uniform
       __syncthreads();
-      tex[(pend_key & (kTexRing - 1)) * 64 + lane] = pend[0];
-      if (npend > 1) tex[((pend_key + 1) & (kTexRing - 1)) * 64 + lane] = pend[1];
+      tex[slot64(pend_key) + lane] = pend[0];
+      if (npend > 1) tex[slot64(pend_key + 1) + lane] = pend[1];
       npend = 0;
       avail = kTexRing;
       __syncthreads();
@@ -954,8 +963,7 @@ __global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(D
                                                                 const float fit_m, const float zdom, const float max_adv) {
   constexpr int COUT = 3, NC = COUT + 3;
   __shared__ float4 tex[kTexRing * 64];
-  __shared__ int2 org[kOrgTable];
-  __shared__ int vbase[kOrgTable];
+  __shared__ int4 org[kOrgTable];
   const int lane = threadIdx.x;
   const int nseg = num_segments(c.S, c.seg_len);
   const int nrb = gridDim.x / nseg;                    // tile slots (segment-major block order, like render_fwd_seg_kernel)
@@ -1045,9 +1053,9 @@ __global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(D
         dsum = fmaf(z, wgt, dsum);
       }
     }
-  } else if (m == 0) fwd_window_march<0>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, vbase, csum, asum, dsum, T);
-  else if (m == 1) fwd_window_march<1>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, vbase, csum, asum, dsum, T);
-  else fwd_window_march<2>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, vbase, csum, asum, dsum, T);
+  } else if (m == 0) fwd_window_march<0>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, csum, asum, dsum, T);
+  else if (m == 1) fwd_window_march<1>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, csum, asum, dsum, T);
+  else fwd_window_march<2>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, csum, asum, dsum, T);
   if (!alive) return;
   const long long base = (long long)seg * NC;
   segbuf[(base + 0) * c.R + r] = T;
