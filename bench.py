@@ -261,6 +261,17 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the launch stream, voxe_profile_*) -------------
     ms_fwd = prof["ms_fwd"] / max(prof["n_fwd"], 1)
     ms_bwd = prof["ms_bwd"] / max(prof["n_bwd"], 1)
+    # N > 1: every rank's camera, in-AABB samples per ray and render kernel times -- the ranks of a weak-scaling job render
+    # DIFFERENT views, and the step costs 157 - 182 M rays/s depending on the view: with these a reader can
+    # tell view imbalance from the cost of the exchange
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([float(args.camera + (0 if strong else rank)), s_in_total / max(R, 1), ms_fwd, ms_bwd],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"camera": [int(t[0].item()) for t in allr], "in_aabb_samples_per_ray": [round(t[1].item(), 2) for t in allr],
+                    "fwd_ms": [round(t[2].item(), 4) for t in allr], "bwd_ms": [round(t[3].item(), 4) for t in allr]}
     # the forward kernel of this launch: image-ordered SH-0 renders march through the LDS texel window (r03) unless switched off
     fwd_kernel = ("voxe::render_fwd_tile_kernel" if args.ray_order == "image" and os.environ.get("VOXE_FWD_TILE", "1") != "0"
                   else "voxe::render_fwd_seg_kernel<3, 1, 1>")
@@ -535,6 +546,7 @@ def main():
                 # gradient reduce-scatter / all-to-all + all-gather of the packed grid (nothing overlaps it: the backward
                 # produces the whole gradient, the next forward consumes the whole grid -- DESIGN.md section 6)
                 "exchange_ms_per_step": (round(exchange_ms, 4) if exchange_ms is not None else None),
+                "per_rank": per_rank,
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
                 "untimed_steps_before_timing": PRE_WARM_STEPS + args.warmup,
             },

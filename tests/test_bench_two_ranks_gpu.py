@@ -38,6 +38,7 @@ def test_two_rank_bench_on_one_gpu(exchange, expect):
     assert cfg["replicas_consistent"] is True and cfg["backend"] == "gloo" and cfg["optimizer"] == "fused"
     assert cfg["grad_exchange"].startswith(expect)
     assert cfg["rays_per_gpu_per_step"] == 96 * 96
+    assert cfg["per_rank"]["camera"] == [3, 4] and all(x > 0 for x in cfg["per_rank"]["bwd_ms"])
     if exchange == "auto":
         assert set(cfg["exchange_autotune_ms"]) == {"reduce-scatter", "all-to-all", "all-reduce"}
 
