@@ -39,7 +39,10 @@ SHADER_CLOCK_HZ = 2.4e9  # MI355X peak engine clock (MI355X_MICROARCH.md); the r
 # container: oracle 50.5 k rays/s vs reference 5.7 k rays/s at 160^3, 400x400, fwd+bwd, 8 threads
 ORACLE_VS_REFERENCE_400 = 8.9
 ORACLE_VS_REFERENCE_100 = 2.6
-PRE_WARM_STEPS = int(os.environ.get("VOXE_BENCH_PRE_WARM", "20"))   # untimed clock-settling steps before the W warm-up steps
+# Untimed clock-settling run before the caller's W warm-up steps: the chip's power state settles over hundreds of
+# milliseconds, not over a fixed number of 1 ms steps -- step() runs until this much time has passed (r03's fixed 20 steps
+# = 23 ms left the driver's `--steps 20 --warmup 5` line 3 - 5 % below the builder's `--steps 100 --warmup 20`)
+PRE_WARM_MS = float(os.environ.get("VOXE_BENCH_PRE_WARM_MS", "400"))
 
 
 def parse():
@@ -212,25 +215,57 @@ def main():
                                      None, ws, (42, 0), zero_first=True)
         opt.autotune(ws, layout0)
         first[0] = False                      # autotune left the gradient region cleared
-    # untimed: the first ~10 steps after start-up run below the sustained clocks (measured: 164 vs 168 M rays/s with 3 vs
-    # 20 steps before the timed region), so a fixed clock-settling run precedes the caller's W warm-up steps
-    for _ in range(PRE_WARM_STEPS):
-        step()
+    # untimed, TIME based: step() until PRE_WARM_MS of wall time (device kept busy: the queue never drains between the
+    # synchronisations of a 10-step batch) has passed; every rank runs the same number of steps (collectives inside)
+    def timed_batch(nsteps):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    # Everything that could leave the GPU idle between the clock-settling run and the timed steps happens BEFORE that run
+    # (garbage collection, event creation, profiler arming): r04 found the `--steps 20 --warmup 5` line 5 % below the
+    # `--steps 100 --warmup 20` line of the same lease because the chip dropped its clocks during the ~50 ms of host work
+    # (gc.collect, 1024 hipEventCreate) between the two and was still ramping back up inside the short timed region.
+    gc.collect()          # like timeit: no interpreter garbage collection inside the timed steps
+    gc.disable()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ops.profile_enable(True)    # (creates the library's timing events)
+    untimed_steps, untimed_s = 0, 0.0
+    if PRE_WARM_MS > 0:
+        step()                                # (first call: allocations, lazy initialisation)
+        untimed_s += timed_batch(10)
+        untimed_steps = 11
+        per_step = untimed_s / 10
+        if dist is not None:
+            tt = torch.tensor([per_step], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            per_step = float(tt.item())
+        more = int(min(max(PRE_WARM_MS * 1e-3 - untimed_s, 0.0) / max(per_step, 1e-6), 20000))
+        while more > 0:
+            n = min(more, 200)
+            untimed_s += timed_batch(n)
+            untimed_steps += n
+            more -= n
     for _ in range(args.warmup):
         step()
-    barrier()
     if fused:   # exchange timing of the timed region only (events on the launch stream; 0 for one process)
         opt.read_exchange_ms()
         opt.exchange_ms, opt.exchange_steps = 0.0, 0
-    gc.collect()          # like timeit: no interpreter garbage collection inside the timed steps
-    gc.disable()
     ops.profile_enable(True)
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         step()
+    marks[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    step_ms_in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_ms_in_order)
     exchange_ms = opt.read_exchange_ms() if fused else None
     prof = ops.profile_read()
     ops.profile_enable(False)
@@ -273,7 +308,9 @@ def main():
         per_rank = {"camera": [int(t[0].item()) for t in allr], "in_aabb_samples_per_ray": [round(t[1].item(), 2) for t in allr],
                     "fwd_ms": [round(t[2].item(), 4) for t in allr], "bwd_ms": [round(t[3].item(), 4) for t in allr]}
     # the forward kernel of this launch: image-ordered SH-0 renders march through the LDS texel window (r03) unless switched off
-    fwd_kernel = ("voxe::render_fwd_tile_kernel" if args.ray_order == "image" and os.environ.get("VOXE_FWD_TILE", "1") != "0"
+    from voxe_hip import dispatch as _dispatch
+
+    fwd_kernel = ("voxe::render_fwd_tile_kernel" if args.ray_order == "image" and _dispatch.current().fwd_window >= 0
                   else "voxe::render_fwd_seg_kernel<3, 1, 1>")
     # algorithmic bytes: per in-AABB sample 8 corners x 4 ch x 4 B = 128 B read (fwd),
     # 128 B re-read + 128 B gradient scatter (bwd); per ray 24 B rays + outputs/upstream I/O
@@ -358,8 +395,12 @@ def main():
         physical["note"] = ("counters per launch from the committed PMC summary whose source_hash equals this tree's; launch time "
                             "(HIP events) and shader clock (voxe_clock_probe: s_memtime / s_memrealtime under a VALU + LDS load, "
                             "right behind the timed steps) are THIS run's; `at_peak_clock` = the same fractions against 2.4 GHz")
+    binding = physical.get("binding") if physical and not physical.get("stale") else None
     roofline = {
-        "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `bound`: the ceiling that actually binds the dominant kernel when the PMC summary of THESE sources is at hand
+        # ("lds_issue" / "valu_issue" / "hbm": see `physical`); `achieved` / `peak` / `frac` are SURVEY 8(d)'s HBM-unit
+        # requested-bytes figures whatever binds (`bound_of_frac`)
+        "bound": binding or "hbm", "bound_of_frac": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
         "kernel": kname, "alg_bytes_per_launch": int(kbytes), "launch_ms": round(kms, 4),
         # `achieved` / `frac` follow SURVEY.md 8(d)'s REQUESTED-bytes model (every trilinear corner fetch / scatter
@@ -417,12 +458,12 @@ def main():
                 ops.adam_step_(flat_p, flat_g, exp_avg, exp_avg_sq, step_no[0], lr=1e-4)
 
             first[0] = True   # (another workspace: its gradient region starts uncleared)
-            for _ in range(args.warmup):
+            gc.collect()      # (a generation-2 collection of the interpreter inside the timed steps showed up as a 35 ms stall;
+            gc.disable()      #  behind the warm-up it would let the chip drop its clocks: it runs BEFORE the warm-up)
+            for _ in range(max(args.warmup, 10)):
                 step2()
-            torch.cuda.synchronize()
-            gc.collect()      # (a generation-2 collection of the interpreter inside the timed steps showed up as a 35 ms stall)
-            gc.disable()
             ops.profile_enable(True)
+            torch.cuda.synchronize()
             t2 = time.perf_counter()
             for _ in range(steps):
                 step2()
@@ -450,7 +491,7 @@ def main():
         # the backward's LDS window is view dependent (profiles/r03_ab_orientation.txt)
         views = {}
         for cam in [int(x) for x in os.environ.get("VOXE_BENCH_VIEWS", "0,12,26,40,77,90").split(",")]:
-            v = small_step_bench(1, hw2=HW, cam0=cam, steps=max(5, args.steps // 2))
+            v = small_step_bench(1, hw2=HW, cam0=cam)
             views[str(cam)] = {k: v[k] for k in ("value", "ms_per_step", "fwd_ms", "bwd_ms", "in_aabb_samples_per_ray")}
         mean_ms = (sum(v["ms_per_step"] for v in views.values()) + ms_per_step) / (len(views) + 1)
         secondary["views"] = {"workload": f"the headline step from 6 other cameras of the 100-view set ({HW}x{HW})", "cameras": views,
@@ -470,7 +511,7 @@ def main():
             ro_b, rd_b = ops.cast_rays(hw, hw, focal_for(hw), pose.rotation, pose.translation, dev)
             gb = torch.randn((hw * hw, 3), generator=torch.Generator().manual_seed(43)).to(dev)
             dt = tb.time_step(dens_cpu.to(dev), feat_cpu.to(dev), aabb, 100.0 / 3.0, ro_b, rd_b, gb, S, NEAR, FAR,
-                              chunk=32768, steps=steps, warmup=1)
+                              chunk=32768, steps=steps, warmup=1, median=True)
             return hw * hw / dt, dt
 
         try:
@@ -481,6 +522,7 @@ def main():
                 "what": "PyTorch-ROCm restatement of the reference path (F.grid_sample x2, softplus, exp, cumprod, autograd, "
                         "torch.optim.Adam; 32768-ray chunks like parallel_rays_chunk_size) on this GPU, same grid / camera / S",
                 "ms_per_step": round(1e3 * dt_full, 2), "speedup": round(rays_per_s / rps_full, 1),
+                "reps": 3, "protocol": "1 warm-up step + median of 3 individually timed steps (5 at 100x100)",
                 "at_100x100": {"value": round(rps_small, 1), "ms_per_step": round(1e3 * dt_small, 2)},
                 "torch": torch.__version__,
             }
@@ -505,30 +547,40 @@ def main():
             vo.render_bwd(grid, cfg, o, d, gc)
             return time.perf_counter() - t1
 
-        # bounded sample: the GPU's full image when a 128x128 probe says it fits ~30 s of wall time, a smaller image otherwise
+        # bounded sample: the GPU's full image when a 128x128 probe says four passes fit ~30 s of wall time, a smaller image
+        # otherwise.  Protocol: one warm-up pass, then the MEDIAN of `reps` timed passes.
         hw = args.cpu_sample
+        cpu_pass(64)                          # thread start-up / first touch
         if hw <= 0:
-            cpu_pass(64)                      # thread start-up / first touch
             probe = cpu_pass(128)
             full = probe * (HW / 128.0) ** 2  # upper bound: the per-call fixed cost (gradient grids) does not scale
-            hw = HW if full <= 30.0 else int(max(128, 128 * (20.0 / max(probe, 1e-3)) ** 0.5))
-        dt = cpu_pass(hw)
+            hw = HW if 4.0 * full <= 30.0 else int(max(128, 128 * (6.0 / max(probe, 1e-3)) ** 0.5))
+        cpu_pass(hw)                          # warm-up at the sample's size
+        reps = 3
+        passes = sorted(cpu_pass(hw) for _ in range(reps))
+        dt = passes[reps // 2]
         threads = vo.num_threads()
         cpu_baseline = {
-            "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port",
+            "value": round(hw * hw / dt, 1), "unit": "rays/s", "cores": threads, "kind": "port", "reps": reps,
+            "passes_s": [round(x, 3) for x in passes],
             # the port is FASTER than the reference's own CPU path: on the same 8 vCPUs (build container) it renders
             # 8.9x the reference PyTorch's rays/s at 400x400 and 2.6x at 100x100, so the reference
             # on these host cores would be about value / vs_reference_factor
             "vs_reference_factor": ORACLE_VS_REFERENCE_400 if hw >= 256 else ORACLE_VS_REFERENCE_100,
             "reference_equivalent_rays_per_s": round(hw * hw / dt / (ORACLE_VS_REFERENCE_400 if hw >= 256 else ORACLE_VS_REFERENCE_100), 1),
             "sample": f"{hw}x{hw} rays of camera {args.camera} (same {G}^3 grid, S={S}, jitter on), 1 forward + 1 backward "
-                      f"of oracle/voxe_cpu.c with OpenMP: {dt:.1f} s wall x {threads} threads = {dt * threads:.0f} core-seconds",
+                      f"of oracle/voxe_cpu.c with OpenMP per pass; 1 warm-up + median of {reps} passes: {dt:.2f} s wall x {threads} "
+                      f"threads = {dt * threads:.0f} core-seconds",
         }
 
     if rank == 0:
         out = {
             "metric": "rendered rays/sec (fwd+bwd)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # per-step device time between consecutive events on the launch stream (rank 0): median / min / max of the K
+            # timed steps; `ms_per_step` above is the contract's wall clock over all K steps / K, max over ranks
+            "ms_per_step_median": round(step_ms[len(step_ms) // 2], 4), "ms_per_step_min": round(step_ms[0], 4),
+            "ms_per_step_max": round(step_ms[-1], 4), "ms_first_steps": [round(x, 4) for x in step_ms_in_order[:6]],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
@@ -548,7 +600,7 @@ def main():
                 "exchange_ms_per_step": (round(exchange_ms, 4) if exchange_ms is not None else None),
                 "per_rank": per_rank,
                 "term_eps": args.term_eps, "optimizer": ("none" if args.no_adam else ("fused" if fused else "split")),
-                "untimed_steps_before_timing": PRE_WARM_STEPS + args.warmup,
+                "untimed_warmup_ms": round(1e3 * untimed_s, 1), "untimed_steps_before_timing": untimed_steps + args.warmup,
             },
             "roofline": roofline, "secondary": secondary,
             "gpu_baseline": gpu_baseline, "cpu_baseline": cpu_baseline,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 6
+#define VOXE_ABI_VERSION 7
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -71,6 +71,37 @@ typedef struct VoxeGridDesc {
   int32_t density_post_act; /* VoxeAct: IDENTITY | RELU | SOFTPLUS                                */
   int32_t feature_kind;     /* VoxeFeatureKind                                                    */
 } VoxeGridDesc;
+
+/* Which kernels render a call, and with which tuning parameters (ABI v7).  Every field: 0 = the shipped default, so a
+ * zero-initialised struct -- or VoxeRenderCfg::dispatch == NULL -- is the shipped dispatch.  The struct is read on every call
+ * from the caller's memory: there is no process-global dispatch state in the library and nothing reads the environment on
+ * the render path (the Python binding resolves its VOXE_* environment switches ONCE into one of these, voxe_hip/dispatch.py).
+ * Forward and backward of one render must be given the same values (the per-ray states a forward leaves in the workspace
+ * belong to one route: voxe_render_route).  Results never depend on these fields beyond float summation order. */
+typedef struct VoxeDispatch {
+  int32_t bwd_mode;            /* 0 auto | 1 plain global-atomic scatter (the A/B baseline) | 2 line-dense scatter            */
+  int32_t tile_map;            /* block -> pixel-tile map: 0 auto | 1 interleaved over the XCDs | 2 XCD bands | 3 tile rows    */
+  int64_t tile_min_rays;       /* image-ordered renders below this many rays take the line-dense scatter backward instead of
+                                  the LDS-window one: 0 = 8192 | > 0 explicit | -1 no minimum                                 */
+  int32_t tile_two_phase;      /* view-dependent grids: 0 two-phase backward when the workspace holds the per-sample sources |
+                                  -1 always the single-kernel channel groups                                                  */
+  int32_t tile_qsplit;         /* parts of a tile that does not fit the window: 0 auto (by launch size) | 1 consecutive passes
+                                  of one block | 4 sibling blocks                                                             */
+  int32_t tile_kl;             /* lateral edge of the backward's LDS window (voxels): 0 auto | 8 | 10                          */
+  float tile_fit_m;            /* a pass fits the window when its spread along the march axis is below this many layers:
+                                  0 = by launch size (4.0 ... 5.5)                                                            */
+  float tile_fit_lat;          /* ... and its lateral extent below this many voxels: 0 = window edge - 2.5                     */
+  int32_t fwd_window;          /* LDS texel window of the SH-0 image-ordered forward: 0 on | -1 off (ray-ordered forward)      */
+  float fwd_fit_lat, fwd_fit_m;/* window forward: fit bounds of a tile (0 = 5.5 voxels / 4.5 layers)                           */
+  float fwd_zdom;              /* a tile marches along z (ray by ray) when |d_z| >= this x max(|d_x|, |d_y|):
+                                  0 = 1.0 | < 0: z-dominant tiles go through the window too (experiment)                      */
+  float fwd_max_adv;           /* layers a window tile may advance per sample: 0 = 1.7                                         */
+  int32_t fwd_segments_per_thread; /* depth segments one thread of the ray-ordered forward walks: 0 = 1                        */
+  int64_t region_min_rays;     /* space-binned route for unordered / sparse rays from this many rays on: 0 = 16384 | > 0
+                                  explicit | -1 route off                                                                     */
+  float region_image_ratio;    /* image-ordered launches take the space-binned route when grid side >= this x image width:
+                                  0 = 1.3 | < 0: every image-ordered launch the route accepts                                 */
+} VoxeDispatch;
 
 typedef struct VoxeRenderCfg {
   int32_t num_samples;        /* S   SHVoxGridRenderConfig.num_samples_per_ray (renderers.py:32)  */
@@ -114,6 +145,7 @@ typedef struct VoxeRenderCfg {
                                  samples) written by voxe_render_fwd for EXACTLY these rays / cfg /
                                  jitter, so the depth-segmented backward starts from them.
                                  0: the backward first re-marches the rays to rebuild them.       */
+  const VoxeDispatch* dispatch; /* HOST pointer, NULL = the shipped dispatch; read during the call only (ABI v7)      */
 } VoxeRenderCfg;
 
 /* depth-segment length of the segmented kernels (samples per segment); launches of at most 20000 rays use 16: they

@@ -16,10 +16,38 @@ for p in (os.path.join(ROOT, "vox-e_amd"), ROOT):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# Image-ordered renders below 8192 rays take the scatter backward by default (faster on an empty chip); the parity
-# tests use small images, so they lower the threshold to keep exercising the LDS-window backward.  The scatter
-# backward is covered by the unordered-ray cases (tests/test_hip_fuzz.py, bench --ray-order random).
-os.environ.setdefault("VOXE_TILE_MIN_RAYS", "0")
+# The suite runs under the SHIPPED kernel dispatch (voxe_hip.dispatch.SHIPPED: e.g. image-ordered renders below 8192 rays take
+# the line-dense scatter backward).  Tests that are about one particular route ask for it through the C ABI, call by call
+# (VoxeRenderCfg::dispatch): the `disp` fixture replaces fields of the dispatch the helpers hand to every render call of ONE
+# test; modules whose small images are meant to exercise the LDS-window (tile) backward use the `tile_always` fixture.
+class _DispatchPatch:
+    def __init__(self):
+        from voxe_hip import dispatch
+
+        self._mod = dispatch
+        self._saved = dispatch._override
+
+    def set(self, **fields):
+        import dataclasses
+
+        self._mod._override = dataclasses.replace(self._mod.current(), **fields)
+
+    def restore(self):
+        self._mod._override = self._saved
+
+
+@pytest.fixture
+def disp():
+    p = _DispatchPatch()
+    yield p
+    p.restore()
+
+
+@pytest.fixture
+def tile_always(disp):
+    """image-ordered renders of any size through the LDS-window backward (VoxeDispatch::tile_min_rays = -1)"""
+    disp.set(tile_min_rays=-1)
+    yield disp
 
 
 def pytest_configure(config):

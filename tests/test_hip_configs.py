@@ -217,12 +217,12 @@ def test_cfg4_attention_render_160_vs_oracle(hw, cam):
     assert rel_l2(gd, rd) < GRAD_TOL, rel_l2(gd, rd)
 
 
-# ---- the SHIPPED dispatch for small images (tests/conftest.py lowers VOXE_TILE_MIN_RAYS to 0 for everything else) -------
+# ---- the SHIPPED dispatch for small images (explicitly: whatever the surrounding fixtures asked for) -------
 @pytest.mark.parametrize("hw", [64, 100])
-def test_default_dispatch_small_images_vs_oracle(hw, monkeypatch):
+def test_default_dispatch_small_images_vs_oracle(hw, disp):
     """with the default threshold an image below 8192 rays takes the depth-segmented scatter backward and 100x100 the
     LDS-window backward: run exactly what ships"""
-    monkeypatch.delenv("VOXE_TILE_MIN_RAYS", raising=False)
+    disp.set(tile_min_rays=0, region_min_rays=0, tile_kl=0)
     grid = _grid(160, "sphere")
     o, d = _rays(hw, 21)
     cfg = make_render_cfg(S, NEAR, FAR, white_bkgd=True)
@@ -231,7 +231,6 @@ def test_default_dispatch_small_images_vs_oracle(hw, monkeypatch):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, image_width=hw)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL
-    assert os.environ.get("VOXE_TILE_MIN_RAYS") is None
 
 
 # ---- multi-view launches: K cameras of the same size in ONE image-ordered launch (VoxeRenderCfg::image_height) ----------
@@ -334,17 +333,17 @@ def test_deterministic_backward_attention_grid_and_unsupported_cases():
 
 
 # ---- space-binned render (voxe_render_region.hip: forward AND backward) forced onto small cases, every variant vs the oracle --
-def _region_env(monkeypatch, image_too=False):
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
+def _region_env(disp, image_too=False):
+    disp.set(region_min_rays=1)
     if image_too:
-        monkeypatch.setenv("VOXE_REGION_IMAGE_RATIO", "0")
+        disp.set(region_image_ratio=-1.0)
 
 
 @pytest.mark.parametrize("case", ["sh0_jitter", "sh0_clip_lindisp", "attn", "diffuse_sh1", "tiny_grid", "image_ordered",
                                   "density_only", "features_only", "jitter_tensor", "sh1", "sh2", "sh1_density_only",
                                   "sh2_features_only"])
-def test_region_backward_variants_vs_oracle(case, monkeypatch):
-    _region_env(monkeypatch, image_too=(case == "image_ordered"))
+def test_region_backward_variants_vs_oracle(case, disp):
+    _region_env(disp, image_too=(case == "image_ordered"))
     rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)   # (not hash(): salted per process)
     dims = (5, 6, 7) if case == "tiny_grid" else (40, 33, 48)
     # (sh1 / sh2: view-dependent grids -- whole texels in LDS, two-phase backward; r03)
@@ -394,7 +393,7 @@ def test_region_backward_variants_vs_oracle(case, monkeypatch):
         assert rel_l2(got, ref) < GRAD_TOL
 
 
-def test_region_backward_equals_scatter_backward_on_a_random_batch(monkeypatch):
+def test_region_backward_equals_scatter_backward_on_a_random_batch(disp):
     """same rays through the space-binned backward and through the line-dense scatter it replaces for large batches"""
     grid = _grid(96, "random")
     o, d = _rays(300, 9)
@@ -402,20 +401,20 @@ def test_region_backward_equals_scatter_backward_on_a_random_batch(monkeypatch):
     o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
     cfg = make_render_cfg(128, NEAR, FAR, perturb=True, white_bkgd=True, seed=1, rng_offset=1)
     gc = np.random.default_rng(3).standard_normal((o.shape[0], 3)).astype(np.float32)
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
+    disp.set(region_min_rays=-1)
     a = gh.hip_backward(grid, cfg, o, d, gc, rng=(1, 1))
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
+    disp.set(region_min_rays=1)
     b = gh.hip_backward(grid, cfg, o, d, gc, rng=(1, 1))
     assert rel_l2(a[0], b[0]) < 5e-5 and rel_l2(a[1], b[1]) < 2e-6, (rel_l2(a[0], b[0]), rel_l2(a[1], b[1]))
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(b[0], rd) < GRAD_TOL and rel_l2(b[1], rf) < GRAD_TOL
 
 
-def test_region_render_generic_bin_vs_oracle(monkeypatch):
+def test_region_render_generic_bin_vs_oracle(disp):
     """few samples over a fine grid (a step of ~4 voxels): nearly every sample starts a new region, a (ray, 32-sample
     depth segment) lane runs out of its 16 segment slots and the rest of its samples go through the GENERIC bin (texels
     from global memory, global atomics, shared by many blocks) -- forward and gradients still equal the oracle"""
-    _region_env(monkeypatch)
+    _region_env(disp)
     grid = _grid(96, "random")
     o, d = _rays(200, 13)
     sel = np.random.default_rng(4).permutation(o.shape[0])[:21000]      # > 20000 rays: 32-sample depth segments
@@ -431,11 +430,11 @@ def test_region_render_generic_bin_vs_oracle(monkeypatch):
 # ---- LDS-staged forward (render_fwd_tile_kernel) against the ray-ordered forward: bit-identical outputs -------------------
 @pytest.mark.parametrize("case", ["400", "266_oblique", "100_sparse", "multi_view", "clip_jitter_tensor", "lindisp", "tiny_grid",
                                   "x_march", "z_march", "z_dominant_default"])
-def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, monkeypatch):
+def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, disp):
     """same interpolation arithmetic, texels from the LDS window instead of L1 / L2 (or from the global fallback for
     footprints outside the window: sparse pixels, oblique tiles, tiny grids): every output bit equal, and equal to the
     oracle within the forward tolerance"""
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
+    disp.set(region_min_rays=-1)
     rng = np.random.default_rng(zlib.crc32(case.encode()) % 997)
     kw, over, jit = dict(white_bkgd=True), {}, None
     if case == "tiny_grid":
@@ -450,7 +449,7 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, mo
                    # camera 77 looks along x, camera 12 mostly along z (ray by ray by default; VOXE_FWD_TILE_ZDOM < 0 marches z)
                    "x_march": (320, 77), "z_march": (320, 12), "z_dominant_default": (320, 12)}[case]
     if case == "z_march":
-        monkeypatch.setenv("VOXE_FWD_TILE_ZDOM", "-1.0")
+        disp.set(fwd_zdom=-1.0)
     o, d = _rays(hw, cam)
     if case == "multi_view":
         o2, d2 = _rays(hw, cam + 30)
@@ -465,9 +464,9 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, mo
     if case == "lindisp":
         kw.update(linear_disparity=True)
     cfg = make_render_cfg(S_, NEAR, FAR, **kw)
-    monkeypatch.setenv("VOXE_FWD_TILE", "0")
+    disp.set(fwd_window=-1)
     a = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
-    monkeypatch.setenv("VOXE_FWD_TILE", "1")
+    disp.set(fwd_window=0)
     b = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
     for key in ("colour", "depth", "acc"):
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
     from thre3d_atom.utils.imaging_utils import pose_spherical
-    from voxe_hip import abi, ops
+    from voxe_hip import abi, dispatch, ops
 
 AABB = ((-1.5, 1.5),) * 3
 LR = 3e-3
@@ -164,7 +164,9 @@ def test_fused_step_equals_split_step(case):
     spec = ops.GridSpec(aabb=AABB, density_scale=100.0 / 3.0 if post == "softplus" else 1.0, density_pre_act=acts[pre],
                         density_post_act=acts[post], feature_kind=abi.FEAT_ATTN if kind == "attn" else abi.FEAT_SH)
     params = ops.RenderParams(num_samples=96, near=NEAR, far=FAR, perturb=True, white_bkgd=kind != "attn",
-                              sh_degree=1 if kind == "sh1" else 0, image_width=hw if ordered else 0)
+                              sh_degree=1 if kind == "sh1" else 0, image_width=hw if ordered else 0,
+                              # (48x48 is below the shipped tile threshold: the ordered cases ask for the LDS-window backward)
+                              dispatch=dispatch.TILE_ALWAYS if ordered else None)
     cout = 1 if kind == "attn" else 3
     shadow = _Run("shadow", dens, feat, spec, params, ro, rd, cout, **kw)
     split = _Run("split", dens, feat, spec, params, ro, rd, cout, **kw)

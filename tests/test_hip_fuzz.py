@@ -12,7 +12,9 @@ from voxe_hip.desc import make_render_cfg
 
 from oracle import voxe_oracle as vo
 
-pytestmark = pytest.mark.gpu
+# the small images of this module are meant for the LDS-window (tile) backward: every render call asks for it through
+# VoxeRenderCfg::dispatch (tile_min_rays = -1); the shipped thresholds are exercised by the other GPU modules
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("tile_always")]
 
 if torch.cuda.is_available():
     import gpu_helpers as gh

@@ -54,7 +54,7 @@ BAND_BARS = {"features": {(1e-3, 1.0): 2e-6, (1e-6, 1e-3): 3e-6, (1e-9, 1e-6): 5
 
 
 @pytest.mark.parametrize("route", ["tile", "region", "scatter"])
-def test_gradient_error_per_magnitude_band_at_bench_size(route, monkeypatch):
+def test_gradient_error_per_magnitude_band_at_bench_size(route, disp):
     """median relative error of the voxel gradients per decade band of |oracle gradient| / max: a deposit that goes wrong
     only for faint voxels (lost corners, a quantised window) fails here and passes a global rel-L2"""
     grid = _grid()
@@ -65,7 +65,7 @@ def test_gradient_error_per_magnitude_band_at_bench_size(route, monkeypatch):
     else:
         perm = np.random.default_rng(11).permutation(o.shape[0])
         o, d = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm])
-        monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "16384" if route == "region" else "-1")
+        disp.set(region_min_rays=16384 if route == "region" else -1)
     cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=42, rng_offset=7)
     gc_ = np.random.default_rng(43).standard_normal((o.shape[0], 3)).astype(np.float32)
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc_, rng=(42, 7), **over)
@@ -83,11 +83,11 @@ def test_gradient_error_per_magnitude_band_at_bench_size(route, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["random_batch", "sparse_image", "generic_bin"])
-def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, monkeypatch):
+def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, disp):
     """the segment tables the production forward writes: (a) every sample the ORACLE's probe calls inside belongs to
     exactly one segment of its ray; (b) a segment's samples all start in the segment's region (generic bin excepted);
     (c) the counting sort is a permutation: `sorted` lists every used slot once, inside its region's range"""
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "1")
+    disp.set(region_min_rays=1)
     grid = _grid(96)
     Sn = 128
     if case == "random_batch":
@@ -96,7 +96,7 @@ def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, mon
         o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
         over = {}
     elif case == "sparse_image":
-        monkeypatch.setenv("VOXE_REGION_IMAGE_RATIO", "0")
+        disp.set(region_image_ratio=-1.0)
         o, d = _rays(56, 21)
         over = dict(image_width=56)
     else:   # few samples over a fine grid: lanes run out of slots, the rest goes to the generic bin
@@ -274,7 +274,7 @@ def test_fused_grid_adam_counts_steps_per_parameter():
     torch.testing.assert_close(fg.features.detach(), rg.features.detach(), rtol=1e-4, atol=2e-6)
 
 
-def test_render_route_and_clock_probe(monkeypatch):
+def test_render_route_and_clock_probe(disp):
     """voxe_render_route names the kernels a render resolves to (it is part of the ray-state key: forward and backward must
     agree), also when a tuning switch flips between the two calls; voxe_clock_probe returns a plausible shader clock"""
     import ctypes as C
@@ -295,11 +295,11 @@ def test_render_route_and_clock_probe(monkeypatch):
     assert route(3000) == abi.ROUTE_PACKED_SCATTER
     assert route(96 * 96, image_width=96, deterministic=True) == abi.ROUTE_DETERMINISTIC
     assert route(0) == abi.ROUTE_NONE
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")
+    disp.set(region_min_rays=-1)
     assert route(20000) == abi.ROUTE_PACKED_SCATTER
     # the switch flipped between a forward and its backward: the states of the other route are NOT taken for valid -- the
     # backward re-marches and the gradients still equal the oracle's
-    monkeypatch.delenv("VOXE_REGION_MIN_RAYS")
+    disp.set(region_min_rays=0)
     o, d = _rays(150, 5)
     sel = np.random.default_rng(1).permutation(o.shape[0])[:17000]
     o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
@@ -307,7 +307,7 @@ def test_render_route_and_clock_probe(monkeypatch):
     dt, ft = gh.t(grid.densities, True), gh.t(grid.features, True)
     colour = ops.render(spec, gh.params_of(cfg), dt, ft, gh.t(o), gh.t(d))[0]          # forward: space-binned route
     gc_ = np.random.default_rng(2).standard_normal((o.shape[0], 3)).astype(np.float32)
-    monkeypatch.setenv("VOXE_REGION_MIN_RAYS", "-1")                                  # backward: line-dense scatter
+    disp.set(region_min_rays=-1)                                  # backward: line-dense scatter
     (colour * gh.t(gc_)).sum().backward()
     torch.cuda.synchronize()
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc_)

@@ -14,7 +14,9 @@ from voxe_hip.desc import make_render_cfg
 
 from oracle import voxe_oracle as vo
 
-pytestmark = pytest.mark.gpu
+# the small images of this module are meant for the LDS-window (tile) backward: every render call asks for it through
+# VoxeRenderCfg::dispatch (tile_min_rays = -1); the shipped thresholds are exercised by the other GPU modules
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("tile_always")]
 
 if torch.cuda.is_available():
     import gpu_helpers as gh
@@ -427,14 +429,14 @@ def test_sample_counts_across_segment_boundaries(S):
 
 @pytest.mark.parametrize("deg", [1, 2, 3])
 @pytest.mark.parametrize("mode", ["full", "diffuse", "full_single_kernel"])
-def test_sh_degrees_image_ordered_backward(deg, mode, monkeypatch):
+def test_sh_degrees_image_ordered_backward(deg, mode, disp):
     """view-dependent grids with image-ordered rays: the LDS-window backward runs the 3 * (deg + 1)^2 + 1 gradient
     channels as groups of 4 (sibling blocks); gradients vs the oracle, vs the ray-order-agnostic kernel, and with one of
     the two tensors frozen (density only: just the group that holds the density channel is launched).  "full" takes the
     two-phase route (per-sample gradient sources in the workspace, then one deposit block per group),
     "full_single_kernel" the groups that re-march (what runs when the workspace has no room for the sources)"""
     if mode == "full_single_kernel":
-        monkeypatch.setenv("VOXE_TILE_TWO_PHASE", "0")
+        disp.set(tile_two_phase=-1)
     g = load_golden("frames32.npz")
     base = grid_from_golden(g, "", "softplus")
     rng = np.random.default_rng(deg)
@@ -469,7 +471,7 @@ def test_sh_degrees_image_ordered_backward(deg, mode, monkeypatch):
             assert dt.grad is None and rel_l2(gh.n(ft.grad), rf) < GRAD_REL_L2
 
 
-def test_early_termination_sh1_routes_agree(monkeypatch):
+def test_early_termination_sh1_routes_agree(disp):
     """term_eps > 0 on a view-dependent grid: the two-phase window backward (the source pass keeps writing zeros after a
     ray terminated), the single-kernel channel groups and the line-dense scatter all differentiate the same forward"""
     g = load_golden("frames32.npz")
@@ -481,9 +483,9 @@ def test_early_termination_sh1_routes_agree(monkeypatch):
     cfg = cfg_from_bounds(g["bounds"], 128, white_bkgd=True, sh_degree=1)
     gc = rng.standard_normal((1600, 3)).astype(np.float32)
     two_d, two_f = gh.hip_backward(grid, cfg, o, d, gc, image_width=40, term_eps=1e-3)
-    monkeypatch.setenv("VOXE_TILE_TWO_PHASE", "0")
+    disp.set(tile_two_phase=-1)
     one_d, one_f = gh.hip_backward(grid, cfg, o, d, gc, image_width=40, term_eps=1e-3)
-    monkeypatch.delenv("VOXE_TILE_TWO_PHASE")
+    disp.set(tile_two_phase=0)
     sc_d, sc_f = gh.hip_backward(grid, cfg, o, d, gc, term_eps=1e-3)
     full_d, full_f = gh.hip_backward(grid, cfg, o, d, gc, image_width=40)
     assert rel_l2(two_d, one_d) < 1e-5 and rel_l2(two_f, one_f) < 1e-5
@@ -493,10 +495,10 @@ def test_early_termination_sh1_routes_agree(monkeypatch):
 
 @pytest.mark.parametrize("kl", [8, 10])
 @pytest.mark.parametrize("hw,cam", [((40, 56), 2), ((33, 47), 5), ((96, 96), 3)])
-def test_window_width_variants(kl, hw, cam, monkeypatch):
+def test_window_width_variants(kl, hw, cam, disp):
     """the LDS-window backward with both lateral window widths (8: fine images, 10: about one pixel per voxel or fewer),
     whatever the launch heuristic would pick: gradients vs the oracle"""
-    monkeypatch.setenv("VOXE_TILE_KL", str(kl))
+    disp.set(tile_kl=int(kl))
     g = load_golden("frames32.npz")
     grid = grid_from_golden(g, "", "softplus")
     h, w = hw

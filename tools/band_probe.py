@@ -6,6 +6,7 @@ import gpu_helpers as gh
 from helpers import band_errors, rel_l2
 from voxe_hip.workload import *
 from voxe_hip import abi
+from voxe_hip.dispatch import Dispatch
 from voxe_hip.desc import make_render_cfg
 from oracle import voxe_oracle as vo
 from thre3d_atom.utils.imaging_utils import pose_spherical
@@ -20,13 +21,11 @@ inv = np.argsort(perm)
 rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
 res = {}
 res["tile"] = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, 7), image_width=400)
-os.environ["VOXE_REGION_MIN_RAYS"] = "16384"
 # NOTE: the in-kernel jitter is keyed by ray index: a permuted batch draws other jitter -> compare permuted runs with an oracle run on the permuted rays
 op, dp, gp = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm]), np.ascontiguousarray(gc[perm])
 rdp, rfp = vo.render_bwd(grid, cfg, op, dp, gp)
-res["region"] = gh.hip_backward(grid, cfg, op, dp, gp, rng=(42, 7))
-os.environ["VOXE_REGION_MIN_RAYS"] = "-1"
-res["scatter"] = gh.hip_backward(grid, cfg, op, dp, gp, rng=(42, 7))
+res["region"] = gh.hip_backward(grid, cfg, op, dp, gp, rng=(42, 7), dispatch=Dispatch(region_min_rays=16384))
+res["scatter"] = gh.hip_backward(grid, cfg, op, dp, gp, rng=(42, 7), dispatch=Dispatch(region_min_rays=-1))
 bands = [(1e-3, 1.0), (1e-6, 1e-3), (1e-9, 1e-6)]
 for k, (gd, gf) in res.items():
     r_d, r_f = (rd, rf) if k == "tile" else (rdp, rfp)
@@ -37,7 +36,7 @@ print("region vs scatter")
 for nm, a, b in (("dens", res["region"][0], res["scatter"][0]), ("feat", res["region"][1], res["scatter"][1])):
     print("  ", nm, {bb: tuple(f"{x:.2e}" if isinstance(x, float) else x for x in v) for bb, v in band_errors(a, b, bands).items()})
 # tile vs scatter on the SAME rays in image order (scatter without the width hint)
-sc = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, 7))
+sc = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, 7), dispatch=Dispatch(region_min_rays=-1))
 print("tile vs scatter(image order, no hint)")
 for nm, a, b in (("dens", res["tile"][0], sc[0]), ("feat", res["tile"][1], sc[1])):
     print("  ", nm, {bb: tuple(f"{x:.2e}" if isinstance(x, float) else x for x in v) for bb, v in band_errors(a, b, bands).items()})

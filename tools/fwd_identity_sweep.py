@@ -6,13 +6,15 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "vox-e_amd"))
 from voxe_hip import ops  # noqa: E402
+from voxe_hip.dispatch import Dispatch  # noqa: E402
 from voxe_hip.workload import synth_pose_angles, RADIUS, NEAR, FAR, focal_for, random_grid, sphere_grid  # noqa: E402
 from thre3d_atom.utils.imaging_utils import pose_spherical  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(123)
 dev = torch.device("cuda", 0)
-FORCE = {"VOXE_FWD_TILE_ZDOM": "-1.0", "VOXE_FWD_TILE_ADV": "9", "VOXE_FWD_TILE_FIT_LAT": "7", "VOXE_FWD_TILE_FIT_M": "7"}
+MODES = {"off": Dispatch(fwd_window=-1), "default": Dispatch(),
+         "forced": Dispatch(fwd_zdom=-1.0, fwd_max_adv=9.0, fwd_fit_lat=7.0, fwd_fit_m=7.0)}
 bad = 0
 for it in range(n):
     side = int(rng.choice([48, 64, 96, 128, 160]))
@@ -27,11 +29,7 @@ for it in range(n):
     prm = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=bool(rng.random() < 0.7), white_bkgd=True, image_width=hw)
     outs = {}
     for mode in ("off", "default", "forced"):
-        for k in FORCE:
-            os.environ.pop(k, None)
-        os.environ["VOXE_FWD_TILE"] = "0" if mode == "off" else "1"
-        if mode == "forced":
-            os.environ.update(FORCE)
+        prm.dispatch = MODES[mode]
         with torch.no_grad():
             c, d, a, _ = ops.render(spec, prm, dens, feat, ro, rd, None, rng=(7, it))
         torch.cuda.synchronize()

@@ -21,15 +21,15 @@ timeout 300 python bench.py --image 266 --no-cpu-baseline --no-gpu-baseline 2>/d
 timeout 300 python bench.py --optimizer split --no-cpu-baseline --no-gpu-baseline 2>/dev/null | tail -1 > $O/bench_400_split_optimizer.json
 timeout 300 env VOXE_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-gpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/bench_400_rccl_1rank.json
 # two ranks sharing the one GPU, exchanging through gloo: the N > 1 code path with the real kernels (correctness, not a measurement)
-for ex in reduce-scatter all-to-all all-reduce auto; do timeout 600 env VOXE_GRAD_EXCHANGE=$ex VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | tail -1; done > $O/two_ranks_one_gpu_gloo.jsonl
+for ex in reduce-scatter all-to-all all-reduce auto; do timeout 600 env VOXE_GRAD_EXCHANGE=$ex VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | tail -1; done > $O/two_ranks_one_gpu_gloo.jsonl
 # ... and the driver's N = 8 command line, eight ranks sharing the GPU
-timeout 600 env VOXE_GRAD_EXCHANGE=reduce-scatter VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 8 --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/eight_ranks_one_gpu_gloo.json
+timeout 600 env VOXE_GRAD_EXCHANGE=reduce-scatter VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 8 --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/eight_ranks_one_gpu_gloo.json
 timeout 300 python tools/refine_bench.py 160 2>/dev/null | tail -4 > $O/refine_bench.txt; cat $O/refine_bench.txt
 timeout 300 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench.txt; cat $O/recon_bench.txt
 (timeout 300 python tools/sh_bench.py 160 400 123; timeout 300 python tools/sh_bench.py 160 180 123 random) 2>/dev/null > $O/sh_bench.txt; cat $O/sh_bench.txt
 # r03: strong scaling (ONE camera split into row bands) with two ranks on the one GPU (gloo), whole-grid passes with kernel-level
 # times, gradient error per magnitude band, LDS / VALU / clock microbenchmarks, gradient truncation on a surface-like scene
-timeout 600 env VOXE_GRAD_EXCHANGE=reduce-scatter VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --steps 3 --warmup 1 --scaling strong 2>/dev/null | tail -1 > $O/two_ranks_one_gpu_gloo_strong.json
+timeout 600 env VOXE_GRAD_EXCHANGE=reduce-scatter VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --steps 3 --warmup 1 --scaling strong 2>/dev/null | tail -1 > $O/two_ranks_one_gpu_gloo_strong.json
 timeout 300 python tools/grid_pass_bench.py 2>/dev/null > $O/grid_passes.txt; cat $O/grid_passes.txt
 timeout 300 python tools/band_probe.py 2>/dev/null > $O/band_probe.txt; tail -12 $O/band_probe.txt
 [ -x tools/microbench/atomics5 ] && timeout 120 ./tools/microbench/atomics5 > $O/microbench5.txt 2>&1

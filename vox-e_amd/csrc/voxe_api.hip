@@ -12,36 +12,23 @@ using namespace voxe;
 
 namespace {
 
-// VOXE_BWD_MODE=scatter forces the plain global-atomic backward, =packed the line-dense scatter backward
-// (A/B measurements, debugging)
-int bwd_mode_override() {
-  static const int mode = [] {
-    const char* e = getenv("VOXE_BWD_MODE");
-    if (e && strcmp(e, "scatter") == 0) return 1;
-    if (e && strcmp(e, "packed") == 0) return 2;
-    return 0;
-  }();
-  return mode;
-}
-bool force_scatter_bwd() { return bwd_mode_override() == 1; }
-bool force_no_tile_bwd() { return bwd_mode_override() != 0; }
-// VOXE_TILE_TWO_PHASE=0: view-dependent grids run the single-kernel channel groups even when the workspace has room for
-// the per-sample sources (read on every call: the tests flip it)
-bool two_phase_disabled() { const char* e = getenv("VOXE_TILE_TWO_PHASE"); return e && e[0] == '0'; }
+// The dispatch of a call: VoxeRenderCfg::dispatch, or the shipped defaults (all fields 0) when it is NULL.  Nothing on the
+// render path reads the environment (ABI v7).
+const VoxeDispatch kDefaultDispatch = {};
+const VoxeDispatch& disp_of(const VoxeRenderCfg* c) { return (c && c->dispatch) ? *c->dispatch : kDefaultDispatch; }
+// bwd_mode 1 forces the plain global-atomic backward, 2 the line-dense scatter backward (A/B measurements, debugging)
+bool force_scatter_bwd(const VoxeDispatch& d) { return d.bwd_mode == 1; }
+bool force_no_tile_bwd(const VoxeDispatch& d) { return d.bwd_mode != 0; }
+// tile_two_phase -1: view-dependent grids run the single-kernel channel groups even when the workspace has room for the
+// per-sample sources
+bool two_phase_disabled(const VoxeDispatch& d) { return d.tile_two_phase < 0; }
 
 // block -> tile mapping (see logical_tile_of()).  Default: image-ordered rays are interleaved over the XCDs (load
 // balance wins: neighbouring pixels share their voxels inside a wave anyway); rays in arbitrary order run in bands
 // (a batch kept in memory order then gives every XCD's L2 a compact part of the volume: forward -22 % at 32768
-// random rays).  VOXE_TILE_MAP = interleave | band | rows overrides both (A/B runs).
-int tile_map_mode(int image_width) {
-  static const int forced = [] {
-    const char* e = getenv("VOXE_TILE_MAP");
-    if (e && strcmp(e, "interleave") == 0) return 0;
-    if (e && strcmp(e, "band") == 0) return 1;
-    if (e && strcmp(e, "rows") == 0) return 2;
-    return -1;
-  }();
-  if (forced >= 0) return forced;
+// random rays).  VoxeDispatch::tile_map = 1 interleave | 2 band | 3 rows overrides both (A/B runs).
+int tile_map_mode(int image_width, const VoxeDispatch& d) {
+  if (d.tile_map >= 1 && d.tile_map <= 3) return d.tile_map - 1;
   return image_width > 0 ? 0 : 1;
 }
 
@@ -82,7 +69,8 @@ int validate(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, Variant* 
 }
 
 void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Variant& v, DevGrid* dg,
-              DevCfg* dc) {
+              HostCfg* dc) {
+  dc->disp = disp_of(c);
   dg->X = g->X; dg->Y = g->Y; dg->Z = g->Z;
   for (int a = 0; a < 3; ++a) {
     dg->lo[a] = g->aabb_lo[a]; dg->hi[a] = g->aabb_hi[a];
@@ -99,7 +87,7 @@ void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Va
   dc->key1 = (uint32_t)(c->seed >> 32) ^ (uint32_t)(c->rng_offset >> 32) ^ 0x7F4A7C15u;
   dc->image_width = c->image_width;
   dc->image_height = c->image_width > 0 ? (c->image_height > 0 ? c->image_height : (int)(R / c->image_width)) : 0;
-  dc->map_mode = tile_map_mode(c->image_width);
+  dc->map_mode = tile_map_mode(c->image_width, dc->disp);
   dc->R = R;
   dc->linear_grad = c->linear_grad;
   dc->seg_len = seg_len_for(R);
@@ -141,10 +129,10 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   // space-binned backward (voxe_render_region.hip): per-sample sources + segment tables
   l.region_off = l.total_with_src;
   l.region = false;
-  if (c && R > 0 && !c->deterministic && !force_no_tile_bwd()) {
+  if (c && R > 0 && !c->deterministic && !force_no_tile_bwd(disp_of(c))) {
     Variant v;
     if (validate(g, c, R, &v) == VOXE_OK) {
-      DevGrid dg; DevCfg dc;
+      DevGrid dg; HostCfg dc;
       make_dev(g, c, R, v, &dg, &dc);
       const bool tiled = tile_bwd_supported(dc, c->sh_degree);
       l.region = region_bwd_supported(dg, dc, c->sh_degree, c->render_diffuse, tiled);
@@ -290,12 +278,12 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   float* packed = (float*)((char*)workspace + l.packed_off);
   if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
   if (R == 0) return finish();
-  DevGrid dg; DevCfg dc;
+  DevGrid dg; HostCfg dc;
   make_dev(grid, cfg, R, v, &dg, &dc);
   // depth-segment states for the segmented backward, when that backward applies and the workspace holds them
   float* state = nullptr;
-  const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
-  const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
+  const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd(dc.disp);
+  const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp);
   if ((tiled || packed_bwd) && workspace_bytes >= l.total) state = (float*)((char*)workspace + l.state_off);
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
@@ -332,13 +320,13 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
   }
   *bricked = false;
   if (R > 0) {
-    DevGrid dg; DevCfg dc;
+    DevGrid dg; HostCfg dc;
     make_dev(grid, cfg, R, v, &dg, &dc);
-    const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
-    const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
+    const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd(dc.disp);
+    const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp);
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
-    if (tiled && l.total_with_src > l.total && workspace_bytes >= l.total_with_src && !two_phase_disabled())
+    if (tiled && l.total_with_src > l.total && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp))
       a.sample_src = (float*)((char*)workspace + l.src_off);
     if (cfg->deterministic) {
       if (!det_bwd_supported(dc, cfg->sh_degree, cfg->render_diffuse)) return VOXE_ERR_UNSUPPORTED;
@@ -452,11 +440,11 @@ int voxe_render_bwd_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, i
   const int st = validate(grid, cfg, R, &v);
   if (st) return st < -1 ? st : VOXE_ERR_BAD_SHAPE;
   if (R == 0) return VOXE_GRAD_ANY;
-  DevGrid dg; DevCfg dc;
+  DevGrid dg; HostCfg dc;
   make_dev(grid, cfg, R, v, &dg, &dc);
   if (cfg->deterministic) return VOXE_GRAD_LINEAR;
-  const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd();
-  const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd();
+  const bool tiled = tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd(dc.disp);
+  const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp);
   if (ws_layout(grid, cfg, R).region) return VOXE_GRAD_LINEAR;   // (given the workspace voxe_workspace_bytes asks for)
   return (packed_bwd && !cfg->linear_grad) ? VOXE_GRAD_BRICKED : VOXE_GRAD_LINEAR;
 }
@@ -466,12 +454,12 @@ int voxe_render_route(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_
   const int st = validate(grid, cfg, R, &v);
   if (st) return st < -1 ? st : VOXE_ERR_BAD_SHAPE;
   if (R == 0) return VOXE_ROUTE_NONE;
-  DevGrid dg; DevCfg dc;
+  DevGrid dg; HostCfg dc;
   make_dev(grid, cfg, R, v, &dg, &dc);
   if (cfg->deterministic) return VOXE_ROUTE_DETERMINISTIC;
   if (ws_layout(grid, cfg, R).region) return VOXE_ROUTE_REGION;
-  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd()) return VOXE_ROUTE_TILE;
-  if (packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd()) return VOXE_ROUTE_PACKED_SCATTER;
+  if (tile_bwd_supported(dc, cfg->sh_degree) && !force_no_tile_bwd(dc.disp)) return VOXE_ROUTE_TILE;
+  if (packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp)) return VOXE_ROUTE_PACKED_SCATTER;
   return VOXE_ROUTE_SCATTER;
 }
 
@@ -629,7 +617,7 @@ int voxe_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
   float* packed = (float*)((char*)workspace + l.packed_off);
   if (!cfg->reuse_packed_grid) launch_pack_any(grid, packed, s);
   if (R == 0) return finish();
-  DevGrid dg; DevCfg dc;
+  DevGrid dg; HostCfg dc;
   make_dev(grid, cfg, R, v, &dg, &dc);
   ProbeArgs a{packed, rays_o, rays_d, jitter, idx, inside, zvals, sigma, rad};
   launch_probe(dg, dc, cfg->sh_degree, cfg->render_diffuse, a, s);

@@ -24,6 +24,16 @@ struct BwdArgs {
   unsigned long long* gdet = nullptr;
   float* det_scale = nullptr;
 };
+// Launch-constant device config + the dispatch decisions of THIS call (VoxeRenderCfg::dispatch, NULL = all defaults): kernels
+// take the DevCfg base by value, host-side predicates and launchers read `disp` through the accessors below (0 = default).
+struct HostCfg : DevCfg {
+  VoxeDispatch disp;
+};
+inline long long disp_tile_min_rays(const VoxeDispatch& d) { return d.tile_min_rays == 0 ? 8192ll : (d.tile_min_rays < 0 ? 0ll : (long long)d.tile_min_rays); }
+inline long long disp_region_min_rays(const VoxeDispatch& d) { return d.region_min_rays == 0 ? 16384ll : (long long)d.region_min_rays; }   // (< 0: route off)
+inline float disp_region_image_ratio(const VoxeDispatch& d) { return d.region_image_ratio == 0.0f ? 1.3f : (d.region_image_ratio < 0.0f ? 0.0f : d.region_image_ratio); }
+inline float disp_or(float v, float dflt) { return v == 0.0f ? dflt : v; }
+
 struct ProbeArgs {
   const float *packed, *rays_o, *rays_d, *jitter;
   int32_t* idx;
@@ -40,7 +50,7 @@ void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_de
 bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
                       long long step_d, long long step_f, float* packed_out, hipStream_t st);
-void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
+void launch_fwd(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const FwdArgs& a,
                 hipStream_t st);
 void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a,
                 hipStream_t st);
@@ -52,14 +62,14 @@ void launch_query(const DevGrid& g, int C, const float* packed, const float* poi
                   const float* d_out, float* gpacked, bool want_d, bool want_f, hipStream_t st);
 
 // voxe_render_tile.hip: LDS-window backward for image-ordered SH-0 / attention renders
-bool tile_bwd_supported(const DevCfg& c, int deg);
+bool tile_bwd_supported(const HostCfg& c, int deg);
 // bytes of BwdArgs::sample_src for an image of R rays, width W, S samples (0: that render does not use it)
 size_t tile_src_bytes(long long R, int W, int H, int S, int deg, int diffuse, int attn);
-void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
+void launch_bwd_tile(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
 // LDS-staged forward for SH-0 image-ordered renders: writes the per-segment partials into a.segbuf (the caller then runs
 // the ordinary combine pass)
-bool fwd_tile_supported(const DevGrid& g, const DevCfg& c, int cout, int ncm);
-void launch_fwd_tile(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st);
+bool fwd_tile_supported(const DevGrid& g, const HostCfg& c, int cout, int ncm);
+void launch_fwd_tile(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st);
 // deterministic (ordered-accumulation) backward: single-group image-ordered renders only
 bool det_bwd_supported(const DevCfg& c, int deg, int diffuse);
 size_t det_bytes(long long nvox, int C);   // [fixed-point gradient | 4 floats], 256-byte aligned parts
@@ -70,7 +80,7 @@ void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, int deg, int d
 
 // voxe_render_region.hip: space-binned render (segments of rays grouped by 8x8x8-cell region; texels and the gradient
 // window of a region live in LDS)
-bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffuse, bool tiled);
+bool region_bwd_supported(const DevGrid& g, const HostCfg& c, int deg, int diffuse, bool tiled);
 size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S, bool full_sh);   // full_sh: SH degree 1 / 2, not diffuse
 void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
                        hipStream_t st);   // segment tables + forward; leaves the per-segment states in `scratch`

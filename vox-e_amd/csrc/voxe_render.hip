@@ -980,7 +980,7 @@ static void launch_unpack(const VoxeGridDesc* gd, const float* gpacked, float* d
 }
 
 template <int COUT, int NCM, int NCU>
-static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
+static void launch_fwd_t(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S, c.seg_len);
   // The march of every ray block is split into depth segments handled by different blocks (a 100x100 image alone
   // is 40 blocks; at 400x400 the finer split hides the gather latency better): with the segment-major block order
@@ -989,9 +989,7 @@ static void launch_fwd_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hi
   // (term_eps never changes a forward -- since r03 it only truncates the BACKWARD: samples behind a transmittance below
   //  it receive no gradient -- so the segmented forward runs whatever its value)
   if (a.segbuf && nseg > 1) {
-    static const int env_fseg = [] { const char* e = getenv("VOXE_FSEG"); return e ? atoi(e) : 0; }();
-    int fseg = 1;
-    if (env_fseg > 0) fseg = env_fseg;
+    const int fseg = c.disp.fwd_segments_per_thread > 0 ? c.disp.fwd_segments_per_thread : 1;
     const int ncoarse = (nseg + fseg - 1) / fseg;
     const int nrb64 = c.image_width > 0
                           ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
@@ -1057,7 +1055,7 @@ void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_de
     case 49: launch_unpack<49>(gd, gpacked, d_dens, d_feat, accumulate, bricked, st); break;
   }
 }
-void launch_fwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a,
+void launch_fwd(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const FwdArgs& a,
                 hipStream_t st) {
   VOXE_DISPATCH(launch_fwd_t, c.attn, deg, diffuse, g, c, a, st);
 }

@@ -941,13 +941,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_dep_kernel(
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
-static long long region_min_rays() {
-  const char* e = getenv("VOXE_REGION_MIN_RAYS");   // read per launch (tests / A-B runs flip it); < 0 disables the path
-  return e ? atoll(e) : 16384ll;
-}
-
-bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffuse, bool tiled) {
-  const long long min_rays = region_min_rays();
+bool region_bwd_supported(const DevGrid& g, const HostCfg& c, int deg, int diffuse, bool tiled) {
+  const long long min_rays = disp_region_min_rays(c.disp);   // (< 0: the route is switched off)
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
   if (!(c.attn || deg <= 2 || diffuse)) return false;          // SH-0 / diffuse / attention: one channel group; SH degree 1 / 2:
                                                                // whole texels in LDS + two-phase backward (degree 3: 49-channel
@@ -959,8 +954,7 @@ bool region_bwd_supported(const DevGrid& g, const DevCfg& c, int deg, int diffus
   // image-ordered launches: only when the pixels are clearly more than a voxel apart (nothing to combine inside a wave:
   // 100x100 cameras on a 160^3 grid).  The pixel spacing is not known on the host; for a camera that frames the volume
   // it is ~ grid side / image width.
-  const char* e = getenv("VOXE_REGION_IMAGE_RATIO");
-  const float ratio = e ? (float)atof(e) : 1.3f;
+  const float ratio = disp_region_image_ratio(c.disp);
   const int side = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
   return (float)side >= ratio * (float)c.image_width;
 }

@@ -1065,39 +1065,31 @@ __global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(D
   segbuf[(base + 2 + COUT) * c.R + r] = dsum;
 }
 
-// The window forward is the default for image-ordered SH-0 renders since r03 (VOXE_FWD_TILE=0 switches it off, read per launch):
+// The window forward is the default for image-ordered SH-0 renders since r03 (VoxeDispatch::fwd_window = -1 switches it off):
 // r02's version (march axis in registers, 360 VALU instructions per wave-sample) was 12 % slower than the ray-ordered forward;
 // with the march axis as a template parameter, layer origins / voxel offsets tabulated once per block, the stores of a slide
 // deferred by one sample and a per-tile choice between window and ray-by-ray march it is 8 - 20 % faster for views that run
 // along x or y (profiles/r03_ab_fwd_window.txt) and equal otherwise.  Outputs are bit-identical either way
 // (tests/test_hip_configs.py::test_lds_staged_forward_*).
-bool fwd_tile_supported(const DevGrid& g, const DevCfg& c, int cout, int ncm) {
+bool fwd_tile_supported(const DevGrid& g, const HostCfg& c, int cout, int ncm) {
   (void)g;
   if (cout != 3 || ncm != 1 || c.image_width <= 0) return false;
-  const char* e = getenv("VOXE_FWD_TILE");
-  return !(e && e[0] == '0');
+  return c.disp.fwd_window >= 0;
 }
-void launch_fwd_tile(const DevGrid& g, const DevCfg& c, const FwdArgs& a, hipStream_t st) {
+void launch_fwd_tile(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
-  // (A-B switches, read per launch)
-  const char* el = getenv("VOXE_FWD_TILE_FIT_LAT");
-  const char* em = getenv("VOXE_FWD_TILE_FIT_M");
-  const char* ez = getenv("VOXE_FWD_TILE_ZDOM");
-  const float fit_lat = el ? (float)atof(el) : 5.5f, fit_m = em ? (float)atof(em) : 4.5f, zdom = ez ? (float)atof(ez) : 1.0f;
-  const char* ea = getenv("VOXE_FWD_TILE_ADV");
-  const float max_adv = ea ? (float)atof(ea) : 1.7f;
+  const float fit_lat = disp_or(c.disp.fwd_fit_lat, 5.5f), fit_m = disp_or(c.disp.fwd_fit_m, 4.5f);
+  const float zdom = disp_or(c.disp.fwd_zdom, 1.0f), max_adv = disp_or(c.disp.fwd_max_adv, 1.7f);
   render_fwd_tile_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf, fit_lat, fit_m, zdom, max_adv);
 }
 
 // Images of a few thousand rays leave the chip empty whatever the kernel and usually have pixels far apart (little to
 // combine in LDS): the depth-segmented line-dense scatter is faster there (64x64: 0.18 vs 0.40 ms; 100x100: 0.40 vs 0.31 ms).
-// VOXE_TILE_MIN_RAYS overrides the threshold (the parity tests set 0 so that small images exercise this kernel).
-bool tile_bwd_supported(const DevCfg& c, int deg) {
-  const char* e = getenv("VOXE_TILE_MIN_RAYS");   // read per launch: the tests flip it (default dispatch vs forced tile kernel)
-  const long long min_rays = e ? atoll(e) : 8192ll;
+// VoxeDispatch::tile_min_rays overrides the threshold (parity tests ask for -1 so that small images exercise this kernel).
+bool tile_bwd_supported(const HostCfg& c, int deg) {
   (void)deg;   // every SH degree: view-dependent grids run their gradient channels as groups of 4 (sibling blocks)
-  return c.image_width > 0 && c.R >= min_rays;
+  return c.image_width > 0 && c.R >= disp_tile_min_rays(c.disp);
 }
 
 // ---- deterministic mode: scales from the measured maxima, fixed-point -> float ---------------------------------------
@@ -1129,13 +1121,13 @@ bool det_bwd_supported(const DevCfg& c, int deg, int diffuse) {
 }
 
 template <int COUT, int NCM, int NCU>
-static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& a, hipStream_t st) {
+static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs& a, hipStream_t st) {
   const long long ntx8 = (c.image_width + 7) / 8, nty8 = tile_rows_total(c, 8);
   // The parts (halves / quadrants) of a tile run as sibling blocks instead of consecutive passes while the launch is
   // small enough for the extra blocks to pay off (LDS bounds residency at 9 blocks per CU, 2304 on the chip; siblings
   // of a tile that fits the window whole retire at once); measured cross-over on MI355X with the segment-major block
   // order: 15 % better at 266x266 (9248 tile-segments), equal at 320x320 (12800), 3 % worse at 400x400, 8 % at 800x800
-  static const int env_q = [] { const char* e = getenv("VOXE_TILE_QSPLIT"); return e ? atoi(e) : 0; }();
+  const int env_q = c.disp.tile_qsplit;
   constexpr int NG = COUT * NCU + 1, WC = NG < 4 ? NG : 4, NGRP = (NG + WC - 1) / WC;
   // channel groups: all of them for a feature gradient; only the one holding the density channel (the last) otherwise
   const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
@@ -1147,11 +1139,11 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
   // run as sibling blocks on an under-filled chip, splitting oblique tiles beats their ring overflows by up to 1.7x (4.0
   // best at 266 px, 4.5 - 5.0 at 128 - 200 px in the 10-wide window); mid-size launches 4.5; a full chip (400x400: 20 000
   // tile-segments) prefers the overflow of ~1 % of the samples to 1.5x the blocks.
-  static const float env_fit_m = [] { const char* e = getenv("VOXE_TILE_FIT_M"); return e ? (float)atof(e) : 0.0f; }();
+  const float env_fit_m = c.disp.tile_fit_m;
   const long long tile_segs = ntx8 * nty8 * num_segments(c.S, c.seg_len);
   const int side_for_kl = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
   const bool wide = (float)side_for_kl >= 0.75f * (float)c.image_width;
-  static const float env_fit_lat = [] { const char* e = getenv("VOXE_TILE_FIT_LAT"); return e ? (float)atof(e) : 0.0f; }();
+  const float env_fit_lat = c.disp.tile_fit_lat;
   const float fit_lat = env_fit_lat;   // (0: the kernel's default, KL - 2.5 voxels)
   const float fit_m = env_fit_m > 0.0f ? env_fit_m : (qsplit == 4 ? (wide ? 4.5f : 4.0f) : (tile_segs <= 16000 ? 4.5f : 5.5f));
 #define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
@@ -1188,8 +1180,7 @@ static void launch_bwd_tile_t(const DevGrid& g, const DevCfg& c, const BwdArgs& 
     // width.  Measured on MI355X (160^3, backward ms, window 8 / 10 / 12): 400 px 0.58 / 0.78 / 1.06, 266 px 0.38 / 0.40 /
     // 0.55, 200 px 0.36 / 0.31 / 0.36, 100 px 0.30 / 0.26 / 0.26 -- the wider window costs residency (19.4 KB of LDS
     // per block) and only pays once most tiles of the 8-wide window would run as halves or quadrants.
-    const char* env_kl_s = getenv("VOXE_TILE_KL");     // 8 | 10 overrides the choice (read per launch: the tests flip it)
-    const int env_kl = env_kl_s ? atoi(env_kl_s) : 0;
+    const int env_kl = c.disp.tile_kl;                 // 8 | 10 overrides the choice
     const int side = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
     const int kl = env_kl ? env_kl : ((float)side >= 0.75f * (float)c.image_width ? 10 : 8);
 #define VOXE_TBWD_KL(KL)                                                       \
@@ -1219,7 +1210,7 @@ size_t tile_src_bytes(long long R, int W, int H1, int S, int deg, int diffuse, i
   return bytes <= ((size_t)4 << 30) ? bytes : 0;   // above 4 GB the single-kernel groups run instead
 }
 
-void launch_bwd_tile(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st) {
+void launch_bwd_tile(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st) {
   if (c.attn) launch_bwd_tile_t<1, 1, 1>(g, c, a, st);
   else if (deg == 0) launch_bwd_tile_t<3, 1, 1>(g, c, a, st);
   else if (deg == 1) { if (diffuse) launch_bwd_tile_t<3, 4, 1>(g, c, a, st); else launch_bwd_tile_t<3, 4, 4>(g, c, a, st); }

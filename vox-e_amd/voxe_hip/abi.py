@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # VoxeStatus
 OK = 0
@@ -50,6 +50,28 @@ class VoxeGridDesc(C.Structure):
     ]
 
 
+class VoxeDispatch(C.Structure):
+    """which kernels render a call / with which tuning parameters; every field 0 = the shipped default (include/voxe.h)"""
+    _fields_ = [
+        ("bwd_mode", C.c_int32),
+        ("tile_map", C.c_int32),
+        ("tile_min_rays", C.c_int64),
+        ("tile_two_phase", C.c_int32),
+        ("tile_qsplit", C.c_int32),
+        ("tile_kl", C.c_int32),
+        ("tile_fit_m", C.c_float),
+        ("tile_fit_lat", C.c_float),
+        ("fwd_window", C.c_int32),
+        ("fwd_fit_lat", C.c_float),
+        ("fwd_fit_m", C.c_float),
+        ("fwd_zdom", C.c_float),
+        ("fwd_max_adv", C.c_float),
+        ("fwd_segments_per_thread", C.c_int32),
+        ("region_min_rays", C.c_int64),
+        ("region_image_ratio", C.c_float),
+    ]
+
+
 class VoxeRenderCfg(C.Structure):
     _fields_ = [
         ("num_samples", C.c_int32),
@@ -70,6 +92,7 @@ class VoxeRenderCfg(C.Structure):
         ("deterministic", C.c_int32),
         ("linear_grad", C.c_int32),
         ("ray_state_valid", C.c_int32),
+        ("dispatch", C.POINTER(VoxeDispatch)),   # NULL = the shipped dispatch
     ]
 
 

@@ -60,17 +60,25 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "voxe.h"), os.path.abspath(__file__)]
     objs = []
-    rebuilt = False
+    todo = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or not _newer(op, [sp] + hdrs):
-            cmd = [hipcc(), *FLAGS, *extra_flags, "-I", INCLUDE, "-c", sp, "-o", op]
+            todo.append([hipcc(), *FLAGS, *extra_flags, "-I", INCLUDE, "-c", sp, "-o", op])
+    rebuilt = bool(todo)
+    if todo:
+        # the translation units are independent: compile them side by side (the tile kernels alone take ~50 s)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-            rebuilt = True
+
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as pool:
+            list(pool.map(run, todo))
     if rebuilt or not os.path.exists(LIB):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:

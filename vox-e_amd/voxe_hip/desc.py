@@ -71,6 +71,7 @@ def make_render_cfg(
     image_height: Optional[int] = None,
     deterministic: bool = False,
     linear_grad: bool = False,
+    dispatch: Optional[abi.VoxeDispatch] = None,
 ) -> abi.VoxeRenderCfg:
     c = abi.VoxeRenderCfg()
     c.num_samples = int(num_samples)
@@ -91,4 +92,9 @@ def make_render_cfg(
     c.deterministic = int(bool(deterministic))
     c.linear_grad = int(bool(linear_grad))
     c.ray_state_valid = int(bool(ray_state_valid))
+    if dispatch is not None:
+        import ctypes
+
+        c.dispatch = ctypes.pointer(dispatch)
+        c._dispatch_keepalive = dispatch   # (the struct must outlive every call that is handed this cfg)
     return c

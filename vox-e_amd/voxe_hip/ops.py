@@ -9,6 +9,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import abi
+from . import dispatch as _dispatch
 from .desc import make_grid_desc, make_render_cfg
 from .runtime import VoxeError, check, ensure_gfx950, f32c, lib, ptr, require_device, stream_ptr
 
@@ -40,6 +41,7 @@ class RenderParams:
     image_height: int = 0     # > 0 (with image_width): the rays are K = R / (H * W) images, one after the other
     deterministic: bool = False   # backward in 64-bit fixed point: bit-reproducible (test / race-check mode)
     linear_grad: bool = False     # render_bwd_acc: write VOXE_GRAD_LINEAR whatever kernel runs (deferred-gradient mode)
+    dispatch: Optional[_dispatch.Dispatch] = None   # kernel routes / tuning of THIS call (VoxeDispatch); None = dispatch.current()
 
 
 @dataclass
@@ -115,7 +117,8 @@ def _state_key(pack_key, params: RenderParams, rays_o, rays_d, jitter, rng, rout
     """identity of a forward call: the backward may consume the ray states only of exactly this call -- and only when it
     resolves to the same kernels (`route` = voxe_render_route: ray-ordered and space-binned renders keep different
     tables, and the choice also depends on process-level tuning switches that may change between the two calls)"""
-    fwd = tuple((k, v) for k, v in vars(params).items() if k not in ("linear_grad", "deterministic"))   # backward-only knobs
+    fwd = tuple((k, v) for k, v in vars(params).items() if k not in ("linear_grad", "deterministic", "dispatch"))   # backward-only knobs
+    fwd += (("dispatch", params.dispatch if params.dispatch is not None else _dispatch.current()),)
     return (pack_key, fwd, rays_o.data_ptr(), rays_d.data_ptr(), rays_o.shape[0],
             None if jitter is None else jitter.data_ptr(), tuple(rng), route)
 
@@ -132,7 +135,8 @@ def _descs(spec: GridSpec, params: RenderParams, densities, features, seed, rng_
                         params.linear_disparity, params.aabb_clip, params.white_bkgd, params.sh_degree,
                         params.render_diffuse, params.term_eps, seed, rng_offset, reuse, params.image_width,
                         image_height=params.image_height, deterministic=params.deterministic,
-                        linear_grad=params.linear_grad)
+                        linear_grad=params.linear_grad,
+                        dispatch=(params.dispatch if params.dispatch is not None else _dispatch.current()).struct())
     return g, c
 
 

@@ -66,7 +66,7 @@ def render(densities: torch.Tensor, features: torch.Tensor, aabb: Sequence[Tuple
 
 
 def time_step(densities, features, aabb, density_scale, rays_o, rays_d, g_colour, num_samples, near, far, chunk: int,
-              steps: int = 3, warmup: int = 1, lr: float = 1e-4):
+              steps: int = 3, warmup: int = 1, lr: float = 1e-4, median: bool = False):
     """seconds per step of (render fwd + autograd bwd over ray chunks of `chunk` rays + torch.optim.Adam): the reference's
     own way of processing an image (parallel_rays_chunk_size, modules/volumetric_model.py:152-176)"""
     import time
@@ -88,6 +88,14 @@ def time_step(densities, features, aabb, density_scale, rays_o, rays_d, g_colour
     for _ in range(warmup):
         step()
     sync()
+    if median:      # every step timed on its own, the median reported (SURVEY 8(d) protocol)
+        times = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            step()
+            sync()
+            times.append(time.perf_counter() - t0)
+        return sorted(times)[len(times) // 2]
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
