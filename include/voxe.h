@@ -330,11 +330,28 @@ int voxe_render_bwd_acc_into(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
 int voxe_render_bwd_layout(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R);
 size_t voxe_workspace_grad_offset(const VoxeGridDesc* grid);  /* byte offset / size of the gradient region, e.g. */
 size_t voxe_workspace_grad_bytes(const VoxeGridDesc* grid);   /* for the multi-GPU all-reduce between the two calls */
+/* Whole-grid regularisers evaluated INSIDE the grid step (modules/sds_trainer.py:305-334): the SDS edit's
+ * default regulariser is the density-correlation loss between the edited and the original densities (weight 200,
+ * edit_pretrained_relu_field.py:171).  Its gradient is elementwise in the parameters the step streams anyway, so only the
+ * moment reduction stays a launch of its own (two small kernels); the separate gradient kernel, the [X,Y,Z,1] gradient
+ * buffer and its round trip through HBM are gone.  dcl_reference == NULL: no term.  Requires the whole grid
+ * (x_begin = 0, x_end = X: the moments are over all voxels).  Same arithmetic as voxe_dcl_fwd_bwd with
+ * grad_scale = dcl_weight (the weight enters the two gradient constants in double instead of multiplying the finished float
+ * gradient: results agree to float rounding, not bit for bit).  The total-variation terms (default weight 0) stay
+ * separate passes: their stencil reads neighbours the in-place update of this very pass is overwriting. */
+typedef struct VoxeGridRegularisers {
+  const float* dcl_reference;   /* [X,Y,Z,1] densities of the pretrained field (constant), device; NULL = no DCL term      */
+  float dcl_weight;             /* density_correlation_weight (x any schedule / 1 / world factor)                         */
+  float* dcl_loss;              /* device float[1] or NULL: receives 1 - corr (unweighted, what the trainer logs)         */
+  void* scratch;                /* >= voxe_dcl_scratch_bytes(X * Y * Z) bytes of device memory                            */
+  size_t scratch_bytes;
+} VoxeGridRegularisers;
 int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x_begin, int32_t x_end,
                         const float* extra_d_densities, const float* extra_d_features,
                         float* exp_avg_densities, float* exp_avg_sq_densities,
                         float* exp_avg_features, float* exp_avg_sq_features,
                         float lr, float beta1, float beta2, float eps, int64_t step, int64_t step_features,
+                        const VoxeGridRegularisers* regularisers /* NULL = none */,
                         void* workspace, size_t workspace_bytes, void* stream);
 /*   `step` / `step_features`: the 1-based Adam step counts of the densities and of the features (torch.optim.Adam keeps
  *   one counter per parameter; step_features = 0 means "the same as step").                                          */
@@ -379,6 +396,8 @@ typedef struct {
   const float* poses;           /* [K,3,4] camera-to-world (rotation | translation), device                    */
   const int64_t* image_rows;    /* [K] rows of `images` of the K cameras, device; NULL = 0 .. K-1              */
   const float* images;          /* [N,3,H,W] device                                                            */
+  int32_t num_images;           /* N: every entry of image_rows (or K itself when image_rows == NULL) must be below it;
+                                   a row outside [0, N) reads nothing and makes that pixel's target NaN (ABI v7)        */
   int32_t K;
   int64_t batch;                /* rays per iteration                                                          */
   int32_t diffuse_regularisation;

@@ -276,3 +276,55 @@ def test_slab_steps_equal_full_step(ordered, dims, slabs):
     with pytest.raises(ops.VoxeError):
         ops.grid_adam_step_(spec, part.dens, part.feat, layout, part.ws, 2, LR, (part.m[0], part.v[0]),
                             (part.m[1], part.v[1]), x_range=(0, dims[0] + 1))
+
+
+def test_density_correlation_inside_the_grid_step_equals_the_separate_pass():
+    """VoxeGridRegularisers (r04): the SDS edit's density-correlation regulariser evaluated inside voxe_grid_adam_step ==
+    voxe_dcl_fwd_bwd into a gradient tensor + the same step with it as extra_d_densities (weight folded into the two gradient
+    constants in double instead of multiplying the float gradient: equal to float rounding), loss value included; slabs and
+    frozen densities are rejected"""
+    side, hw = 40, 96
+    dens, feat, ro, rd = _scene(side, 3, hw, True, None)
+    ref = (dens * 0.8 + 0.1 * torch.randn_like(dens)).contiguous()
+    spec = ops.GridSpec(aabb=AABB, density_scale=100.0 / 3.0, density_pre_act=abi.ACT_IDENTITY, density_post_act=abi.ACT_SOFTPLUS)
+    params = ops.RenderParams(num_samples=96, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw)
+    gcol = torch.randn((ro.shape[0], 3), generator=torch.Generator().manual_seed(5)).to(ro.device)
+    weight = 200.0
+    runs = {}
+    for mode in ("separate", "in_step"):
+        d, f = dens.clone(), feat.clone()
+        st_d, st_f = (torch.zeros_like(d), torch.zeros_like(d)), (torch.zeros_like(f), torch.zeros_like(f))
+        ws = ops.Workspace()
+        outs = [torch.empty((ro.shape[0], k), device=ro.device) for k in (3, 1, 1, 1)]
+        loss_val = torch.zeros((), device=ro.device)
+        vals = []
+        for it in range(1, 4):
+            ops.render_fwd_into(spec, params, d, f, ro, rd, None, *outs, ws, (9, it))
+            layout = ops.render_bwd_acc(spec, params, d, f, ro, rd, None, outs[0], outs[1], outs[2], gcol, None, None, ws, (9, it),
+                                        zero_first=(it == 1))
+            if mode == "separate":
+                dd = d.clone().requires_grad_(True)
+                l = ops.density_correlation_loss(dd, ref)
+                (l * weight).backward()
+                vals.append(float(l))
+                ops.grid_adam_step_(spec, d, f, layout, ws, it, 1e-2, state_densities=st_d, state_features=st_f,
+                                    extra_d_densities=dd.grad.contiguous())
+            else:
+                ops.grid_adam_step_(spec, d, f, layout, ws, it, 1e-2, state_densities=st_d, state_features=st_f,
+                                    dcl_reference=ref, dcl_weight=weight, dcl_loss=loss_val)
+                vals.append(float(loss_val))
+        runs[mode] = (d, f, st_d[0], vals)
+    a, b = runs["separate"], runs["in_step"]
+    assert all(abs(x - y) < 2e-6 for x, y in zip(a[3], b[3])), (a[3], b[3])
+    # (two runs of the render backward differ by the order of their float atomics, and Adam's first steps turn the rounding
+    #  noise of near-zero gradients into +-lr moves: first moments to 5e-4, parameters against their movement)
+    assert _rel(a[2], b[2]) < 5e-4, _rel(a[2], b[2])
+    assert _rel(a[0] - dens, b[0] - dens) < 0.02 and _rel(a[1] - feat, b[1] - feat) < 0.02, (_rel(a[0] - dens, b[0] - dens), _rel(a[1] - feat, b[1] - feat))
+    assert float((b[0] - dens).abs().max()) > 1e-3
+    d, f = dens.clone(), feat.clone()
+    st_d, st_f = (torch.zeros_like(d), torch.zeros_like(d)), (torch.zeros_like(f), torch.zeros_like(f))
+    with pytest.raises(ops.VoxeError):       # the moments are over the whole grid: no slabs
+        ops.grid_adam_step_(spec, d, f, 0, ws, 1, 1e-2, state_densities=st_d, state_features=st_f, x_range=(0, side // 2),
+                            dcl_reference=ref, dcl_weight=weight)
+    with pytest.raises(ops.VoxeError):       # frozen densities have nothing to regularise
+        ops.grid_adam_step_(spec, d, f, 0, ws, 1, 1e-2, state_densities=None, state_features=st_f, dcl_reference=ref, dcl_weight=weight)

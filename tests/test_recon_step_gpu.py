@@ -123,3 +123,51 @@ def test_fused_grid_adam_reconstruction_step_drives_the_trainer_state():
     assert float((grid.densities.detach() - before).abs().max()) > 1e-3
     # ordinary renders work again afterwards (the mode ended with the context manager)
     assert grid.voxe_workspace("sh").deferred is None
+
+
+def test_recon_step_bounds_its_image_rows_and_a_failed_call_leaves_the_optimiser_consistent():
+    """ADVICE r03: (a) image_rows are bounded by VoxeReconStep::num_images -- a row outside the image stack reads nothing and
+    shows up as a NaN loss, K cameras without a row table need K <= N; (b) a reconstruction_step that raises does not advance
+    the optimiser's step counters, leaves no half-accumulated gradient behind, and the scheduler sees optimiser steps"""
+    import warnings
+
+    from voxe_hip.runtime import VoxeError
+
+    side, hw, K = 32, 48, 4
+    dens, feat, poses, images, spec, params = _setup(side, hw, K)
+    st_d = (torch.zeros_like(dens), torch.zeros_like(dens))
+    st_f = (torch.zeros_like(feat), torch.zeros_like(feat))
+    losses = torch.zeros(4, device=DEV)
+    d_b, f_b = dens.clone(), feat.clone()
+    bad_rows = torch.tensor([0, 1, K, 2], device=DEV)                     # row K is one past the stack
+    ops.recon_step_(spec, params, d_b, f_b, ops.Workspace(), ops.Workspace(), hw, hw, focal_for(hw), poses, bad_rows, images,
+                    4096, False, st_d, st_f, 1, 1, 1e-2, losses, (3, 0))
+    assert bool(torch.isnan(losses[0]))
+    with pytest.raises(VoxeError):                                        # K cameras, no row table, only K - 1 images
+        ops.recon_step_(spec, params, dens.clone(), feat.clone(), ops.Workspace(), ops.Workspace(), hw, hw, focal_for(hw), poses,
+                        None, images[: K - 1].contiguous(), 4096, False, st_d, st_f, 1, 1, 1e-2, losses, (3, 0))
+
+    from thre3d_atom.modules.optim import FusedGridAdam
+    from thre3d_atom.modules.volumetric_model import VolumetricModel
+    from thre3d_atom.thre3d_reprs.renderers import SHVoxGridRenderConfig, _render_params, render_sh_voxel_grid
+    from thre3d_atom.thre3d_reprs.voxels import VoxelGrid, VoxelSize
+    from thre3d_atom.utils.imaging_utils import CameraBounds
+
+    vg = VoxelGrid(dens.cpu(), feat.cpu(), VoxelSize(3.0 / side, 3.0 / side, 3.0 / side), density_preactivation=torch.nn.Identity(),
+                   density_postactivation=torch.nn.Softplus(), expected_density_scale=3.0, tunable=True)
+    model = VolumetricModel(vg, render_sh_voxel_grid, SHVoxGridRenderConfig(48, CameraBounds(NEAR, FAR), white_bkgd=True), device=DEV)
+    grid = model.thre3d_repr
+    rp = _render_params(grid, None, model.render_config, attn=False)
+    with FusedGridAdam(grid, lr=1e-2) as opt:
+        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.5)
+        opt.reconstruction_step(rp, hw, hw, focal_for(hw), poses, None, images, 4096, True, losses, (5, 0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")       # "lr_scheduler.step() before optimizer.step()" must not fire
+            sched.step()
+        ws = grid.voxe_workspace("sh")
+        with pytest.raises(VoxeError):           # fewer images than cameras: rejected inside the library call
+            opt.reconstruction_step(rp, hw, hw, focal_for(hw), poses, None, images[: K - 1].contiguous(), 4096, True, losses, (5, 1))
+        assert opt.state[grid.densities]["step"] == 1 and opt.state[grid.features]["step"] == 1
+        assert ws.deferred.clean_ptr == 0 and ws.key is None      # the next call clears the gradient region and re-packs
+        opt.reconstruction_step(rp, hw, hw, focal_for(hw), poses, None, images, 4096, True, losses, (5, 2))
+        assert opt.state[grid.densities]["step"] == 2 and bool(torch.isfinite(losses).all())

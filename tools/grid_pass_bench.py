@@ -71,6 +71,34 @@ def main():
         check(L.voxe_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), 1e-4, 0.9, 0.999, 1e-8, step[0], st), "adam")
 
     rows.append(("adam_kernel on features", 7 * p.numel() * 4, timed(adam)))
+    # the whole-grid work of ONE default SDS iteration (density-correlation regulariser + fused Adam of both tensors):
+    # r03 = voxe_dcl_fwd_bwd into a gradient tensor, then voxe_grid_adam_step with it as extra_d_densities (5 launches);
+    # r04 = voxe_grid_adam_step with VoxeGridRegularisers (moments + finalize + the step: 3 launches, no gradient tensor)
+    spec = ops.GridSpec(aabb=((-1.5, 1.5),) * 3, density_scale=100.0 / 3.0)
+    gdesc, _ = ops._descs(spec, ops.RenderParams(num_samples=1, near=0.0, far=1.0), dens, feat, 0, 0, False)
+    dd, ff = dens.clone(), feat.clone()
+    st_d, st_f = (torch.zeros_like(dd), torch.zeros_like(dd)), (torch.zeros_like(ff), torch.zeros_like(ff))
+    ws = ops.Workspace()
+    ws.buf = torch.zeros(L.voxe_workspace_bytes(C.byref(gdesc), None, 0), dtype=torch.uint8, device=dev)
+    cnt = [0]
+
+    def sds_r03():
+        cnt[0] += 1
+        check(L.voxe_dcl_fwd_bwd(ptr(dd), ptr(ref), n, 200.0, ptr(loss), ptr(d_a), 0, ptr(sc), sc.numel(), st), "dcl")
+        ops.grid_adam_step_(spec, dd, ff, 0, ws, cnt[0], 1e-4, state_densities=st_d, state_features=st_f, extra_d_densities=d_a)
+
+    def sds_r04():
+        cnt[0] += 1
+        ops.grid_adam_step_(spec, dd, ff, 0, ws, cnt[0], 1e-4, state_densities=st_d, state_features=st_f, dcl_reference=ref,
+                            dcl_weight=200.0, dcl_loss=loss)
+
+    def adam_only():
+        cnt[0] += 1
+        ops.grid_adam_step_(spec, dd, ff, 0, ws, cnt[0], 1e-4, state_densities=st_d, state_features=st_f)
+
+    rows.append(("fused grid step alone (grid_adam_v5_kernel)", 9 * 4 * n * 4, timed(adam_only)))
+    rows.append(("SDS iteration, r03: dcl_fwd_bwd -> extra_d -> fused grid step", (9 * 4 + 5 + 1) * n * 4, timed(sds_r03)))
+    rows.append(("SDS iteration, r04: DCL inside the fused grid step", (9 * 4 + 2 + 1) * n * 4, timed(sds_r04)))
     print(f"# whole-grid passes at {side}^3 on {torch.cuda.get_device_name(0)}; peak {PEAK:.0f} GB/s (HBM3E spec); device time per call")
     print(f"{'pass':62s} {'MB':>8s} {'ms':>8s} {'GB/s':>8s} {'of peak':>8s}")
     for name, nbytes, ms in rows:

@@ -499,7 +499,8 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   if (grid->feature_kind != VOXE_FEAT_SH) return VOXE_ERR_UNSUPPORTED;
   if (rs->H <= 0 || rs->W <= 0 || rs->K <= 0 || rs->batch <= 0 || rs->batch > (int64_t)rs->K * rs->H * rs->W)
     return VOXE_ERR_BAD_SHAPE;
-  if (cfg->image_width != 0 || cfg->deterministic) return VOXE_ERR_UNSUPPORTED;   // a random batch has no image order
+  if (rs->num_images <= 0 || (!rs->image_rows && rs->K > rs->num_images)) return VOXE_ERR_BAD_SHAPE;
+  if (cfg->image_width != 0 || cfg->image_height != 0 || cfg->deterministic) return VOXE_ERR_UNSUPPORTED;   // a random batch has no image order
   const int nrender = rs->diffuse_regularisation ? 2 : 1;
   if (nrender == 2 && !workspace2) return VOXE_ERR_WORKSPACE;
   const ReconLayout l = recon_layout(rs->batch);
@@ -515,7 +516,7 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   if (st) return st;
   st = voxe_cast_rays_indexed(rs->H, rs->W, rs->focal, rs->poses, rs->K, subset, B, rays_o, rays_d, stream);
   if (st) return st;
-  launch_gather_pixels(rs->images, (const long long*)rs->image_rows, (const long long*)subset, B, rs->H * rs->W, target, s);
+  launch_gather_pixels(rs->images, (const long long*)rs->image_rows, (const long long*)subset, B, rs->H * rs->W, rs->num_images, target, s);
   VoxeRenderCfg rc[2] = {*cfg, *cfg};
   void* ws[2] = {workspace, workspace2};
   size_t wsb[2] = {workspace_bytes, workspace2_bytes};
@@ -545,7 +546,7 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   }
   return voxe_grid_adam_step(grid, VOXE_GRAD_LINEAR, 0, grid->X, nullptr, nullptr, rs->exp_avg_densities,
                              rs->exp_avg_sq_densities, rs->exp_avg_features, rs->exp_avg_sq_features, rs->lr, rs->beta1,
-                             rs->beta2, rs->eps, rs->step_densities, rs->step_features, workspace, workspace_bytes, stream);
+                             rs->beta2, rs->eps, rs->step_densities, rs->step_features, nullptr, workspace, workspace_bytes, stream);
 }
 
 int voxe_clock_probe(int32_t spin, double* shader_hz, void* stream) {
@@ -582,7 +583,8 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
                         const float* extra_d_densities,
                         const float* extra_d_features, float* exp_avg_d, float* exp_avg_sq_d, float* exp_avg_f,
                         float* exp_avg_sq_f, float lr, float beta1, float beta2, float eps, int64_t step,
-                        int64_t step_features, void* workspace, size_t workspace_bytes, void* stream) {
+                        int64_t step_features, const VoxeGridRegularisers* reg, void* workspace, size_t workspace_bytes,
+                        void* stream) {
   if (!grid || !grid->densities || !grid->features) return VOXE_ERR_NULL_POINTER;
   if (grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0 || step < 1 || step_features < 0) return VOXE_ERR_BAD_SHAPE;
   if ((long long)grid->X * grid->Y * grid->Z * (grid->F + 1) >= (1LL << 31)) return VOXE_ERR_BAD_SHAPE;
@@ -594,11 +596,21 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
     return VOXE_ERR_UNSUPPORTED;
   const WsLayout l = ws_layout(grid, nullptr, 0);
   if (!workspace || workspace_bytes < l.state_off) return VOXE_ERR_WORKSPACE;
+  DclTerm dcl;
+  if (reg && reg->dcl_reference) {
+    // moments over the WHOLE grid of the current parameters; the gradient is evaluated inside the step
+    const long long n = (long long)grid->X * grid->Y * grid->Z;
+    if (x_begin != 0 || x_end != grid->X || !exp_avg_d) return VOXE_ERR_UNSUPPORTED;
+    if (!reg->scratch || reg->scratch_bytes < dcl_scratch_bytes(n)) return VOXE_ERR_WORKSPACE;
+    dcl.b = reg->dcl_reference;
+    dcl.stats = launch_dcl_moments(grid->densities, reg->dcl_reference, n, reg->dcl_weight, reg->dcl_loss, reg->scratch,
+                                   (hipStream_t)stream);
+  }
   if (x_begin == x_end) return VOXE_OK;
   if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, x_begin, x_end, (float*)((char*)workspace + l.grad_off),
                         extra_d_densities, extra_d_features, exp_avg_d, exp_avg_sq_d, exp_avg_f, exp_avg_sq_f, lr, beta1,
                         beta2, eps, step, step_features > 0 ? step_features : step,
-                        (float*)((char*)workspace + l.packed_off), (hipStream_t)stream))
+                        (float*)((char*)workspace + l.packed_off), (hipStream_t)stream, dcl))
     return VOXE_ERR_UNSUPPORTED;
   return finish();
 }

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void dcl_moments_kernel(const float* __restric
 __global__ __launch_bounds__(256) void dcl_finalize_kernel(const double* __restrict__ partial,
                                                            int nblocks, long long n,
                                                            double* __restrict__ stats,
-                                                           float* __restrict__ loss_out) {
+                                                           float* __restrict__ loss_out, double fold_scale = 1.0) {
   double s[5] = {0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
 #pragma unroll
@@ -148,10 +148,10 @@ __global__ __launch_bounds__(256) void dcl_finalize_kernel(const double* __restr
     const double cov = tot[4] / dn - ma * mb;
     const double eps = 0.0000001;
     const double D = sqrt(fmax(va * vb, 0.0));
-    *loss_out = (float)(1.0 - cov / (D + eps));
+    if (loss_out) *loss_out = (float)(1.0 - cov / (D + eps));
     stats[0] = ma; stats[1] = mb;
-    stats[2] = 1.0 / (dn * (D + eps));
-    stats[3] = (D > 0.0) ? cov * vb / (dn * D * (D + eps) * (D + eps)) : 0.0;
+    stats[2] = fold_scale / (dn * (D + eps));
+    stats[3] = (D > 0.0) ? fold_scale * cov * vb / (dn * D * (D + eps) * (D + eps)) : 0.0;
   }
 }
 
@@ -171,6 +171,16 @@ __global__ __launch_bounds__(256) void dcl_grad_kernel(const float* __restrict__
 }
 
 size_t dcl_scratch_bytes(long long) { return sizeof(double) * (kRedBlocks * 5 + 8); }
+
+const double* launch_dcl_moments(const float* a, const float* b, long long n, float grad_scale, float* loss_out, void* scratch,
+                                 hipStream_t st) {
+  double* partial = (double*)scratch;
+  double* stats = partial + kRedBlocks * 5;
+  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  dcl_moments_kernel<<<nb, 256, 0, st>>>(a, b, n, partial);
+  dcl_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, n, stats, loss_out, (double)grad_scale);
+  return stats;
+}
 
 void launch_dcl(const float* a, const float* b, long long n, float grad_scale, float* loss_out,
                 float* d_a, int accumulate, void* scratch, hipStream_t st) {
@@ -458,13 +468,18 @@ void launch_disparity_bwd(const float* depth, const float* acc, const float* d_d
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_pixels_kernel(const float* __restrict__ images, const long long* __restrict__ image_rows,
                                                             const long long* __restrict__ subset, long long B, int per,
-                                                            float* __restrict__ out) {
+                                                            int num_images, float* __restrict__ out) {
   // images [N, 3, H, W]; subset: flat (camera, y, x) indices over the K cached cameras; out [B, 3]
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B) return;
   const long long f = subset[i];
   const long long cam = f / per, rem = f - cam * per;
   const long long row = image_rows ? image_rows[cam] : cam;
+  if (row < 0 || row >= num_images) {   // a caller's bug: never read outside `images`; the NaN target shows up in the loss
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) out[i * 3 + ch] = __int_as_float(0x7fc00000);
+    return;
+  }
   const float* __restrict__ src = images + row * 3 * (long long)per + rem;
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) out[i * 3 + ch] = src[(long long)ch * per];
@@ -495,9 +510,9 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(const double* __restri
 }
 
 void launch_gather_pixels(const float* images, const long long* image_rows, const long long* subset, long long B, int per,
-                          float* out, hipStream_t st) {
+                          int num_images, float* out, hipStream_t st) {
   if (B <= 0) return;
-  gather_pixels_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>(images, image_rows, subset, B, per, out);
+  gather_pixels_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>(images, image_rows, subset, B, per, num_images, out);
 }
 size_t l1_scratch_bytes() { return sizeof(double) * (kRedBlocks * 2 + 8); }
 void launch_l1_loss_grad(const float* a, const float* b, long long n, float* d_a, float* out2, void* scratch, hipStream_t st) {

@@ -47,9 +47,19 @@ void launch_pack_any(const VoxeGridDesc* gd, float* packed, hipStream_t st);
 void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_dens, float* d_feat,
                        int accumulate, int bricked, hipStream_t st);
 // fused un-pack + Adam + re-pack (false: channel count without a kernel)
+// density-correlation term evaluated inside the grid step: reference densities b, the finalized moment statistics of
+// launch_dcl_moments (mean a, mean b, k1, k2 with the weight folded in), see dcl_grad_kernel
+struct DclTerm {
+  const float* b = nullptr;
+  const double* stats = nullptr;
+};
 bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
-                      long long step_d, long long step_f, float* packed_out, hipStream_t st);
+                      long long step_d, long long step_f, float* packed_out, hipStream_t st, DclTerm dcl = DclTerm());
+// moments + finalize of the density-correlation loss (no gradient kernel): stats = (mean a, mean b, k1 * scale, k2 * scale)
+// in `scratch` (returned pointer), loss value to loss_out (nullable)
+const double* launch_dcl_moments(const float* a, const float* b, long long n, float grad_scale, float* loss_out, void* scratch,
+                                 hipStream_t st);
 void launch_fwd(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const FwdArgs& a,
                 hipStream_t st);
 void launch_bwd(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a,
@@ -109,7 +119,7 @@ void launch_upsample(const float* src, int X, int Y, int Z, int C, float* dst, i
 void launch_disparity_bwd(const float* depth, const float* acc, const float* d_disp, const float* d_depth_in,
                           const float* d_acc_in, float* d_depth_out, float* d_acc_out, long long R, hipStream_t st);
 void launch_gather_pixels(const float* images, const long long* image_rows, const long long* subset, long long B, int per,
-                          float* out, hipStream_t st);
+                          int num_images, float* out, hipStream_t st);
 size_t l1_scratch_bytes();
 void launch_l1_loss_grad(const float* a, const float* b, long long n, float* d_a, float* out2, void* scratch, hipStream_t st);
 double run_clock_probe(int spin, hipStream_t st);   // sustained shader clock in Hz (blocking; 0 on failure)

@@ -149,6 +149,13 @@ __device__ __forceinline__ float adam_update(float p, float gi, float& m, float&
   return p - h.step_size * (mi / denom);
 }
 
+// density-correlation gradient of one voxel (dcl_grad_kernel's expression; stats = mean a, mean b, k1, k2 with the weight folded in)
+__device__ __forceinline__ float dcl_term(const DclTerm& t, float a, long long i) {
+  const float ma = (float)t.stats[0], mb = (float)t.stats[1], k1 = (float)t.stats[2], k2 = (float)t.stats[3];
+  const float A = a - ma, B = t.b[i] - mb;
+  return A * k2 - B * k1;
+}
+
 template <int C>
 __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpacked, float* __restrict__ dens,
                                                         float* __restrict__ feat, const float* __restrict__ extra_d,
@@ -156,7 +163,8 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
                                                         float* __restrict__ v_d, float* __restrict__ m_f,
                                                         float* __restrict__ v_f, float* __restrict__ packed,
                                                         long long vox_begin, long long vox_end, float scale,
-                                                        int pre_act, int bricked, int Y, int Z, AdamHyper h_d, AdamHyper h_f) {
+                                                        int pre_act, int bricked, int Y, int Z, AdamHyper h_d, AdamHyper h_f,
+                                                        DclTerm dcl) {
   constexpr int F = C - 1;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = vox_begin + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < vox_end; i += stride) {
@@ -194,7 +202,8 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
     float d = dens[i];
     if (m_d) {
       const float gd = g[F] * pre_activate_grad(pre_act, d, scale);
-      const float gi = extra_d ? gd + extra_d[i] : gd;
+      float gi = extra_d ? gd + extra_d[i] : gd;
+      if (dcl.b) gi += dcl_term(dcl, d, i);
       float m = m_d[i], v = v_d[i];
       d = adam_update(d, gi, m, v, h_d);
       dens[i] = d; m_d[i] = m; v_d[i] = v;
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ 
                                                            float* __restrict__ v_d, float4* __restrict__ m_f,
                                                            float4* __restrict__ v_f, float4* __restrict__ packed,
                                                            long long vox_begin, int nchunks, float scale, int pre_act,
-                                                           AdamHyper h_d, AdamHyper h_f, int flip) {
+                                                           AdamHyper h_d, AdamHyper h_f, int flip, DclTerm dcl) {
   __shared__ float4 lds4[4][3][192];   // [wave][buffer][256 voxels x 3 floats]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nwaves = gridDim.x * 4;
@@ -312,7 +321,8 @@ __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float gd = g[k].w * pre_activate_grad(pre_act, d[k], scale);
-        const float gi = extra_d ? gd + extra_d[vb + k * 64 + lane] : gd;
+        float gi = extra_d ? gd + extra_d[vb + k * 64 + lane] : gd;
+        if (dcl.b) gi += dcl_term(dcl, d[k], vb + k * 64 + lane);
         d[k] = adam_update(d[k], gi, md[k], vd[k], h_d);
         dens[vb + k * 64 + lane] = d[k];
         m_d[vb + k * 64 + lane] = md[k];
@@ -335,7 +345,8 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
                                                              float* __restrict__ v_d, float* __restrict__ m_f,
                                                              float* __restrict__ v_f, float* __restrict__ packed,
                                                              long long vox_begin, long long vox_end, float scale,
-                                                             int pre_act, int bricked, int Y, int Z, AdamHyper h_d, AdamHyper h_f) {
+                                                             int pre_act, int bricked, int Y, int Z, AdamHyper h_d, AdamHyper h_f,
+                                                             DclTerm dcl) {
   constexpr int F = C - 1;
   const unsigned e_end = (unsigned)(vox_end * C), stride = gridDim.x * blockDim.x;
   for (unsigned e = (unsigned)(vox_begin * C) + blockIdx.x * blockDim.x + threadIdx.x; e < e_end; e += stride) {
@@ -361,7 +372,8 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
       float d = dens[i];
       if (m_d) {
         const float gd = g * pre_activate_grad(pre_act, d, scale);
-        const float gi = extra_d ? gd + extra_d[i] : gd;
+        float gi = extra_d ? gd + extra_d[i] : gd;
+        if (dcl.b) gi += dcl_term(dcl, d, i);
         float m = m_d[i], v = v_d[i];
         d = adam_update(d, gi, m, v, h_d);
         dens[i] = d; m_d[i] = m; v_d[i] = v;
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(256) void grid_adam_wide_kernel(float* __restrict__
 template <int C>
 static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d,
                                const float* extra_f, float* m_d, float* v_d, float* m_f, float* v_f, AdamHyper h_d,
-                               AdamHyper h_f, float* packed_out, hipStream_t st, int flip) {
+                               AdamHyper h_f, float* packed_out, hipStream_t st, int flip, DclTerm dcl) {
   const long long plane = (long long)gd->Y * gd->Z, nvox = (x_end - x_begin) * plane;
   if constexpr (C > 4) {
     const long long n = nvox * C;
@@ -382,7 +394,7 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
     grid_adam_wide_kernel<C><<<nbw, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
                                                   extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane,
                                                   x_end * plane, gd->density_scale, gd->density_pre_act, bricked ? 1 : 0, gd->Y,
-                                                  gd->Z, h_d, h_f);
+                                                  gd->Z, h_d, h_f, dcl);
     return;
   }
   if constexpr (C == 4 && VOXE_GA_V5) {
@@ -397,11 +409,11 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
             reinterpret_cast<float4*>(gpacked), const_cast<float*>(gd->densities),
             reinterpret_cast<float4*>(const_cast<float*>(gd->features)), extra_d, reinterpret_cast<const float4*>(extra_f), m_d, v_d,
             reinterpret_cast<float4*>(m_f), reinterpret_cast<float4*>(v_f), reinterpret_cast<float4*>(packed_out), vb, (int)nchunks,
-            gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0);
+            gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0, dcl);
         if (tail < ve)   // fewer than 256 voxels left: the per-voxel kernel
           grid_adam_kernel<C><<<1, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features), extra_d,
                                                  extra_f, m_d, v_d, m_f, v_f, packed_out, tail, ve, gd->density_scale,
-                                                 gd->density_pre_act, 0, gd->Y, gd->Z, h_d, h_f);
+                                                 gd->density_pre_act, 0, gd->Y, gd->Z, h_d, h_f, dcl);
         return;
       }
     }
@@ -409,12 +421,12 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
   const int nb = (int)((nvox + 255) / 256 < VOXE_GA_BLOCKS ? (nvox + 255) / 256 : VOXE_GA_BLOCKS);
   grid_adam_kernel<C><<<nb, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features),
                                           extra_d, extra_f, m_d, v_d, m_f, v_f, packed_out, x_begin * plane, x_end * plane, gd->density_scale,
-                                          gd->density_pre_act, bricked ? 1 : 0, gd->Y, gd->Z, h_d, h_f);
+                                          gd->density_pre_act, bricked ? 1 : 0, gd->Y, gd->Z, h_d, h_f, dcl);
 }
 
 bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
-                      long long step_d, long long step_f, float* packed_out, hipStream_t st) {
+                      long long step_d, long long step_f, float* packed_out, hipStream_t st, DclTerm dcl) {
   // torch.optim.Adam keeps one step counter PER PARAMETER: the two tensors' bias corrections may differ (a tensor that
   // skipped a step, e.g. a regulariser-only iteration on the densities)
   auto hyper = [&](long long step) {
@@ -425,11 +437,11 @@ bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_e
   const AdamHyper h_d = hyper(step_d), h_f = hyper(step_f);
   const int flip = (int)(step_d & 1);   // alternate sweep direction: the tail of one step's sweep is the head of the next (Infinity Cache)
   switch (gd->F + 1) {
-    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
-    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
-    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
-    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
-    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip); return true;
+    case 2: launch_grid_adam_t<2>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip, dcl); return true;
+    case 4: launch_grid_adam_t<4>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip, dcl); return true;
+    case 13: launch_grid_adam_t<13>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip, dcl); return true;
+    case 28: launch_grid_adam_t<28>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip, dcl); return true;
+    case 49: launch_grid_adam_t<49>(gd, bricked, x_begin, x_end, gpacked, extra_d, extra_f, m_d, v_d, m_f, v_f, h_d, h_f, packed_out, st, flip, dcl); return true;
   }
   return false;
 }

@@ -89,6 +89,23 @@ class FusedGridAdam(torch.optim.Optimizer):
         self._train = (train_d, train_f)
         # dropped without detach() (an exception unwound the training loop, the caller forgot): leave the mode anyway
         self._finalizer = weakref.finalize(self, FusedGridAdam._release, self.workspace, mine)
+        self._dcl = None          # (reference densities, weight): density-correlation regulariser evaluated inside step()
+        self.dcl_loss = None      # device scalar: its unweighted value at the last step()
+
+    def set_density_correlation(self, regular_density, weight: float) -> None:
+        """evaluate the SDS edit's density-correlation regulariser (modules/sds_trainer.py:507-524: 1 - corr(densities,
+        `regular_density`), times `weight`) INSIDE step(): no autograd node, no [X,Y,Z,1] gradient tensor, no separate gradient
+        kernel; `self.dcl_loss` holds its value (unweighted) after every step().  `regular_density` None switches it off."""
+        if regular_density is None:
+            self._dcl, self.dcl_loss = None, None
+            return
+        if self.kind != "sh" or not self._train[0]:
+            raise RuntimeError("set_density_correlation needs trainable densities of an SH grid")
+        ref = regular_density.detach().to(self._dens.device, torch.float32).contiguous()
+        if ref.numel() != self._dens.numel():
+            raise ValueError("regular_density must have the shape of the grid's densities")
+        self._dcl = (ref, float(weight))
+        self.dcl_loss = torch.zeros((), dtype=torch.float32, device=self._dens.device)
 
     @staticmethod
     def _release(workspace, mine) -> None:
@@ -155,11 +172,21 @@ class FusedGridAdam(torch.optim.Optimizer):
         if ws.sibling is None:
             ws.sibling = _ops.Workspace()
         fresh = ws.buf is None or d.clean_ptr != ws.buf.data_ptr()
-        _ops.recon_step_(self.spec, render_params, self._dens, self._feat, ws, ws.sibling, height, width, focal, poses,
-                         image_rows, images, batch, diffuse_regularisation,
-                         None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
-                         None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]), step_d, step_f, group["lr"],
-                         losses, rng, beta1=beta1, beta2=beta2, eps=group["eps"], zero_gradient_first=fresh)
+        try:
+            _ops.recon_step_(self.spec, render_params, self._dens, self._feat, ws, ws.sibling, height, width, focal, poses,
+                             image_rows, images, batch, diffuse_regularisation,
+                             None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
+                             None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]), step_d, step_f, group["lr"],
+                             losses, rng, beta1=beta1, beta2=beta2, eps=group["eps"], zero_gradient_first=fresh)
+        except Exception:
+            # the call may have failed BEHIND its first backward (e.g. the diffuse pass was rejected): the gradient region
+            # then holds a partial gradient and the packed grid may be stale -- the next call must clear / re-pack first
+            d.clean_ptr = 0
+            ws.invalidate()
+            raise
+        # This path does not go through Optimizer.step(): registered step pre / post hooks are NOT invoked; the scheduler's
+        # "optimizer.step() before lr_scheduler.step()" check is told that a step happened.
+        self._opt_called = True
         for st in (st_d, st_f):
             if st is not None:
                 st["step"] += 1
@@ -179,6 +206,11 @@ class FusedGridAdam(torch.optim.Optimizer):
         have_render_grad = d is not None and d.dirty and self.workspace.buf is not None
         if not have_render_grad:
             # no render gradient in the workspace this iteration (e.g. a regulariser-only step): per-tensor Adam
+            if self._dcl is not None:     # (the in-step regulariser lives in the fused pass: here it goes through autograd)
+                with torch.enable_grad():
+                    dcl = _ops.density_correlation_loss(self._dens, self._dcl[0])
+                    (dcl * self._dcl[1]).backward()
+                self.dcl_loss.copy_(dcl.detach())
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -190,19 +222,21 @@ class FusedGridAdam(torch.optim.Optimizer):
             return loss
         st_d = self._state_of(self._dens) if train_d else None
         st_f = self._state_of(self._feat) if train_f else None
-        for st in (st_d, st_f):
-            if st is not None:
-                st["step"] += 1
         # torch.optim.Adam counts steps PER PARAMETER: after a step in which only one tensor had a gradient (the per-tensor
-        # branch above) the two counters differ, and so do the bias corrections
-        step_d = st_d["step"] if st_d is not None else st_f["step"]
-        step_f = st_f["step"] if st_f is not None else step_d
+        # branch above) the two counters differ, and so do the bias corrections.  (The counters move only once the kernel call
+        # went through: a raised VoxeError leaves the optimiser as it was.)
+        step_d = (st_d["step"] if st_d is not None else st_f["step"]) + 1
+        step_f = (st_f["step"] + 1) if st_f is not None else step_d
         extra_d = self._dens.grad.contiguous() if (train_d and self._dens.grad is not None) else None
         extra_f = self._feat.grad.contiguous() if (train_f and self._feat.grad is not None) else None
         _ops.grid_adam_step_(self.spec, self._dens, self._feat, d.layout, self.workspace, step_d, group["lr"], step_features=step_f,
                              state_densities=None if st_d is None else (st_d["exp_avg"], st_d["exp_avg_sq"]),
                              state_features=None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]),
                              extra_d_densities=extra_d, extra_d_features=extra_f, beta1=beta1, beta2=beta2,
-                             eps=group["eps"])
+                             eps=group["eps"], dcl_reference=None if self._dcl is None else self._dcl[0],
+                             dcl_weight=0.0 if self._dcl is None else self._dcl[1], dcl_loss=self.dcl_loss)
+        for st in (st_d, st_f):
+            if st is not None:
+                st["step"] += 1
         d.dirty, d.layout = False, _ops.abi.GRAD_ANY
         return loss

@@ -181,6 +181,12 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
     else:   # (data-parallel runs exchange the flat .grad buffer: ordinary gradients)
         optimizer = VoxeAdam([{"params": grid.parameters(), "lr": learning_rate}], betas=(0.9, 0.999))
     lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_gamma)
+    # the default regulariser of the edit (density correlation with the pretrained field, sds_trainer.py:305-309 of the
+    # reference) is evaluated INSIDE the fused grid step: no autograd node, no gradient tensor, no extra pass over the grid
+    dcl_in_step = (isinstance(optimizer, FusedGridAdam) and not uncoupled_mode and not l2_mode and not l1_mode
+                   and density_correlation_weight != 0.0)
+    if dcl_in_step:
+        optimizer.set_density_correlation(regular_density, density_correlation_weight)
     extra_info = {CAMERA_BOUNDS: camera_bounds, CAMERA_INTRINSICS: camera_intrinsics, HEMISPHERICAL_RADIUS: extra_radius}
 
     log.info(f"SDS editing: grid {grid.grid_dims}, image [{im_h} x {im_w}], {num_iterations} iterations")
@@ -223,7 +229,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
             if uncoupled_mode:
                 fit = torch.nn.functional.mse_loss if uncoupled_l2_mode else torch.nn.functional.l1_loss
                 total_loss = total_loss + fit(colour, pixels_batch) * density_correlation_weight
-            else:
+            elif not dcl_in_step:
                 dcl, _ = density_correlation_loss_fn(grid.densities, regular_density, l2_mode=l2_mode, l1_mode=l1_mode)
                 total_loss = total_loss + dcl * (density_correlation_weight * reg_scale)
             if feature_correlation_weight > 0.0:
@@ -235,7 +241,8 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
 
             if flat is not None:
                 flat.zero_grad()
-            total_loss.backward()
+            if torch.is_tensor(total_loss) and total_loss.requires_grad:   # (everything may live inside the grid step)
+                total_loss.backward()
             if flat is not None:
                 flat.all_reduce_grad()      # sum of the per-band render gradients (+ world x regulariser / world)
             optimizer.step()
@@ -244,7 +251,10 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
             trained_time += time.perf_counter() - last
 
             if global_step % summary_freq == 0 or global_step in (1, num_iterations):
-                log.info(f"Iteration: {global_step}, total_loss: {float(total_loss.detach()): .3f}")
+                shown = float(total_loss.detach()) if torch.is_tensor(total_loss) else float(total_loss)
+                if dcl_in_step:    # (its value comes out of the grid step)
+                    shown += density_correlation_weight * float(optimizer.dcl_loss)
+                log.info(f"Iteration: {global_step}, total_loss: {shown: .3f}")
             if global_step % lr_freq == 0 and global_step >= lr_decay_start:
                 lr_scheduler.step()
                 log.info(f"Adjusted learning rate | learning rates: {[g['lr'] for g in optimizer.param_groups]}")

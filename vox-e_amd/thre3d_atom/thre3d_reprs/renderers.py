@@ -25,16 +25,28 @@ from voxe_hip.runtime import VoxeError
 RenderConfig = Any
 RenderProcedure = Callable[[Module, Rays, RenderConfig, Optional[int]], RenderOut]
 
-# Early ray termination is NOT part of the reference (it integrates all S samples).  0.0 keeps exact
-# reference semantics; set_early_termination(eps) stops a ray once its transmittance drops below eps.
+# Gradient truncation is NOT part of the reference (it differentiates all S samples).  0.0 keeps exact reference semantics.
 _TERM_EPS = 0.0
 
 
-def set_early_termination(eps: float) -> None:
-    """gradient truncation of the HIP renderer (VoxeRenderCfg::term_eps; not in the reference, 0 = off): the backward stops
-    marching a ray once its transmittance is below `eps`; forward outputs are never affected"""
+def set_gradient_truncation(eps: float) -> None:
+    """gradient truncation of the HIP renderer (VoxeRenderCfg::term_eps; not in the reference, 0 = off): the BACKWARD stops
+    marching a ray once its transmittance is below `eps` -- the samples in front keep their exact gradient, the samples behind
+    get none (a biased gradient, by at most eps of the ray's weight); forward outputs are never affected.  While it is on,
+    unordered batches of >= 16384 rays do not take the space-binned route (its backward has no truncation): they render
+    through the line-dense scatter, which is slower for such batches -- switch it on for image-ordered renders (SDS steps)."""
     global _TERM_EPS
     _TERM_EPS = float(eps)
+
+
+def set_early_termination(eps: float) -> None:
+    """deprecated name of `set_gradient_truncation` (until r02 the switch also cut the FORWARD march short; since r03 the
+    forward always integrates every sample like the reference and only the gradient is truncated)"""
+    import warnings
+
+    warnings.warn("set_early_termination() is now set_gradient_truncation(): the forward is always exact, only the backward "
+                  "is truncated", DeprecationWarning, stacklevel=2)
+    set_gradient_truncation(eps)
 
 
 @dataclasses.dataclass

@@ -105,10 +105,17 @@ class VoxeProfile(C.Structure):
     ]
 
 
+class VoxeGridRegularisers(C.Structure):
+    _fields_ = [
+        ("dcl_reference", C.c_void_p), ("dcl_weight", C.c_float), ("dcl_loss", C.c_void_p),
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+    ]
+
+
 class VoxeReconStep(C.Structure):
     _fields_ = [
         ("H", C.c_int32), ("W", C.c_int32), ("focal", C.c_float),
-        ("poses", C.c_void_p), ("image_rows", C.c_void_p), ("images", C.c_void_p),
+        ("poses", C.c_void_p), ("image_rows", C.c_void_p), ("images", C.c_void_p), ("num_images", C.c_int32),
         ("K", C.c_int32), ("batch", C.c_int64), ("diffuse_regularisation", C.c_int32),
         ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
         ("step_densities", C.c_int64), ("step_features", C.c_int64),
@@ -168,7 +175,7 @@ HIP_ONLY = {
     "workspace_grad_offset": (C.c_size_t, [_GD]),
     "workspace_grad_bytes": (C.c_size_t, [_GD]),
     "grid_adam_step": (C.c_int, [_GD, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                 C.c_int64, C.c_int64, _P, C.c_size_t, _P]),
+                                 C.c_int64, C.c_int64, C.POINTER(VoxeGridRegularisers), _P, C.c_size_t, _P]),
     "render_route": (C.c_int, [_GD, _RC, C.c_int64]),
     "disparity_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "clock_probe": (C.c_int, [C.c_int32, C.POINTER(C.c_double), _P]),

@@ -589,20 +589,27 @@ def workspace_packed_view(spec: GridSpec, densities, features, workspace: Worksp
 def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, workspace: Workspace, step: int, lr: float,
                     state_densities=None, state_features=None, extra_d_densities=None, extra_d_features=None,
                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                    x_range: Optional[Tuple[int, int]] = None, step_features: Optional[int] = None) -> None:
+                    x_range: Optional[Tuple[int, int]] = None, step_features: Optional[int] = None,
+                    dcl_reference: Optional[torch.Tensor] = None, dcl_weight: float = 0.0,
+                    dcl_loss: Optional[torch.Tensor] = None) -> None:
     """voxe_grid_adam_step: consume the workspace gradient (+ optional extra gradients in tensor layout), update
     densities / features in place with torch.optim.Adam arithmetic, leave the NEW grid packed and a zeroed gradient
     region in the workspace.  state_* = (exp_avg, exp_avg_sq) or None to freeze that tensor.  x_range = (x_begin, x_end)
     restricts the step to a slab of x-planes (sharded optimiser: the caller exchanges the other slabs of the packed grid
     before the next render).  `step` / `step_features`: the 1-based Adam step of the densities / of the features
-    (torch.optim.Adam counts per parameter; `step_features` None = the same as `step`)."""
+    (torch.optim.Adam counts per parameter; `step_features` None = the same as `step`).
+    `dcl_reference` (densities of the pretrained field, same shape as `densities`): the density-correlation regulariser of the
+    SDS edit (modules/sds_trainer.py:507-524) with weight `dcl_weight` is evaluated INSIDE the step -- its moments by two small
+    launches on the current parameters, its gradient per voxel in the Adam pass -- and `dcl_loss` (float32 scalar tensor on the
+    device) receives the unweighted loss value."""
     device = densities.device
     ensure_gfx950(device)
     tensors = [("densities", densities, densities), ("features", features, features)]
     for nm, st, ref in (("state_densities", state_densities, densities), ("state_features", state_features, features)):
         if st is not None:
             tensors += [(nm, st[0], ref), (nm, st[1], ref)]
-    for nm, t, ref in (("extra_d_densities", extra_d_densities, densities), ("extra_d_features", extra_d_features, features)):
+    for nm, t, ref in (("extra_d_densities", extra_d_densities, densities), ("extra_d_features", extra_d_features, features),
+                       ("dcl_reference", dcl_reference, densities)):
         if t is not None:
             tensors.append((nm, t, ref))
     for nm, t, ref in tensors:
@@ -617,10 +624,18 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
     with torch.cuda.device(device):
         ws = workspace.buf
         x0, x1 = (0, int(densities.shape[0])) if x_range is None else (int(x_range[0]), int(x_range[1]))
+        reg = None
+        if dcl_reference is not None:
+            if dcl_loss is not None and (not dcl_loss.is_cuda or dcl_loss.dtype != torch.float32 or dcl_loss.numel() != 1):
+                raise VoxeError("grid_adam_step_: dcl_loss must be a float32 scalar tensor on the device")
+            sc = _scratch_for(device, lib().voxe_dcl_scratch_bytes(densities.numel()))
+            reg = abi.VoxeGridRegularisers()
+            reg.dcl_reference, reg.dcl_weight, reg.dcl_loss = ptr(dcl_reference), float(dcl_weight), ptr(dcl_loss)
+            reg.scratch, reg.scratch_bytes = ptr(sc), sc.numel()
         check(lib().voxe_grid_adam_step(C.byref(g), int(grad_layout), x0, x1, ptr(extra_d_densities), ptr(extra_d_features),
                                         ptr(m_d), ptr(v_d), ptr(m_f), ptr(v_f), float(lr), float(beta1), float(beta2),
                                         float(eps), int(step), int(step if step_features is None else step_features),
-                                        ptr(ws), ws.numel(), stream_ptr(device)),
+                                        None if reg is None else C.byref(reg), ptr(ws), ws.numel(), stream_ptr(device)),
               "voxe_grid_adam_step")
     for t in (densities, features, m_d, v_d, m_f, v_f):
         if t is not None:
@@ -660,6 +675,7 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
     rs = abi.VoxeReconStep()
     rs.H, rs.W, rs.focal = int(height), int(width), float(focal)
     rs.poses, rs.images, rs.image_rows = ptr(poses), ptr(images), ptr(image_rows)
+    rs.num_images = int(images.shape[0])
     rs.K, rs.batch, rs.diffuse_regularisation = int(poses.shape[0]), int(batch), int(bool(diffuse_regularisation))
     rs.lr, rs.beta1, rs.beta2, rs.eps = float(lr), float(beta1), float(beta2), float(eps)
     rs.step_densities, rs.step_features = int(step_densities), int(step_features)
@@ -676,7 +692,12 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
         # (a buffer this call allocated holds whatever torch.empty returned in its gradient region)
         rs.zero_gradient_first = int(bool(zero_gradient_first) or ws is not had)
         c.reuse_packed_grid = int(workspace.key == key)
-        ws2 = workspace2.ensure(nbytes, device) if diffuse_regularisation else None
+        ws2 = None
+        if diffuse_regularisation:
+            # the second workspace runs the DIFFUSE render: for view-dependent grids that render may take another route (and
+            # need other scratch) than the specular one -- size it with the diffuse cfg, and never below the first workspace
+            _, c2 = _descs(spec, dataclasses.replace(p, render_diffuse=True), densities, features, rng[0], rng[1], False)
+            ws2 = workspace2.ensure(max(nbytes, L.voxe_workspace_bytes(C.byref(g), C.byref(c2), int(batch))), device)
         need = L.voxe_recon_scratch_bytes(int(batch))
         sc = holder.get("buf")
         if sc is None or sc.numel() < need or sc.device != ws.device:
