@@ -94,6 +94,36 @@ struct Lat {
   static __device__ __forceinline__ int wrap(int x) { return KL == 8 ? (x & 63) : x; }
 };
 
+// r04: the window's address map.  Even KL with four channels: a PARITY-CLASS BANKED layout -- the three parity bits of a
+// window voxel (ring slot, lateral a, lateral b) are the low bits of its position and the channel sits right above them,
+//   index (doubles) = 32 ((KL/2)^2 (slot >> 1) + (KL/2) (a >> 1) + (b >> 1)) + 8 ch + 4 (slot & 1) + 2 (a & 1) + (b & 1),
+// so the LDS bank pair of a double is (ch, slot parity, a parity, b parity): 32 combinations = the 32 bank pairs.  The eight
+// corners of a cell have eight different parity classes, so the deposit can choose, per lane and sample, the corner ORDER
+// such that instruction (cc, j) of lane L goes to class cc ^ (lane bits 1..3) and channel (j + lane bits 0, 4) & 3: the 32
+// lanes of a half-wave hit 32 DIFFERENT bank pairs in every one of the 32 deposit instructions -- conflict free BY
+// CONSTRUCTION, whatever the view direction (r01 - r03 rotated corners / channels / layers by lane constants, which left 31 %
+// of the LDS cycles to bank conflicts on the axis-aligned bench camera and more on diagonal views).  Other window widths and
+// channel counts keep the r03 map (channel planes, per-layer rotation).
+#ifndef VOXE_TILE_PCB
+#define VOXE_TILE_PCB 1
+#endif
+template <int KL, int C>
+struct WinMap {
+  static constexpr bool kPcb = VOXE_TILE_PCB && (KL % 2 == 0) && C == 4 && (VOXE_TILE_RING % 2 == 0);
+  // strides (doubles) of a pair of b, of a, of ring slots: 32 doubles = one (channel, parity class) block per voxel octet
+  static constexpr int kSB = 32, kSA = 32 * (KL / 2), kSS = 32 * (KL / 2) * (KL / 2);
+  static constexpr int kDoubles = kPcb ? (VOXE_TILE_RING / 2) * kSS : C * Lat<KL>::kPlane;
+  // double index of window voxel (ring slot of layer `key`, lateral a, b), window channel ch
+  static __device__ __forceinline__ int at(int slot, int key, int a, int b, int ch) {
+    if constexpr (kPcb) {
+      (void)key;
+      return (slot >> 1) * kSS + ((slot & 1) << 2) + (a >> 1) * kSA + ((a & 1) << 1) + (b >> 1) * kSB + (b & 1) + (ch << 3);
+    } else {
+      return ch * Lat<KL>::kPlane + slot * Lat<KL>::kLayerSlots + Lat<KL>::pos(key, a * KL + b);
+    }
+  }
+};
+
 // wave-wide integer min / max, result wave-uniform (DPP inside rows of 16, readlane across rows).
 // Must be called with all 64 lanes active.
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -132,7 +162,7 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
                                             const Window& w, int key, int lane, int CM, int memch,
                                             unsigned long long* __restrict__ gdet = nullptr) {
   constexpr int C = WC;
-  constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots, kPlane = Lat<KL>::kPlane;
+  constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots;
   constexpr int kPerInstr = 64 / C;  // voxels per wave instruction (C == 4 -> 16, C == 2 -> 32)
   constexpr int NJ = (kLayerSlots + kPerInstr - 1) / kPerInstr;
   const int im = w.sgn * key;
@@ -141,20 +171,27 @@ __device__ __forceinline__ void flush_layer(double* __restrict__ win, float* __r
   // ~15 % of the kernel's VALU time); the NJ window reads of a layer are issued together (one LDS round trip instead of NJ)
   const int offu = __builtin_amdgcn_readfirstlane(w.off_u(im)), offv = __builtin_amdgcn_readfirstlane(w.off_v(im));
   const long long vox0 = (long long)im * w.stride_m + (long long)offu * w.stride_u + (long long)offv * w.stride_v;
-  const int lbase = ring_slot(key) * kLayerSlots;
   const int ch = lane % C;
   int idx[NJ];
   double val[NJ];
+  // lateral cell (a, b) of this lane in instruction j (b is the z-run).  Parity-class banked window: the 16 voxels of an
+  // instruction are two a-rows x eight b as ever, but dealt to the lanes as 2 x 2 blocks, so that 16 consecutive lanes see all
+  // four (a, b) parity classes -- a layer has ONE slot parity, so 2-way bank conflicts are the floor of a single-layer flush
+  // (rows of eight b per 32 lanes: 4-way).
+  auto cell_of = [&](int j) {
+    if constexpr (WinMap<KL, WC>::kPcb && KL == 8) { const int q = lane >> 2; return (2 * j + (q & 1)) * kLat + (q >> 1); }
+    else return j * kPerInstr + lane / C;
+  };
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int ab = j * kPerInstr + lane / C;  // lateral cell: a = ab / KL, b = ab % KL (b is the z-run)
-    idx[j] = ch * kPlane + lbase + Lat<KL>::pos(key, ab);
+    const int ab = cell_of(j);
+    idx[j] = WinMap<KL, WC>::at(ring_slot(key), key, ab / kLat, ab % kLat, ch);
     const bool live = (kLayerSlots % kPerInstr == 0) || ab < kLayerSlots;
     val[j] = live ? win[idx[j]] : 0.0;        // (DET: the same 64 bits, read as a double only to be tested against zero)
   }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int ab = j * kPerInstr + lane / C;
+    const int ab = cell_of(j);
     if constexpr (DET) {
       const unsigned long long q = (unsigned long long)__double_as_longlong(val[j]);
       if (q != 0ull) {
@@ -213,7 +250,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
   constexpr int NGRP = (NG + C - 1) / C;      // channel groups (1 for SH-0 / diffuse / attention renders)
   static_assert(MODE == 0 || (COUT == 3 && NGRP > 1), "the two-phase backward is for view-dependent grids");
   constexpr int kLat = KL, kLayerSlots = Lat<KL>::kLayerSlots, kPlane = Lat<KL>::kPlane;
-  constexpr int kWinDoubles = MODE == 1 ? 1 : C * kPlane;   // (the source pass has no window)
+  constexpr int kWinDoubles = MODE == 1 ? 1 : WinMap<KL, C>::kDoubles;   // (the source pass has no window)
   __shared__ double win[kWinDoubles];
   const int lane = threadIdx.x;
   for (int i = lane; i < kWinDoubles; i += 64) win[i] = 0.0;
@@ -556,7 +593,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
               wv[s] = (w.v == 1) ? cell.w[1][s] : cell.w[2][s];
             }
             // per layer (cm = 0, 1): ring slot, lateral position of corner (cu, cv) = (0, 0), window test
-            int lofs[2], ab0[2];
+            int lofs[2], ab0[2], la[2], lb[2], lsl[2];
             bool fits = true;
   #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -575,8 +612,70 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
 #endif
               lofs[s] = sl * kLayerSlots;
               ab0[s] = a0 * kLat + b0 + (KL == 8 ? VOXE_TILE_ROT * sl : 0);  // + the per-layer rotation of Lat::pos()
+              la[s] = a0; lb[s] = b0; lsl[s] = sl;
             }
-            if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
+            // (density-only / feature-only SH-0 backwards deposit their zero channels too: exact zeros, skipped by the flush)
+            constexpr bool kPcbPath = WinMap<KL, C>::kPcb;
+            if (kPcbPath && fits) {
+              // Parity-class banked deposit (see WinMap): instruction (cc, j) of this lane goes to the corner whose window
+              // voxel has parity class cc ^ (hm, hu, hv) -- lane bits 2, 3, 4 -- and to channel (j + lane bits 0..1) & 3.
+              // Instructions with the slot-parity bit 0 ("A") take the layer whose ring slot has parity hm, the others
+              // ("B") the other layer; per layer and lateral axis the corner with parity h is used where the axis bit is 0.
+              // (The two layers of a footprint have their own lateral origins, hence their own a / b parities.)
+              if constexpr (kPcbPath) {
+                // lane bits -> (channel rotation, parity class): bit 0 and bit 4 rotate the channel, bits 1..3 pick the class.
+                // Any 16 consecutive lanes then differ in index bits 0..3 (bank pair modulo 16: channel bit 0 + class) and any
+                // 32 in bits 0..4 -- conflict free whether the LDS serves a 64-bit atomic in groups of 16 or of 32 lanes
+                // (the first assignment, class from bits 2..4 and channel from bits 0..1, left 64 M of the 81 M conflict
+                // cycles: 16 lanes shared 8 bank pairs).
+                const int hm = (lane >> 1) & 1, hu = (lane >> 2) & 1, hv = (lane >> 3) & 1;
+                const bool rm = ((lsl[0] ^ hm) & 1) != 0;
+                const int sA = rm ? lsl[1] : lsl[0], sB = rm ? lsl[0] : lsl[1];
+                const int aA = rm ? la[1] : la[0], aB = rm ? la[0] : la[1];
+                const int bA = rm ? lb[1] : lb[0], bB = rm ? lb[0] : lb[1];
+                const float wmA = rm ? wm[1] : wm[0], wmB = rm ? wm[0] : wm[1];
+                // (t0, x0): index term / weight of the corner with parity h along one lateral axis, (t1, x1): the other corner
+                auto split = [](int a, int h, float w0, float w1, int stride, int lo, int& t0, int& t1, float& x0, float& x1) {
+                  const int d0 = (a ^ h) & 1;
+                  const int c0 = a + d0, c1 = a + 1 - d0;
+                  t0 = (c0 >> 1) * stride + (h << lo);
+                  t1 = (c1 >> 1) * stride + ((1 - h) << lo);
+                  x0 = d0 ? w1 : w0;
+                  x1 = d0 ? w0 : w1;
+                };
+                int gA[2], gB[2], hA[2], hB[2];
+                float wuA[2], wuB[2], wvA[2], wvB[2];
+                split(aA, hu, wu[0], wu[1], WinMap<KL, C>::kSA, 1, gA[0], gA[1], wuA[0], wuA[1]);
+                split(aB, hu, wu[0], wu[1], WinMap<KL, C>::kSA, 1, gB[0], gB[1], wuB[0], wuB[1]);
+                split(bA, hv, wv[0], wv[1], WinMap<KL, C>::kSB, 0, hA[0], hA[1], wvA[0], wvA[1]);
+                split(bB, hv, wv[0], wv[1], WinMap<KL, C>::kSB, 0, hB[0], hB[1], wvB[0], wvB[1]);
+                const int FA = (sA >> 1) * WinMap<KL, C>::kSS + (hm << 2), FB = (sB >> 1) * WinMap<KL, C>::kSS + ((1 - hm) << 2);   // (sA & 1 == hm by the choice of A)
+                const int fgA[2] = {FA + gA[0], FA + gA[1]}, fgB[2] = {FB + gB[0], FB + gB[1]};
+                const float wmuA[2] = {wmA * wuA[0], wmA * wuA[1]}, wmuB[2] = {wmB * wuB[0], wmB * wuB[1]};
+                const int crot = (lane & 1) | ((lane >> 3) & 2);
+                const bool c1 = crot & 1, c2 = crot & 2;
+                const float q0 = c1 ? gch[1] : gch[0], q1 = c1 ? gch[2] : gch[1], q2 = c1 ? gch[3] : gch[2], q3 = c1 ? gch[0] : gch[3];
+                const float gr[4] = {c2 ? q2 : q0, c2 ? q3 : q1, c2 ? q0 : q2, c2 ? q1 : q3};   // gr[j] = gch[(j + crot) & 3]
+                int choff[4];
+  #pragma unroll
+                for (int j = 0; j < 4; ++j) choff[j] = ((j + crot) & 3) << 3;
+  #pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                  const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;  // compile-time bits of this instruction
+                  const float wgt = (bm ? wmuB[bu] : wmuA[bu]) * (bm ? wvB[bv] : wvA[bv]);
+                  const int idx = (bm ? fgB[bu] : fgA[bu]) + (bm ? hB[bv] : hA[bv]);
+  #pragma unroll
+                  for (int ch = 0; ch < 4; ++ch) {
+                    if constexpr (DET)
+                      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(win) + (choff[ch] + idx),
+                                             det_quant(gr[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                      __hip_atomic_fetch_add(&win[choff[ch] + idx], (double)(gr[ch] * wgt), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+                  }
+                }
+              }
+            } else if (fits) {  // common case: the whole 2x2x2 footprint is inside the LDS window
               // Lanes permute the corner order (corner index XOR rot, rot = 3 per-lane bits) AND the channel order
               // (crot): the lanes of one wave instruction then spread over 8 corners x C channel planes, so lanes that
               // share a voxel rarely hit the same LDS address / bank in the same instruction.  With an XOR the
@@ -651,15 +750,16 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
                   const bool inwin = ((unsigned)(key - w.base) < (unsigned)kRing) && ((unsigned)a < (unsigned)kLat) &&
                                      ((unsigned)b < (unsigned)kLat);
                   if (inwin) {
-                    const int idx = ring_slot(key) * kLayerSlots + Lat<KL>::pos(key, a * kLat + b);
+                    const int idx = WinMap<KL, C>::at(ring_slot(key), key, a, b, 0);
+                    constexpr int kChStep = WinMap<KL, C>::kPcb ? 8 : kPlane;
   #pragma unroll
                     for (int ch = 0; ch < C; ++ch) {
                       if (NGRP > 1 || (ch < COUT && WANT_F) || (ch == COUT && WANT_D)) {
                         if constexpr (DET)
-                          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(win) + (ch * kPlane + idx),
+                          __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(win) + (ch * kChStep + idx),
                                                  det_quant(gch[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         else
-                          __hip_atomic_fetch_add(&win[ch * kPlane + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
+                          __hip_atomic_fetch_add(&win[ch * kChStep + idx], (double)(gch[ch] * wgt), __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_WORKGROUP);
                       }
                     }
