@@ -52,6 +52,21 @@ constexpr int kRBX = VOXE_REGION_BX, kRBY = VOXE_REGION_BY, kRBZ = VOXE_REGION_B
 constexpr int kRWX = kRBX + 1, kRWY = kRBY + 1, kRWZ = kRBZ + 1;
 constexpr int kRWin = kRWX * kRWY * kRWZ;   // 729 voxels for 8 x 8 x 8 cells
 constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient window (doubles), padded off the bank period
+// r04: parity-class banked gradient window of the 4-channel backward (the map of voxe_render_tile.hip's WinMap in three
+// lateral-free dimensions): index (doubles) = 32 (((x >> 1) * kPY + (y >> 1)) * kPZ + (z >> 1)) + 8 ch + 4 (x & 1) + 2 (y & 1)
+// + (z & 1) for window voxel (x, y, z) in [0, 9)^3.  The lanes pick the ORDER of a sample's 8 corners so that instruction
+// (cc, j) of lane L adds to parity class cc ^ (lane bits 1..3) and channel (j + lane bits 0, 4) & 3: the lanes of a half-wave
+// hit different bank pairs whatever the rays do (segments of unrelated rays meet in a region: r02 / r03 measured 0.84 of the
+// launch in LDS cycles, a third of them conflicts).  9 is odd: the map spends 10^3 / 9^3 of the r03 window (32 KB for 23.5).
+#ifndef VOXE_REGION_PCB
+#define VOXE_REGION_PCB 1
+#endif
+constexpr int kPX = (kRWX + 1) / 2, kPY = (kRWY + 1) / 2, kPZ = (kRWZ + 1) / 2;
+constexpr int kPcbDoubles = 32 * kPX * kPY * kPZ;
+constexpr long long kBankedMinRays = 65536;   // launches from this many rays on take the banked window (see launch_bwd_region_t)
+__device__ __forceinline__ int pcb_index(int x, int y, int z, int ch) {
+  return 32 * (((x >> 1) * kPY + (y >> 1)) * kPZ + (z >> 1)) + (ch << 3) + ((x & 1) << 2) + ((y & 1) << 1) + (z & 1);
+}
 #ifndef VOXE_REGION_CHUNK
 #define VOXE_REGION_CHUNK 16       // longest segment (samples): bounds the lane divergence of the region kernels
 #endif
@@ -592,7 +607,7 @@ __global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch b
 }
 
 // ---- pass 5: backward, one block per region ------------------------------------------------------------------------------------
-template <int COUT, int NCM>
+template <int COUT, int NCM, bool BANKED>
 __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ jitter, const float* __restrict__ colour, const float* __restrict__ depth,
@@ -601,8 +616,10 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
     const int nreg) {
   constexpr int C = COUT + 1, CM = COUT * NCM + 1;
   constexpr bool kTexLds = VOXE_REGION_BWD_TEX != 0;
+  constexpr bool kPcb = BANKED && C == 4;
+  constexpr int kWinDoubles = kPcb ? kPcbDoubles : C * kRPlane;
   __shared__ float tex[kTexLds ? kRWin * C : 1];
-  __shared__ double win[C * kRPlane];
+  __shared__ double win[kWinDoubles];
   const int tid = threadIdx.x;
   const unsigned region = min(blockIdx.x, (unsigned)nreg);     // blocks nreg .. nreg + kGenericBlocks - 1: the generic bin
   const unsigned first = bs.start[region * kLenClasses];
@@ -611,8 +628,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   if (!rb.generic) {
     if constexpr (kTexLds) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
-    for (int i = tid; i < C * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
+    for (int i = tid; i < kWinDoubles; i += VOXE_REGION_BLOCK) win[i] = 0.0;
   }
+  // lane constants of the parity-class deposit
+  const int lane = tid & 63;
+  const int hx = (lane >> 1) & 1, hy = (lane >> 2) & 1, hz = (lane >> 3) & 1, crot = (lane & 1) | ((lane >> 3) & 2);
   __syncthreads();
   const float basis0[1] = {kC0};
   const bool white = c.white && !c.attn;
@@ -706,6 +726,39 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
           for (int ch = 0; ch < C; ++ch)
             if (gch[ch] != 0.0f) atomicAdd(texel + (ch == COUT ? CM - 1 : ch * NCM), gch[ch] * w);
         }
+      } else if constexpr (kPcb) {
+        // per axis: the corner whose window coordinate has parity h goes where the instruction's axis bit is 0
+        const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
+        auto split = [](int l, int h, float w0, float w1, int stride, int lo, int& t0, int& t1, float& x0, float& x1) {
+          const int d0 = (l ^ h) & 1;
+          const int c0 = l + d0, c1 = l + 1 - d0;
+          t0 = (c0 >> 1) * stride + (h << lo);
+          t1 = (c1 >> 1) * stride + ((1 - h) << lo);
+          x0 = d0 ? w1 : w0;
+          x1 = d0 ? w0 : w1;
+        };
+        int tx[2], ty[2], tz[2];
+        float wx[2], wy[2], wz[2];
+        split(lx, hx, cell.w[0][0], cell.w[0][1], 32 * kPY * kPZ, 2, tx[0], tx[1], wx[0], wx[1]);
+        split(ly, hy, cell.w[1][0], cell.w[1][1], 32 * kPZ, 1, ty[0], ty[1], wy[0], wy[1]);
+        split(lz, hz, cell.w[2][0], cell.w[2][1], 32, 0, tz[0], tz[1], wz[0], wz[1]);
+        const bool c1 = crot & 1, c2 = crot & 2;
+        const float q0 = c1 ? gch[1] : gch[0], q1 = c1 ? gch[2] : gch[1], q2 = c1 ? gch[3] : gch[2], q3 = c1 ? gch[0] : gch[3];
+        const float gr[4] = {c2 ? q2 : q0, c2 ? q3 : q1, c2 ? q0 : q2, c2 ? q1 : q3};   // gr[j] = gch[(j + crot) & 3]
+        int choff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) choff[j] = ((j + crot) & 3) << 3;
+        const int txy[4] = {tx[0] + ty[0], tx[1] + ty[0], tx[0] + ty[1], tx[1] + ty[1]};
+        const float wxy[4] = {wx[0] * wy[0], wx[1] * wy[0], wx[0] * wy[1], wx[1] * wy[1]};
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const float w = wxy[cc & 3] * wz[cc >> 2];
+          const int idx = txy[cc & 3] + tz[cc >> 2];
+          // (a frozen tensor's channels deposit exact zeros: skipped by the flush)
+#pragma unroll
+          for (int ch = 0; ch < 4; ++ch)
+            __hip_atomic_fetch_add(&win[choff[ch] + idx], (double)(gr[ch] * w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -726,7 +779,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   // flush: lanes = (voxel, channel), channel fastest -> 16-byte dense global atomics along the z-runs of the window
   for (int e = tid; e < kRWin * C; e += VOXE_REGION_BLOCK) {
     const int vl = e / C, ch = e - vl * C;
-    const double val = win[ch * kRPlane + vl];
+    const double val = kPcb ? win[pcb_index(vl / (kRWY * kRWZ), (vl / kRWZ) % kRWY, vl % kRWZ, ch)] : win[ch * kRPlane + vl];
     if (val == 0.0) continue;
     const int x = rb.ox + vl / (kRWY * kRWZ), y = rb.oy + (vl / kRWZ) % kRWY, zz = rb.oz + vl % kRWZ;
     if (x >= g.X || y >= g.Y || zz >= g.Z) continue;   // (weight-0 corners of size-1 axes / beyond the grid's far faces)
@@ -1040,9 +1093,19 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
   const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, NCU > 1);
   const BinScratch bs = bin_scratch(l, scratch);
   if constexpr (NCU == 1) {
-    region_bwd_kernel<COUT, NCM><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
-        g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
-        a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+    // The parity-class banked window (conflict free, +75 VALU per sample, 32 KB instead of 23.5: 3 blocks per CU instead of 4)
+    // pays when the regions are FULL: 160 000 unordered rays 0.79 -> 0.51 ms, 80 000 (8 cameras of 100x100) 0.373 -> 0.357,
+    // but 32 768 (a reconstruction batch: ~110 segments per region, under two waves) 0.246 -> 0.287 per render
+    // (profiles/r04_ab_lds_layout.txt).  VOXE_REGION_PCB = 0 builds without it.
+    if (VOXE_REGION_PCB && COUT == 3 && c.R >= kBankedMinRays) {
+      region_bwd_kernel<COUT, NCM, true><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
+          g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
+          a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+    } else {
+      region_bwd_kernel<COUT, NCM, false><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
+          g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
+          a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+    }
   } else {
     float4* src = (float4*)((char*)scratch + l.src);
     const size_t lds = full_tex_lds(region_bwd_src_kernel<NCM, NCU>, COUT * NCM + 1);

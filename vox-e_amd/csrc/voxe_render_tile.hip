@@ -24,6 +24,8 @@
 #include <limits.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "voxe_device.hpp"
 #include "voxe_launch.hpp"
 #include "voxe_render_common.hpp"
@@ -106,6 +108,9 @@ struct Lat {
 // channel counts keep the r03 map (channel planes, per-layer rotation).
 #ifndef VOXE_TILE_PCB
 #define VOXE_TILE_PCB 1
+#endif
+#ifndef VOXE_TILE_AXIS_TEMPLATE
+#define VOXE_TILE_AXIS_TEMPLATE 1   // the backward's march instantiated per window axis (4-channel texel kernels)
 #endif
 template <int KL, int C>
 struct WinMap {
@@ -292,7 +297,9 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
   // views whose image x axis maps to u; for the others (e.g. cameras above the volume whose image x is world y) the same
   // instruction count cost 19 % more LDS cycles in bank conflicts (PMC: SQ_LDS_BANK_CONFLICT 105 M vs 80 M per launch): those
   // tiles take their lanes down the pixel COLUMNS instead (profiles/r03_ab_orientation.txt).
-  {
+  // (the parity-class banked window is conflict free whatever the lane order: no re-orientation there)
+  // (decided by the deposit's window type alone: the two phases of the view-dependent backward must map lanes alike)
+  if constexpr (!WinMap<KL, (COUT * NCU + 1 < 4 ? COUT * NCU + 1 : 4)>::kPcb) {
     const unsigned long long am0 = __ballot(alive);
     if ((am0 & 1ull) && (am0 >> 1 & 1ull) && (am0 >> 8 & 1ull)) {
       float d0[3], dx[3], dy[3];
@@ -423,6 +430,14 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     // lowest layer key a sample with low-corner index pm can write (layers pm and pm + 1)
     auto minkey = [&](int pm) { return w.sgn > 0 ? pm : -(pm + 1); };
     auto pick = [&](const int (&t)[3], int axis) { return axis == 0 ? t[0] : (axis == 1 ? t[1] : t[2]); };
+    // r04: the march of the pass with the window's axes as COMPILE-TIME constants (MA = 0 / 1 / 2; -1: run time).  The deposit
+    // is VALU bound since the banked window (LDS issue 0.39, VALU issue 0.83), and the run-time axis picks of the cell's
+    // (march, u, v) indices / weights were ~16 v_cndmask per sample on wave-uniform masks that live in spilled SGPRs
+    // (v_readlane + s_nop each): like fwd_window_march<M>.  Only the 4-channel texel kernels are instantiated three times.
+    auto march = [&](auto axis_tag) {
+    constexpr int MA = decltype(axis_tag)::value;
+    constexpr int UA = (MA == 0) ? 1 : 0, VA = (MA == 2) ? 1 : 2;
+    auto pick_m = [&](const int (&t)[3]) { if constexpr (MA >= 0) return t[MA]; else return pick(t, w.m); };
 
     // ---- per-ray constants of the backward (see render_bwd_kernel) -------------------------------
     float gc[COUT], gsum = 0.0f;
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
       float p[3];
       rc.point(z_cur, p);
       footprint(g, p, fp_cur);
-      first_key = minkey(pick(fp_cur.i0, w.m));
+      first_key = minkey(pick_m(fp_cur.i0));
     }
     w.base = wave_min_i32(first_key);
     __syncthreads();  // window zeroed
@@ -584,13 +599,20 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
             const int base_slot = ring_slot(w.base);   // wave-uniform (scalar unit)
 #endif
             // the cell in (march, lateral u, lateral v) order; all 8 corners are in range (make_cell)
-            const int pm = pick(cell.i, w.m), pu = pick(cell.i, w.u), pv = pick(cell.i, w.v);
+            int pm, pu, pv;
             float wm[2], wu[2], wv[2];
+            if constexpr (MA >= 0) {
+              pm = cell.i[MA]; pu = cell.i[UA]; pv = cell.i[VA];
   #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              wm[s] = (w.m == 0) ? cell.w[0][s] : ((w.m == 1) ? cell.w[1][s] : cell.w[2][s]);
-              wu[s] = (w.u == 0) ? cell.w[0][s] : cell.w[1][s];
-              wv[s] = (w.v == 1) ? cell.w[1][s] : cell.w[2][s];
+              for (int s = 0; s < 2; ++s) { wm[s] = cell.w[MA][s]; wu[s] = cell.w[UA][s]; wv[s] = cell.w[VA][s]; }
+            } else {
+              pm = pick(cell.i, w.m); pu = pick(cell.i, w.u); pv = pick(cell.i, w.v);
+  #pragma unroll
+              for (int s = 0; s < 2; ++s) {
+                wm[s] = (w.m == 0) ? cell.w[0][s] : ((w.m == 1) ? cell.w[1][s] : cell.w[2][s]);
+                wu[s] = (w.u == 0) ? cell.w[0][s] : cell.w[1][s];
+                wv[s] = (w.v == 1) ? cell.w[1][s] : cell.w[2][s];
+              }
             }
             // per layer (cm = 0, 1): ring slot, lateral position of corner (cu, cv) = (0, 0), window test
             int lofs[2], ab0[2], la[2], lb[2], lsl[2];
@@ -787,7 +809,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
       int lb = INT_MAX;
       if (has) {
         if (k + 1 < k_lo) lb = first_key;
-        else if (k + 1 <= k_hi) lb = minkey(pick(fp_cur.i0, w.m));
+        else if (k + 1 <= k_hi) lb = minkey(pick_m(fp_cur.i0));
       }
       const int newbase = wave_min_i32(lb);
       // VOXE_TILE_SLIDE_MIN > 1: let the window lag -- flush only once that many layers can go at once (every flush
@@ -817,7 +839,14 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
         }
       }
     }
-
+    };   // march
+    if constexpr (VOXE_TILE_AXIS_TEMPLATE && CM == 4 && MODE == 0 && !DET) {
+      if (w.m == 0) march(std::integral_constant<int, 0>{});
+      else if (w.m == 1) march(std::integral_constant<int, 1>{});
+      else march(std::integral_constant<int, 2>{});
+    } else {
+      march(std::integral_constant<int, -1>{});
+    }
   };
   // lanes and reference lane of part q under the chosen split
   auto in_part = [&](int q) {
@@ -1220,6 +1249,9 @@ bool det_bwd_supported(const DevCfg& c, int deg, int diffuse) {
   return c.image_width > 0 && (c.attn || deg == 0 || diffuse);   // one channel group, image-ordered rays
 }
 
+// grid side / image width from which on the backward takes the 10-wide lateral window (pixels ~0.6 voxel apart and more)
+constexpr float kWideWindowRatio = 0.58f;
+
 template <int COUT, int NCM, int NCU>
 static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs& a, hipStream_t st) {
   const long long ntx8 = (c.image_width + 7) / 8, nty8 = tile_rows_total(c, 8);
@@ -1242,7 +1274,7 @@ static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs&
   const float env_fit_m = c.disp.tile_fit_m;
   const long long tile_segs = ntx8 * nty8 * num_segments(c.S, c.seg_len);
   const int side_for_kl = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
-  const bool wide = (float)side_for_kl >= 0.75f * (float)c.image_width;
+  const bool wide = (float)side_for_kl >= kWideWindowRatio * (float)c.image_width;
   const float env_fit_lat = c.disp.tile_fit_lat;
   const float fit_lat = env_fit_lat;   // (0: the kernel's default, KL - 2.5 voxels)
   const float fit_m = env_fit_m > 0.0f ? env_fit_m : (qsplit == 4 ? (wide ? 4.5f : 4.0f) : (tile_segs <= 16000 ? 4.5f : 5.5f));
@@ -1282,7 +1314,9 @@ static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs&
     // per block) and only pays once most tiles of the 8-wide window would run as halves or quadrants.
     const int env_kl = c.disp.tile_kl;                 // 8 | 10 overrides the choice
     const int side = g.X > g.Y ? (g.X > g.Z ? g.X : g.Z) : (g.Y > g.Z ? g.Y : g.Z);
-    const int kl = env_kl ? env_kl : ((float)side >= 0.75f * (float)c.image_width ? 10 : 8);
+    // r04 (parity-class banked windows; profiles/r04_small_image_sweep.txt): 266 px on 160^3 (ratio 0.60) now prefers the
+    // 10-wide window too (backward 0.353 -> 0.344 ms); 400 px (0.40) keeps 8
+    const int kl = env_kl ? env_kl : ((float)side >= kWideWindowRatio * (float)c.image_width ? 10 : 8);
 #define VOXE_TBWD_KL(KL)                                                       \
     do {                                                                       \
       if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, KL, nb, 0, 1);         \
