@@ -141,11 +141,11 @@ __device__ __forceinline__ float post_activate(int act, float v) {
   post_activate_vg(act, v, value, grad);
   return value;
 }
-__device__ __forceinline__ float sigmoidf(float x) {
-  const float t = fast_exp(-fabsf(x));
-  const float rc = fast_rcp(1.0f + t);
-  return x >= 0.0f ? rc : t * rc;
-}
+// sigmoid(x) = 1 / (1 + exp(-x)) evaluated as written: exp2 saturates to +inf for x < -88 (-> rcp(inf) = 0, the true value is
+// below 1e-38) and to 0 for x > 88 (-> 1); relative error <= 2 ulp everywhere else.  r04: the sign-split form
+// (exp(-|x|), select, extra multiply) cost 3 more VALU instructions per call, three calls per sample in kernels that are VALU
+// bound since the banked LDS window.
+__device__ __forceinline__ float sigmoidf(float x) { return fast_rcp(1.0f + fast_exp(-x)); }
 
 // ------------------------------------------------------------------------------------------------
 // Sample depths: sample_uniform_points_on_rays (sample.py:15-68) as a rolling generator.
