@@ -475,7 +475,7 @@ def main():
             b2 = pr2["ms_bwd"] / max(pr2["n_bwd"], 1)
             phys2 = None
             if K > 1:   # the 8-camera launch takes the space-binned route: ceilings of its backward kernel (one launch per PH_BWD)
-                phys2 = physical_of("voxe::region_bwd_kernel<3, 1>", lambda k: True, b2)
+                phys2 = physical_of("voxe::region_bwd_kernel<3, 1", lambda k: True, b2)
             return {
                 "workload": f"same grid and step, {K} x {hw2}x{hw2} camera(s) in one launch", "cameras_per_step": K,
                 "value": round(R2 * steps / e2, 1), "unit": "rays/s",

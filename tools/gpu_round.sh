@@ -1,7 +1,7 @@
 #!/bin/bash
 # Full evidence run for a round: GPU tests, smoke, bench lines, rocprofv3 kernel stats.
-#   1. gpurun -- bash tools/gpu_pmc.sh            2. python tools/pmc_to_json.py r03   (stamps the summary with the source hash)
-#   3. gpurun --timeout 2400 -- bash tools/gpu_round.sh r03        4. copy what is to be judged from gpurun_out/r03 to profiles/
+#   1. gpurun -- bash tools/gpu_pmc.sh            2. python tools/pmc_to_json.py r04   (stamps the summary with the source hash)
+#   3. gpurun --timeout 3000 -- bash tools/gpu_round.sh r04        4. copy what is to be judged from gpurun_out/r04 to profiles/
 set -u
 TAG=${1:-r01}
 export TMPDIR=/tmp
@@ -10,7 +10,9 @@ mkdir -p $O
 nproc > $O/host.txt; lscpu | grep -E "Model name|Socket|Core|Thread" >> $O/host.txt
 timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -6 | tee $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -3 | tee $O/smoke.log
-timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench_400.json
+# the driver's command line first (its contract: --steps 20 --warmup 5), then the long one on the same lease
+timeout 600 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_400.json
+timeout 600 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-gpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/bench_400_long.json
 timeout 300 python bench.py --scene sphere --no-cpu-baseline --no-gpu-baseline 2>/dev/null | tail -1 > $O/bench_400_sphere.json
 timeout 300 python bench.py --image 100 --no-cpu-baseline --no-gpu-baseline 2>/dev/null | tail -1 > $O/bench_100.json
 timeout 300 python bench.py --grid 256 --image 800 --no-cpu-baseline --no-gpu-baseline --steps 10 2>/dev/null | tail -1 > $O/bench_256_800.json
@@ -32,7 +34,6 @@ timeout 300 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench.t
 timeout 600 env VOXE_GRAD_EXCHANGE=reduce-scatter VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --steps 3 --warmup 1 --scaling strong 2>/dev/null | tail -1 > $O/two_ranks_one_gpu_gloo_strong.json
 timeout 300 python tools/grid_pass_bench.py 2>/dev/null > $O/grid_passes.txt; cat $O/grid_passes.txt
 timeout 300 python tools/band_probe.py 2>/dev/null > $O/band_probe.txt; tail -12 $O/band_probe.txt
-[ -x tools/microbench/atomics5 ] && timeout 120 ./tools/microbench/atomics5 > $O/microbench5.txt 2>&1
 timeout 300 python bench.py --scene sphere --term-eps 1e-4 --no-cpu-baseline --no-gpu-baseline 2>/dev/null | tail -1 > $O/bench_400_sphere_term1e-4.json
 timeout 300 env RECON_PYTHON_ITER=1 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench_python_iteration.txt
 for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
@@ -44,5 +45,8 @@ cd $GRAFT_REPO_ROOT
 head -6 $O/prof_recon/${TAG}_recon_kernel_stats.csv | cut -c1-160
 head -12 $O/prof_refine/${TAG}_refine_kernel_stats.csv | cut -c1-160
 head -8 $O/prof/${TAG}_kernel_stats.csv | cut -c1-200
+# r04: bit-identity of the LDS-window forward over random cases, and the wide fuzz soak (shipped dispatch + tile kernel on small images)
+timeout 900 python tools/fwd_identity_sweep.py 60 2>/dev/null | tail -2 > $O/fwd_identity_sweep.txt; cat $O/fwd_identity_sweep.txt
+VOXE_FUZZ_SEEDS=4000 timeout 1500 python -m pytest tests/test_hip_fuzz.py -q -m gpu 2>&1 | tail -3 > $O/fuzz_soak.txt; cat $O/fuzz_soak.txt
 # (PMC counters: run tools/gpu_pmc.sh BEFORE this script and tools/pmc_to_json.py <tag> locally -- bench.py only uses a PMC summary
 #  whose source_hash equals the kernels it runs, so the summary has to exist, with the final sources, when the lines above are taken)
