@@ -1,5 +1,5 @@
 export TMPDIR=/tmp
-O=gpurun_out/r04_check14; mkdir -p $O
+O=gpurun_out/r04_check15; mkdir -p $O
 timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -3 | tee $O/pytest_gpu.log
 for rep in 1 2; do
 for lib in "" variants/libvoxe_hip_head.so; do
