@@ -341,13 +341,15 @@ def _region_env(disp, image_too=False):
 
 @pytest.mark.parametrize("case", ["sh0_jitter", "sh0_clip_lindisp", "attn", "diffuse_sh1", "tiny_grid", "image_ordered",
                                   "density_only", "features_only", "jitter_tensor", "sh1", "sh2", "sh1_density_only",
-                                  "sh2_features_only"])
+                                  "sh2_features_only", "sh3", "sh3_density_only"])
 def test_region_backward_variants_vs_oracle(case, disp):
     _region_env(disp, image_too=(case == "image_ordered"))
     rng = np.random.default_rng(zlib.crc32(case.encode()) % 1000)   # (not hash(): salted per process)
     dims = (5, 6, 7) if case == "tiny_grid" else (40, 33, 48)
-    # (sh1 / sh2: view-dependent grids -- whole texels in LDS, two-phase backward; r03)
+    # (sh1 / sh2: view-dependent grids -- whole texels in LDS, two-phase backward; r03.  sh3: 49-channel texels, 151.6 KB; r04)
     nfeat = 12 if case in ("diffuse_sh1", "sh1", "sh1_density_only") else (27 if case in ("sh2", "sh2_features_only") else (1 if case == "attn" else 3))
+    if case.startswith("sh3"):
+        nfeat = 48
     dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
     feat = rng.uniform(-1, 1, (*dims, nfeat)).astype(np.float32)
     grid = vo.Grid(dens, feat, [(-1.5, 1.5), (-1.2, 1.3), (-1.5, 1.4)], 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS,
@@ -369,6 +371,8 @@ def test_region_backward_variants_vs_oracle(case, disp):
         kw.update(sh_degree=1, perturb=True, seed=5, rng_offset=9)
     if case in ("sh2", "sh2_features_only"):
         kw.update(sh_degree=2)
+    if case.startswith("sh3"):
+        kw.update(sh_degree=3, perturb=True, seed=5, rng_offset=9)
     if case == "jitter_tensor":
         kw.update(perturb=True)
         jit = rng.random((o.shape[0], 70)).astype(np.float32)
@@ -383,7 +387,7 @@ def test_region_backward_variants_vs_oracle(case, disp):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, jitter=jit, rng=(5, 9), **over)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, jitter=jit)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (case, rel_l2(gd, rd), rel_l2(gf, rf))
-    if case in ("density_only", "features_only", "sh1_density_only", "sh2_features_only"):
+    if case in ("density_only", "features_only", "sh1_density_only", "sh2_features_only", "sh3_density_only"):
         # one tensor frozen: the other's gradient is unchanged
         from voxe_hip import ops
         dt, ft = gh.t(grid.densities, case.endswith("density_only")), gh.t(grid.features, case.endswith("features_only"))
@@ -519,3 +523,33 @@ def test_real_scene_config_200_grid_416_samples_lindisp_vs_oracle():
     gd, gf = gh.hip_backward(grid, cfg, o2, d2, g2, rng=(21, 4))
     rd, rf = vo.render_bwd(grid, cfg, o2, d2, g2)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+@pytest.mark.parametrize("deg,dims", [(1, (9, 7, 5)), (2, (13, 11, 9)), (3, (8, 8, 8)), (3, (7, 5, 3))])
+def test_wide_texel_conversions_whole_chunks_tail_and_accumulate(deg, dims):
+    """view-dependent grids are packed / un-packed 64 voxels at a time with 16-byte accesses (r04): grids of a whole number of
+    chunks, with a tail and smaller than one chunk give the oracle's gradients; accumulate = 1 adds to what the tensors hold"""
+    from voxe_hip import ops
+    rng = np.random.default_rng(70 + deg)
+    dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
+    feat = rng.uniform(-1, 1, (*dims, 3 * (deg + 1) ** 2)).astype(np.float32)
+    grid = vo.Grid(dens, feat, [(-1.5, 1.5)] * 3, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    o, d = _rays(24, 3)
+    cfg = make_render_cfg(48, NEAR, FAR, white_bkgd=True, sh_degree=deg)
+    gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+    out, ref = gh.hip_forward(grid, cfg, o, d), vo.render_fwd(grid, cfg, o, d)
+    _check_forward(out, ref)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL
+    # accumulate into tensors that already hold values
+    spec, params = gh.spec_of(grid), gh.params_of(cfg)
+    td, tf, to, tdir = gh.t(dens), gh.t(feat), gh.t(o), gh.t(d)
+    outs = [torch.empty((o.shape[0], n), device="cuda") for n in (3, 1, 1, 1)]
+    ws = ops.Workspace()
+    ops.render_fwd_into(spec, params, td, tf, to, tdir, None, *outs, ws, (0, 0))
+    d_d, d_f = torch.full_like(td, 0.25), torch.full_like(tf, -0.5)
+    ops.render_bwd_into(spec, params, td, tf, to, tdir, None, outs[0], outs[1], outs[2], gh.t(gc), None, None, d_d, d_f, ws,
+                        (0, 0), accumulate=True)
+    np.testing.assert_allclose(gh.n(d_d) - 0.25, gd, rtol=0, atol=2e-6 * max(1.0, float(np.abs(gd).max())))
+    np.testing.assert_allclose(gh.n(d_f) + 0.5, gf, rtol=0, atol=2e-6 * max(1.0, float(np.abs(gf).max())))

@@ -77,6 +77,17 @@ __device__ __forceinline__ int pcb_index(int x, int y, int z, int ch) {
 #define VOXE_REGION_SLOTS 16
 #endif
 constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, depth segment)
+#ifndef VOXE_REGION_SH3
+#define VOXE_REGION_SH3 1          // SH degree 3 (49-channel texels) on this route too: the staging kernels take 151.6 KB of LDS
+#endif
+#ifndef VOXE_REGION_STAGE_FWD_NCU
+#define VOXE_REGION_STAGE_FWD_NCU 1    // view-dependent grids: stage a region's whole texels in LDS up to this many coefficients per colour
+                                       // (r04, 32 400 random rays, staged / from L2: forward SH-1 0.49 / 0.47, SH-2 1.01 / 0.71, SH-3 2.78 / 1.13 ms;
+                                       // backward SH-1 1.10 / 1.16, SH-2 2.49 / 2.27, SH-3 5.41 / 3.74 -- 81.6 / 151.6 KB leave ONE block per CU)
+#endif
+#ifndef VOXE_REGION_STAGE_BWD_NCU
+#define VOXE_REGION_STAGE_BWD_NCU 4
+#endif
 #ifndef VOXE_REGION_SH_WC
 #define VOXE_REGION_SH_WC 7        // gradient channels per deposit pass of a view-dependent grid (window: WC x 5.9 KB of LDS).
                                    // Swept (32 400 random rays, backward ms, SH-1 / SH-2): 4 -> 1.21 / 2.56, 7 -> 1.10 / 2.48 (13 = 2 / 4
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
                                                                        const float* __restrict__ rays_o,
                                                                        const float* __restrict__ rays_d,
                                                                        const float* __restrict__ jitter, BinScratch bs,
-                                                                       const int nreg) {
+                                                                       const int nreg, const int stage) {
   constexpr int C = COUT + 1;
   // single-group renders (SH-0 / diffuse / attention) stage (coefficient 0 of every colour, density); view-dependent ones
   // the whole texel (dynamic LDS: 46.6 KB at degree 1, 81.6 KB at degree 2)
@@ -437,7 +448,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
   const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
   if (n == 0) return;                       // block-uniform
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
-  if (!rb.generic) {
+  // stage == 0 (degree-3 texels, launch_fwd_region_t): the region's segments march together but fetch their texels from L1 / L2
+  const bool from_global = rb.generic || stage == 0;
+  if (!from_global) {
     if constexpr (NCU == 1) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
     else load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
   }
@@ -467,7 +480,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
       Cell cell;
       make_cell_fast(g, fp, cell);
       float v, rad[COUT];
-      if (rb.generic) {
+      if (from_global) {
+        if (!rb.generic) {   // (a segment's samples outside its region belong to another segment, as below)
+          const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
+          if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
+        }
         gather<COUT, NCM, NCU>(g, packed, cell, basis, v, rad);
       } else {
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
@@ -800,7 +817,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ jitter, const float* __restrict__ d_colour, const float* __restrict__ d_depth,
     const float* __restrict__ d_acc, const int want_d, const int want_f, BinScratch bs, const int nreg,
-    float4* __restrict__ src) {
+    float4* __restrict__ src, const int stage) {
   constexpr int COUT = 3;
   extern __shared__ float4 tex_dyn[];
   float* const tex = reinterpret_cast<float*>(tex_dyn);
@@ -810,7 +827,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
   const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
   if (n == 0) return;
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
-  if (!rb.generic) load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+  const bool from_global = rb.generic || stage == 0;   // (see region_fwd_kernel)
+  if (!from_global) load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
   __syncthreads();
   const bool white = c.white && !c.attn;
   const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
@@ -848,7 +866,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
       Cell cell;
       make_cell_fast(g, fp, cell);
       float v, rad[COUT];
-      if (rb.generic) {
+      if (from_global) {
+        if (!rb.generic) {
+          const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
+          if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
+        }
         gather<COUT, NCM, NCU>(g, packed, cell, basis, v, rad);
       } else {
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
@@ -997,9 +1019,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_dep_kernel(
 bool region_bwd_supported(const DevGrid& g, const HostCfg& c, int deg, int diffuse, bool tiled) {
   const long long min_rays = disp_region_min_rays(c.disp);   // (< 0: the route is switched off)
   if (min_rays < 0 || c.R < min_rays || c.term_eps > 0.0f) return false;
-  if (!(c.attn || deg <= 2 || diffuse)) return false;          // SH-0 / diffuse / attention: one channel group; SH degree 1 / 2:
-                                                               // whole texels in LDS + two-phase backward (degree 3: 49-channel
-                                                               // texels do not fit)
+  // SH-0 / diffuse / attention: one channel group.  SH degree 1 - 3: whole texels in LDS + two-phase backward (degree 3:
+  // 729 texels x 52 floats = 151.6 KB of the CU's 160 KB -- one block per CU, still 2.4x the generic scatter; r04)
+  if (VOXE_REGION_SH3 == 0 && !(c.attn || deg <= 2 || diffuse)) return false;
   if (num_segments(c.S, c.seg_len) > 256) return false;       // (the lanes of a ray meet in one block's LDS: region_fold_kernel)
   if (c.R > (1ll << 19) || c.S >= 65536) return false;         // segment records hold 32-bit rays / 16-bit sample indices;
                                                                // the tables take ~12 KB per ray (S = 256): capped at 512 k rays (6 GB) per launch
@@ -1081,8 +1103,10 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
   region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes);
-  const size_t lds = NCU > 1 ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;
-  region_fwd_kernel<COUT, NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  // degree 3: staging the 151.6 KB of a region's texels leaves one block (4 waves) per CU
+  const int stage = (NCU > VOXE_REGION_STAGE_FWD_NCU) ? 0 : 1;
+  const size_t lds = (NCU > 1 && stage) ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;
+  region_fwd_kernel<COUT, NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg, stage);
   const int rays_per_block = 256 / nseg;        // (nseg <= 256: region_bwd_supported)
   region_fold_kernel<COUT><<<(int)((c.R + rays_per_block - 1) / rays_per_block), 256, 0, st>>>(
       c, bs, a.colour, a.depth, a.acc, a.disparity, rays_per_block);
@@ -1108,10 +1132,11 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
     }
   } else {
     float4* src = (float4*)((char*)scratch + l.src);
-    const size_t lds = full_tex_lds(region_bwd_src_kernel<NCM, NCU>, COUT * NCM + 1);
+    const int stage = (NCU > VOXE_REGION_STAGE_BWD_NCU) ? 0 : 1;
+    const size_t lds = stage ? full_tex_lds(region_bwd_src_kernel<NCM, NCU>, COUT * NCM + 1) : 0;
     region_bwd_src_kernel<NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(
         g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.d_colour, a.d_depth, a.d_acc, a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs,
-        l.nreg, src);
+        l.nreg, src, stage);
     // channel groups of VOXE_REGION_SH_WC: all of them for a feature gradient, only the one holding the density channel (the last) otherwise
     constexpr int NGRP = (COUT * NCU + 1 + VOXE_REGION_SH_WC - 1) / VOXE_REGION_SH_WC;
     const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
@@ -1126,7 +1151,7 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
     else if (deg == 0) FN<3, 1, 1>(__VA_ARGS__);                                         \
     else if (deg == 1) { if (diffuse) FN<3, 4, 1>(__VA_ARGS__); else FN<3, 4, 4>(__VA_ARGS__); }   \
     else if (deg == 2) { if (diffuse) FN<3, 9, 1>(__VA_ARGS__); else FN<3, 9, 9>(__VA_ARGS__); }   \
-    else FN<3, 16, 1>(__VA_ARGS__);   /* (degree 3: diffuse only, region_bwd_supported) */ \
+    else { if (diffuse || VOXE_REGION_SH3 == 0) FN<3, 16, 1>(__VA_ARGS__); else FN<3, 16, 16>(__VA_ARGS__); }   \
   } while (0)
 
 // forward of the space-binned path: fills the segment tables + per-segment states in `scratch` (the backward reuses them
