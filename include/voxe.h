@@ -389,6 +389,9 @@ int voxe_disparity_bwd(const float* depth, const float* acc, const float* d_disp
  *   update  : voxe_grid_adam_step over the whole grid with the given Adam state / hyper-parameters; afterwards
  *             `workspace` holds the updated grid packed (pass cfg->reuse_packed_grid = 1 next time) and a cleared gradient.
  *   scratch : voxe_recon_scratch_bytes(batch) bytes of device memory (rays, targets, outputs, upstream gradients).
+ *   SH-0 grids with diffuse_regularisation: when `workspace` holds voxe_workspace_bytes(grid, cfg, 2 * batch) bytes, both
+ *   renders run as ONE launch of 2 * batch rays (same rays, jitter streams offset + 1 / + 2 as below; one binning pass,
+ *   one forward, one backward) and `workspace2` is not touched; a smaller `workspace` takes the two-render path.
  *   Requires an SH grid (3 colour channels).  Arithmetic identical to the composition of the separate calls.        */
 typedef struct {
   int32_t H, W;

@@ -68,9 +68,24 @@ int validate(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, Variant* 
   return VOXE_OK;
 }
 
+// voxe_recon_step's paired render (two renders of the same batch with independent jitter streams in ONE launch of 2 B rays):
+// set around its calls of the render entry points; the space-binned kernels read DevCfg::pair_R
+struct PairSpec { int64_t rays; uint64_t rng_offset; };
+thread_local const PairSpec* tl_pair = nullptr;
+struct PairScope {
+  explicit PairScope(const PairSpec* p) { tl_pair = p; }
+  ~PairScope() { tl_pair = nullptr; }
+};
+
 void make_dev(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R, const Variant& v, DevGrid* dg,
               HostCfg* dc) {
   dc->disp = disp_of(c);
+  dc->pair_R = 0; dc->key0b = dc->key1b = 0;
+  if (tl_pair) {
+    dc->pair_R = tl_pair->rays;
+    dc->key0b = (uint32_t)c->seed ^ ((uint32_t)tl_pair->rng_offset * 0x9E3779B1u);
+    dc->key1b = (uint32_t)(c->seed >> 32) ^ (uint32_t)(tl_pair->rng_offset >> 32) ^ 0x7F4A7C15u;
+  }
   dg->X = g->X; dg->Y = g->Y; dg->Z = g->Z;
   for (int a = 0; a < 3; ++a) {
     dg->lo[a] = g->aabb_lo[a]; dg->hi[a] = g->aabb_hi[a];
@@ -472,8 +487,11 @@ int voxe_disparity_bwd(const float* depth, const float* acc, const float* d_disp
 }
 
 namespace {
+#ifndef VOXE_RECON_PAIRED
+#define VOXE_RECON_PAIRED 1
+#endif
 inline size_t up256b(size_t x) { return (x + 255) / 256 * 256; }
-struct ReconLayout { size_t subset, rays_o, rays_d, target, out[2], d_colour[2], partial, total; };
+struct ReconLayout { size_t subset, rays_o, rays_d, target, out[2], d_colour[2], partial, out2, d_colour2, total; };
 ReconLayout recon_layout(int64_t B) {
   ReconLayout l;
   size_t off = 0;
@@ -485,6 +503,9 @@ ReconLayout recon_layout(int64_t B) {
   for (int i = 0; i < 2; ++i) { l.out[i] = off; off += up256b(b * 5 * sizeof(float)); }        // colour [B,3] | depth [B] | acc [B]
   for (int i = 0; i < 2; ++i) { l.d_colour[i] = off; off += up256b(b * 3 * sizeof(float)); }
   l.partial = off; off += up256b(l1_scratch_bytes());
+  // paired render: colour [2B,3] | depth [2B] | acc [2B], d_colour [2B,3]
+  l.out2 = off; off += up256b(2 * b * 5 * sizeof(float));
+  l.d_colour2 = off; off += up256b(2 * b * 3 * sizeof(float));
   l.total = off;
   return l;
 }
@@ -517,6 +538,40 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   st = voxe_cast_rays_indexed(rs->H, rs->W, rs->focal, rs->poses, rs->K, subset, B, rays_o, rays_d, stream);
   if (st) return st;
   launch_gather_pixels(rs->images, (const long long*)rs->image_rows, (const long long*)subset, B, rs->H * rs->W, rs->num_images, target, s);
+  // SH-0 grids: the diffuse render is the specular kernel with another jitter stream -- both renders as ONE launch of 2 B
+  // rays on the space-binned route (one binning pass, one forward, one backward; no second packed grid).  32 768-ray
+  // batches leave the chip half empty and the binning / scan / fold passes are launch-latency sized: r04, 160^3,
+  // 1.15 -> see profiles/r04_recon_bench.txt.  Needs `workspace` sized for 2 B rays (voxe_workspace_bytes(grid, cfg, 2 B)).
+  if (nrender == 2 && cfg->sh_degree == 0 && VOXE_RECON_PAIRED) {
+    VoxeRenderCfg pc = *cfg;
+    pc.rng_offset = cfg->rng_offset + 1;
+    pc.render_diffuse = 0;
+    pc.linear_grad = 1;
+    const PairSpec pair{B, cfg->rng_offset + 2};
+    PairScope scope(&pair);
+    const WsLayout wl = ws_layout(grid, &pc, 2 * B);
+    if (wl.region && workspace_bytes >= wl.total_with_src) {
+      float* colour = (float*)(sc + l.out2);
+      float *depth = colour + 6 * B, *acc = depth + 2 * B;
+      float* d_colour = (float*)(sc + l.d_colour2);
+      st = voxe_render_fwd(grid, &pc, rays_o, rays_d, 2 * B, nullptr, colour, depth, acc, nullptr, workspace, workspace_bytes, stream);
+      if (st) return st;
+      for (int i = 0; i < 2; ++i)
+        launch_l1_loss_grad(colour + 3 * B * i, target, 3 * B, d_colour + 3 * B * i, rs->losses + 2 * i, sc + l.partial, s);
+      pc.ray_state_valid = 1;
+      pc.reuse_packed_grid = 1;
+      int32_t layout = VOXE_GRAD_ANY;
+      st = voxe_render_bwd_acc_into(grid, &pc, rays_o, rays_d, 2 * B, nullptr, colour, depth, acc, d_colour, nullptr, nullptr,
+                                    rs->exp_avg_densities != nullptr, rs->exp_avg_features != nullptr,
+                                    rs->zero_gradient_first ? 1 : 0, &layout, workspace, workspace_bytes, nullptr, 0, stream);
+      if (st) return st;
+      if (layout != VOXE_GRAD_LINEAR) return VOXE_ERR_UNSUPPORTED;
+      return voxe_grid_adam_step(grid, VOXE_GRAD_LINEAR, 0, grid->X, nullptr, nullptr, rs->exp_avg_densities,
+                                 rs->exp_avg_sq_densities, rs->exp_avg_features, rs->exp_avg_sq_features, rs->lr, rs->beta1,
+                                 rs->beta2, rs->eps, rs->step_densities, rs->step_features, nullptr, workspace, workspace_bytes,
+                                 stream);
+    }
+  }
   VoxeRenderCfg rc[2] = {*cfg, *cfg};
   void* ws[2] = {workspace, workspace2};
   size_t wsb[2] = {workspace_bytes, workspace2_bytes};

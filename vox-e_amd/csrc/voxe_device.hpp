@@ -39,6 +39,10 @@ struct DevCfg {
   long long R;
   int linear_grad;            // the scatter backward writes the linear gradient layout (VoxeRenderCfg::linear_grad)
   int seg_len;                // samples per depth segment of the segmented kernels (seg_len_for(R))
+  // paired launch (voxe_recon_step on SH-0 grids, space-binned route only): rays [pair_R, 2 pair_R) of the launch are rays
+  // [0, pair_R) of the ray arrays again, drawn with the second jitter stream (key0b, key1b); 0 = off
+  long long pair_R;
+  uint32_t key0b, key1b;
 };
 
 // ------------------------------------------------------------------------------------------------

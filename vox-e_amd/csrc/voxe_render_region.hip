@@ -63,7 +63,10 @@ constexpr int kRPlane = kRWin + 7;          // channel plane of the gradient win
 #endif
 constexpr int kPX = (kRWX + 1) / 2, kPY = (kRWY + 1) / 2, kPZ = (kRWZ + 1) / 2;
 constexpr int kPcbDoubles = 32 * kPX * kPY * kPZ;
-constexpr long long kBankedMinRays = 65536;   // launches from this many rays on take the banked window (see launch_bwd_region_t)
+#ifndef VOXE_REGION_PCB_MIN_RAYS
+#define VOXE_REGION_PCB_MIN_RAYS 65536
+#endif
+constexpr long long kBankedMinRays = VOXE_REGION_PCB_MIN_RAYS;   // launches from this many rays on take the banked window (see launch_bwd_region_t)
 __device__ __forceinline__ int pcb_index(int x, int y, int z, int ch) {
   return 32 * (((x >> 1) * kPY + (y >> 1)) * kPZ + (z >> 1)) + (ch << 3) + ((x & 1) << 2) + ((y & 1) << 1) + (z & 1);
 }
@@ -143,11 +146,20 @@ __device__ __forceinline__ void ray_basis(const float (&d)[3], float dnorm, floa
   }
 }
 
+// paired launch (DevCfg::pair_R): the ray-array index and jitter keys of launch ray r
+__device__ __forceinline__ long long pair_source(const DevCfg& c, long long r, uint32_t& k0, uint32_t& k1) {
+  k0 = c.key0; k1 = c.key1;
+  if (c.pair_R > 0 && r >= c.pair_R) { k0 = c.key0b; k1 = c.key1b; return r - c.pair_R; }
+  return r;
+}
+
 struct SegRay {
   float o[3], d[3], dnorm;
   DepthGen dg;
-  __device__ __forceinline__ void init(const DevGrid& g, const DevCfg& c, long long r, const float* __restrict__ rays_o,
+  __device__ __forceinline__ void init(const DevGrid& g, const DevCfg& c, long long r_launch, const float* __restrict__ rays_o,
                                        const float* __restrict__ rays_d, const float* __restrict__ jitter) {
+    uint32_t k0, k1;
+    const long long r = pair_source(c, r_launch, k0, k1);
 #pragma unroll
     for (int a = 0; a < 3; ++a) { o[a] = rays_o[3 * r + a]; d[a] = rays_d[3 * r + a]; }
     dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -158,7 +170,7 @@ struct SegRay {
     dg.step = 1.0f / (float)(c.S - 1);
     dg.perturb = c.perturb != 0;
     dg.jit = jitter ? jitter + r * c.S : nullptr;
-    dg.base = jitter_base(c.key0, c.key1, r);
+    dg.base = jitter_base(k0, k1, r);
     dg.kc = INT_MIN;
   }
   __device__ __forceinline__ void point(float z, float (&p)[3]) const {
@@ -193,7 +205,11 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     if (r >= c.R) return;
   }
   RayCtx<3, 1, 1> rc;   // (origin, direction, depth generator, conservative in-AABB sample range)
-  rc.init(g, c, r, rays_o, rays_d, jitter);
+  {
+    DevCfg cj = c;        // (paired launch: the second half's jitter keys, the first half's rays)
+    const long long rs = pair_source(c, r, cj.key0, cj.key1);
+    rc.init(g, cj, rs, rays_o, rays_d, jitter);
+  }
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
   const int k_lo = max(rc.k_lo, ks), k_hi = min(rc.k_hi, ke);
   const long long nlanes = c.R * nseg, lane_id = lane_of(r, seg, c.R);

@@ -687,6 +687,9 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
     holder = scratch_holder if scratch_holder is not None else workspace.recon_scratch
     with torch.cuda.device(device):
         nbytes = L.voxe_workspace_bytes(C.byref(g), C.byref(c), int(batch))
+        if diffuse_regularisation and p.sh_degree == 0:
+            # SH-0: the library runs both renders as ONE launch of 2 * batch rays when the first workspace holds that launch
+            nbytes = max(nbytes, L.voxe_workspace_bytes(C.byref(g), C.byref(c), 2 * int(batch)))
         had = workspace.buf
         ws = workspace.ensure(nbytes, device)
         # (a buffer this call allocated holds whatever torch.empty returned in its gradient region)
