@@ -498,6 +498,41 @@ def main():
                               "mean_rays_per_s_incl_headline_camera": round(HW * HW / (mean_ms * 1e-3), 1),
                               "mean_ms_per_step": round(mean_ms, 4)}
 
+        # the reconstruction trainer's iteration (BASELINE.json configs[1] scale: 32 768 random rays over 8 cameras, specular +
+        # diffuse L1, fused Adam) as ONE library call, voxe_recon_step -- tools/recon_bench.py has the trainer-level version
+        def recon_iteration_bench(iters):
+            K, B = 8, 32768
+            d2, f2 = dens.clone(), feat.clone()
+            st_d, st_f = (torch.zeros_like(d2), torch.zeros_like(d2)), (torch.zeros_like(f2), torch.zeros_like(f2))
+            cams = [pose_spherical(*synth_pose_angles(3 + 11 * i, 100), RADIUS) for i in range(K)]
+            poses = torch.stack([torch.cat([p_i.rotation, p_i.translation], dim=-1) for p_i in cams]).to(dev).contiguous()
+            images = torch.rand((K, 3, HW, HW), generator=torch.Generator().manual_seed(45)).to(dev)
+            losses = torch.zeros(4, device=dev)
+            ws_a, ws_b = ops.Workspace(), ops.Workspace()
+            pr = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True)
+
+            def it(n):
+                ops.recon_step_(spec, pr, d2, f2, ws_a, ws_b, HW, HW, focal_for(HW), poses, None, images, B, True, st_d, st_f,
+                                n, n, 1e-4, losses, (77, 10 * n), zero_gradient_first=(n == 1))
+
+            gc.collect()
+            gc.disable()
+            for n in range(1, 11):
+                it(n)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for n in range(11, 11 + iters):
+                it(n)
+            torch.cuda.synchronize()
+            e3 = (time.perf_counter() - t3) / iters
+            gc.enable()
+            return {"workload": f"voxe_recon_step: {B} random rays over {K} cameras ({HW}x{HW}), specular + diffuse render, L1 losses, "
+                                "backward, fused Adam -- one library call per iteration",
+                    "ms_per_iteration": round(1e3 * e3, 4), "iterations_per_s": round(1.0 / e3, 1),
+                    "value": round(2 * B / e3, 1), "unit": "rendered rays/s (2 renders, fwd + bwd)"}
+
+        secondary["recon_iteration"] = recon_iteration_bench(max(args.steps, 20))
+
     # ---- same-GPU baseline: a plain PyTorch restatement of the path (the reference's execution model: ~40 ATen ops with
     # [rays x samples] temporaries + autograd + torch.optim.Adam; voxe_hip/torch_baseline.py, pinned to the reference's
     # outputs and gradients by tests/test_torch_baseline.py) under PyTorch-ROCm on this very GPU, outside the timed region ----

@@ -306,7 +306,7 @@ def test_density_correlation_inside_the_grid_step_equals_the_separate_pass():
                 dd = d.clone().requires_grad_(True)
                 l = ops.density_correlation_loss(dd, ref)
                 (l * weight).backward()
-                vals.append(float(l))
+                vals.append(float(l.detach()))
                 ops.grid_adam_step_(spec, d, f, layout, ws, it, 1e-2, state_densities=st_d, state_features=st_f,
                                     extra_d_densities=dd.grad.contiguous())
             else:

@@ -109,6 +109,9 @@ struct Lat {
 #ifndef VOXE_TILE_PCB
 #define VOXE_TILE_PCB 1
 #endif
+#ifndef VOXE_TILE_AXIS_TEMPLATE_SH
+#define VOXE_TILE_AXIS_TEMPLATE_SH 0   // ... and the deposit passes of view-dependent grids (MODE 2)
+#endif
 #ifndef VOXE_TILE_AXIS_TEMPLATE
 #define VOXE_TILE_AXIS_TEMPLATE 1   // the backward's march instantiated per window axis (4-channel texel kernels)
 #endif
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
       }
     }
     };   // march
-    if constexpr (VOXE_TILE_AXIS_TEMPLATE && CM == 4 && MODE == 0 && !DET) {
+    if constexpr (VOXE_TILE_AXIS_TEMPLATE && !DET && ((CM == 4 && MODE == 0) || (VOXE_TILE_AXIS_TEMPLATE_SH && MODE == 2))) {
       if (w.m == 0) march(std::integral_constant<int, 0>{});
       else if (w.m == 1) march(std::integral_constant<int, 1>{});
       else march(std::integral_constant<int, 2>{});
