@@ -198,6 +198,35 @@ struct DepthGen {
   }
 };
 
+// Stratum table of one depth segment (r04).  Without AABB clipping every ray of a launch has the same (near, far), so the
+// stratum (lower_k, span_k) of sample k -- DepthGen::z()'s three zlin() values, two mid-points and the difference, ~17 VALU
+// instructions per sample in kernels that are VALU-issue bound -- is the same for all rays: the lanes of a block tabulate the
+// strata of their segment ONCE, with DepthGen's own expressions (identical floats), and a sample's depth becomes one LDS
+// read + `lower + span * u`.  Entry j of the table belongs to sample ks + j.
+__device__ __forceinline__ float2 depth_stratum(const DepthGen& dg, int k) {
+  const float z0 = dg.zlin(k);
+  if (!dg.perturb) return make_float2(z0, 0.0f);
+  const float zm = (k > 0) ? dg.zlin(k - 1) : 0.0f;
+  const float zp = (k < dg.S - 1) ? dg.zlin(k + 1) : 0.0f;
+  const float lower = (k == 0) ? z0 : 0.5f * (z0 + zm);
+  const float upper = (k == dg.S - 1) ? z0 : 0.5f * (zp + z0);
+  return make_float2(lower, upper - lower);
+}
+template <bool TAB>
+struct SegDepth {
+  const float2* tab;   // LDS
+  int ks;
+  __device__ __forceinline__ float z(DepthGen& dg, int k) const {
+    if constexpr (TAB) {
+      const float2 t = tab[k - ks];
+      if (!dg.perturb) return t.x;
+      return t.x + t.y * dg.uniform(k);
+    } else {
+      return dg.z(k);
+    }
+  }
+};
+
 // _ray_aabb_intersection (sample.py:71-184): per-ray (near, far)
 __device__ __forceinline__ void ray_aabb_bounds(const DevGrid& g, const float (&o)[3],
                                                 const float (&d)[3], float& near, float& far) {

@@ -109,6 +109,12 @@ struct Lat {
 #ifndef VOXE_TILE_PCB
 #define VOXE_TILE_PCB 1
 #endif
+#ifndef VOXE_TILE_STRATA
+#define VOXE_TILE_STRATA 1   // stratum table per depth segment (voxe_device.hpp: SegDepth) in the window forward: -2 .. -5 % forward time
+#endif
+#ifndef VOXE_TILE_STRATA_BWD
+#define VOXE_TILE_STRATA_BWD 0   // ... and in the SH-0 tile backward: measured equal (0.478 ms either way; 80 B more scratch), off
+#endif
 #ifndef VOXE_TILE_AXIS_TEMPLATE_SH
 #define VOXE_TILE_AXIS_TEMPLATE_SH 0   // ... and the deposit passes of view-dependent grids (MODE 2)
 #endif
@@ -372,6 +378,15 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
       }
     }
   }
+  // r04: the strata of this depth segment, tabulated once per block (SegDepth; not with per-ray AABB bounds)
+  constexpr bool kStrata = VOXE_TILE_STRATA_BWD && CM == 4 && MODE == 0 && !DET;
+  __shared__ float2 strat[kStrata ? 64 : 1];
+  bool use_strata = false;
+  if constexpr (kStrata) {
+    use_strata = !c.aabb_clip && (ke + 1 - ks) < 64;
+    if (use_strata && lane <= ke + 1 - ks && ks + lane < c.S) strat[lane] = depth_stratum(rc.dg, ks + lane);
+    __syncthreads();
+  }
   auto run_pass = [&](const bool alive_q, const int centre_lane, const int centre_lane2) {
     rc.dg.kc = INT_MIN;                        // fresh rolling depth window for this pass
     const int k_lo = max(rc.k_lo, ks);          // this lane's samples inside the segment
@@ -437,8 +452,9 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     // is VALU bound since the banked window (LDS issue 0.39, VALU issue 0.83), and the run-time axis picks of the cell's
     // (march, u, v) indices / weights were ~16 v_cndmask per sample on wave-uniform masks that live in spilled SGPRs
     // (v_readlane + s_nop each): like fwd_window_march<M>.  Only the 4-channel texel kernels are instantiated three times.
-    auto march = [&](auto axis_tag) {
+    auto march = [&](auto axis_tag, auto strata_tag) {
     constexpr int MA = decltype(axis_tag)::value;
+    const SegDepth<decltype(strata_tag)::value> sd{strat, ks};
     constexpr int UA = (MA == 0) ? 1 : 0, VA = (MA == 2) ? 1 : 2;
     auto pick_m = [&](const int (&t)[3]) { if constexpr (MA >= 0) return t[MA]; else return pick(t, w.m); };
 
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     bool dead = false;          // early ray termination reached (term_eps > 0)
     int first_key = INT_MAX;
     if (has) {
-      z_cur = rc.dg.z(k_lo);
+      z_cur = sd.z(rc.dg, k_lo);
       float p[3];
       rc.point(z_cur, p);
       footprint(g, p, fp_cur);
@@ -528,7 +544,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
         const bool last = (k == c.S - 1);
         float z_next = z;
         if (!last) {
-          z_next = rc.dg.z(k + 1);
+          z_next = sd.z(rc.dg, k + 1);
           float pn[3];
           rc.point(z_next, pn);
           footprint(g, pn, fp_cur);
@@ -843,12 +859,20 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
       }
     }
     };   // march
-    if constexpr (VOXE_TILE_AXIS_TEMPLATE && !DET && ((CM == 4 && MODE == 0) || (VOXE_TILE_AXIS_TEMPLATE_SH && MODE == 2))) {
-      if (w.m == 0) march(std::integral_constant<int, 0>{});
-      else if (w.m == 1) march(std::integral_constant<int, 1>{});
-      else march(std::integral_constant<int, 2>{});
+    auto march_axis = [&](auto strata_tag) {
+      if constexpr (VOXE_TILE_AXIS_TEMPLATE && !DET && ((CM == 4 && MODE == 0) || (VOXE_TILE_AXIS_TEMPLATE_SH && MODE == 2))) {
+        if (w.m == 0) march(std::integral_constant<int, 0>{}, strata_tag);
+        else if (w.m == 1) march(std::integral_constant<int, 1>{}, strata_tag);
+        else march(std::integral_constant<int, 2>{}, strata_tag);
+      } else {
+        march(std::integral_constant<int, -1>{}, strata_tag);
+      }
+    };
+    if constexpr (kStrata) {
+      if (use_strata) march_axis(std::true_type{});
+      else march_axis(std::false_type{});
     } else {
-      march(std::integral_constant<int, -1>{});
+      march_axis(std::false_type{});
     }
   };
   // lanes and reference lane of part q under the chosen split
@@ -907,11 +931,12 @@ constexpr int kOrgTable = VOXE_FWD_TILE_TABLE;  // layers tabulated per block: k
 // The march of one (tile, depth segment) with the march axis M as a COMPILE-TIME constant (r03): the corner -> (layer, lateral
 // offset) mapping, the texel strides and the picks of the cell's (m, u, v) indices fold into immediates.  r02's kernel took
 // the axes from registers: 360 VALU instructions per wave-sample against 170 of the ray-ordered forward, and was VALU bound.
-template <int M>
+template <int M, bool STRATA>
 __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg& c, const float* __restrict__ packed,
                                                  RayCtx<3, 1, 1>& rc, const int lane, const bool has, const int k_lo,
                                                  const int k_hi, const int kmin, const int kmax, const int ref,
-                                                 float4* __restrict__ tex, int4* __restrict__ org, float (&csum)[3],
+                                                 float4* __restrict__ tex, int4* __restrict__ org,
+                                                 const SegDepth<STRATA> sd, float (&csum)[3],
                                                  float& asum, float& dsum, float& T) {
   constexpr int COUT = 3;
   constexpr int U = (M == 0) ? 1 : 0, V = (M == 2) ? 1 : 2;   // lateral axes (v = z whenever m != z: coalesced layer reads)
@@ -944,7 +969,7 @@ __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg&
   for (int a = 0; a < 3; ++a) { fp_cur.i0[a] = 0; fp_cur.w[a][0] = fp_cur.w[a][1] = 0.0f; }
   int first_key = INT_MAX;
   if (has) {
-    z_cur = rc.dg.z(k_lo);
+    z_cur = sd.z(rc.dg, k_lo);
     float p[3];
     rc.point(z_cur, p);
     footprint(g, p, fp_cur);
@@ -992,7 +1017,7 @@ __device__ __forceinline__ void fwd_window_march(const DevGrid& g, const DevCfg&
       const bool last = (k == c.S - 1);
       float z_next = z;
       if (!last) {
-        z_next = rc.dg.z(k + 1);
+        z_next = sd.z(rc.dg, k + 1);
         float pn[3];
         rc.point(z_next, pn);
         footprint(g, pn, fp_cur);
@@ -1155,13 +1180,19 @@ __global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(D
       if (lat <= fit_lat && alongm <= fit_m && adv <= max_adv && (mm != 2 || zdom < 0.0f)) m = mm;   // (zdom < 0: experiment, march along z too)
     }
   }
-  if (m < 0) {
+  // r04: the strata of this depth segment, tabulated once per block (SegDepth; not with per-ray AABB bounds)
+  __shared__ float2 strat[64];
+  const bool use_strata = VOXE_TILE_STRATA && !c.aabb_clip && (ke + 1 - ks) < 64;
+  if (use_strata && lane <= ke + 1 - ks && ks + lane < c.S) strat[lane] = depth_stratum(rc.dg, ks + lane);
+  __syncthreads();
+  auto march_rays = [&](auto strata_tag) {   // ray by ray (the loop of render_fwd_seg_kernel)
+    const SegDepth<decltype(strata_tag)::value> sd{strat, ks};
     if (has) {
-      float z_next = rc.dg.z(k_lo);
+      float z_next = sd.z(rc.dg, k_lo);
       for (int k = k_lo; k <= k_hi; ++k) {
         const float z = z_next;
         const bool last = (k == c.S - 1);
-        if (!last) z_next = rc.dg.z(k + 1);
+        if (!last) z_next = sd.z(rc.dg, k + 1);
         float p[3];
         rc.point(z, p);
         Footprint fp;
@@ -1185,9 +1216,17 @@ __global__ __launch_bounds__(64, VOXE_FWD_TILE_LB) void render_fwd_tile_kernel(D
         dsum = fmaf(z, wgt, dsum);
       }
     }
-  } else if (m == 0) fwd_window_march<0>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, csum, asum, dsum, T);
-  else if (m == 1) fwd_window_march<1>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, csum, asum, dsum, T);
-  else fwd_window_march<2>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, csum, asum, dsum, T);
+  };
+  auto march_tile = [&](auto strata_tag) {
+    constexpr bool ST = decltype(strata_tag)::value;
+    const SegDepth<ST> sd{strat, ks};
+    if (m < 0) march_rays(strata_tag);
+    else if (m == 0) fwd_window_march<0, ST>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, sd, csum, asum, dsum, T);
+    else if (m == 1) fwd_window_march<1, ST>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, sd, csum, asum, dsum, T);
+    else fwd_window_march<2, ST>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ref, tex, org, sd, csum, asum, dsum, T);
+  };
+  if (use_strata) march_tile(std::true_type{});
+  else march_tile(std::false_type{});
   if (!alive) return;
   const long long base = (long long)seg * NC;
   segbuf[(base + 0) * c.R + r] = T;
