@@ -533,11 +533,12 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   float* rays_o = (float*)(sc + l.rays_o);
   float* rays_d = (float*)(sc + l.rays_d);
   float* target = (float*)(sc + l.target);
-  int st = voxe_random_subset((int64_t)rs->K * rs->H * rs->W, B, cfg->seed, cfg->rng_offset, subset, stream);
-  if (st) return st;
-  st = voxe_cast_rays_indexed(rs->H, rs->W, rs->focal, rs->poses, rs->K, subset, B, rays_o, rays_d, stream);
-  if (st) return st;
-  launch_gather_pixels(rs->images, (const long long*)rs->image_rows, (const long long*)subset, B, rs->H * rs->W, rs->num_images, target, s);
+  // batch assembly: keyed subset of the K * H * W pixels -> rays + target pixels (one launch; same streams as voxe_random_subset,
+  // voxe_cast_rays_indexed and the pixel gather)
+  if ((int64_t)rs->K * rs->H * rs->W > (1ll << 31)) return VOXE_ERR_BAD_SHAPE;
+  int st = VOXE_OK;
+  launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
+                     (const long long*)rs->image_rows, rs->num_images, (long long*)subset, rays_o, rays_d, target, s);
   // SH-0 grids: the diffuse render is the specular kernel with another jitter stream -- both renders as ONE launch of 2 B
   // rays on the space-binned route (one binning pass, one forward, one backward; no second packed grid).  32 768-ray
   // batches leave the chip half empty and the binning / scan / fold passes are launch-latency sized: r04, 160^3,
@@ -556,8 +557,7 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
       float* d_colour = (float*)(sc + l.d_colour2);
       st = voxe_render_fwd(grid, &pc, rays_o, rays_d, 2 * B, nullptr, colour, depth, acc, nullptr, workspace, workspace_bytes, stream);
       if (st) return st;
-      for (int i = 0; i < 2; ++i)
-        launch_l1_loss_grad(colour + 3 * B * i, target, 3 * B, d_colour + 3 * B * i, rs->losses + 2 * i, sc + l.partial, s);
+      launch_l1_loss_grad_n(colour, target, 3 * B, 2, d_colour, rs->losses, sc + l.partial, s);   // both renders, one launch pair
       pc.ray_state_valid = 1;
       pc.reuse_packed_grid = 1;
       int32_t layout = VOXE_GRAD_ANY;

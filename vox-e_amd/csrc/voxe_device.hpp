@@ -227,6 +227,38 @@ struct SegDepth {
   }
 };
 
+// The same table for kernels whose blocks march many rays (space-binned route): strata of samples k0 .. k0 + n - 1 built by all
+// threads of the block from the launch's (near, far); `on` is block-uniform (false: per-ray AABB bounds, or S beyond the table).
+struct BlockStrata {
+  const float2* tab;
+  int k0;
+  bool on;
+  __device__ __forceinline__ float z(DepthGen& dg, int k) const {
+    if (on) {
+      const float2 t = tab[k - k0];
+      if (!dg.perturb) return t.x;
+      return t.x + t.y * dg.uniform(k);
+    }
+    return dg.z(k);
+  }
+};
+__device__ __forceinline__ BlockStrata build_block_strata(float2* tab, int capacity, const DevCfg& c, int k0, int n, int tid,
+                                                          int nthreads) {
+  BlockStrata b{tab, k0, !c.aabb_clip && n <= capacity};
+  if (b.on) {
+    DepthGen dg;   // (what RayCtx::init / SegRay::init set without AABB clipping)
+    dg.near = c.near; dg.far = c.far;
+    dg.lindisp = c.lindisp != 0;
+    dg.S = c.S; dg.half = c.S >> 1;
+    dg.step = 1.0f / (float)(c.S - 1);
+    dg.perturb = c.perturb != 0;
+    dg.jit = nullptr; dg.base = 0u; dg.kc = INT_MIN; dg.zm = dg.z0 = dg.zp = 0.0f;
+    for (int i = tid; i < n; i += nthreads)
+      if (k0 + i < c.S) tab[i] = depth_stratum(dg, k0 + i);
+  }
+  return b;   // (the caller's next __syncthreads() publishes the table)
+}
+
 // _ray_aabb_intersection (sample.py:71-184): per-ray (near, far)
 __device__ __forceinline__ void ray_aabb_bounds(const DevGrid& g, const float (&o)[3],
                                                 const float (&d)[3], float& near, float& far) {

@@ -40,13 +40,8 @@ void launch_cast_rays(int H, int W, float focal, const float* rot, const float* 
   cast_rays_kernel<<<(int)((n + 255) / 256), 256, 0, st>>>(H, W, focal, p, rays_o, rays_d);
 }
 
-__global__ __launch_bounds__(256) void cast_rays_indexed_kernel(int H, int W, float focal, int K,
-                                                                const float* __restrict__ poses,
-                                                                const long long* __restrict__ flat_index, long long B,
-                                                                float* __restrict__ rays_o, float* __restrict__ rays_d) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  const long long f = flat_index[i];
+__device__ __forceinline__ void cast_indexed_ray(int H, int W, float focal, int K, const float* __restrict__ poses, long long f,
+                                                 long long i, float* __restrict__ rays_o, float* __restrict__ rays_d) {
   const long long per = (long long)H * W;
   long long cam = f / per;
   const long long rem = f - cam * per;
@@ -63,6 +58,14 @@ __global__ __launch_bounds__(256) void cast_rays_indexed_kernel(int H, int W, fl
     rays_o[3 * i + r] = pose[4 * r + 3];
   }
 }
+__global__ __launch_bounds__(256) void cast_rays_indexed_kernel(int H, int W, float focal, int K,
+                                                                const float* __restrict__ poses,
+                                                                const long long* __restrict__ flat_index, long long B,
+                                                                float* __restrict__ rays_o, float* __restrict__ rays_d) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  cast_indexed_ray(H, W, focal, K, poses, flat_index[i], i, rays_o, rays_d);
+}
 
 void launch_cast_rays_indexed(int H, int W, float focal, const float* poses, int K, const long long* flat_index,
                               long long B, float* rays_o, float* rays_d, hipStream_t st) {
@@ -76,13 +79,17 @@ __global__ __launch_bounds__(256) void random_subset_kernel(uint32_t n, long lon
   if (i < count) out[i] = (long long)feistel_permute((uint32_t)i, n, half, key0, key1);
 }
 
-void launch_random_subset(long long n, long long count, unsigned long long seed, unsigned long long rng_offset,
-                          long long* out, hipStream_t st) {
+struct SubsetKeys { int half; uint32_t key0, key1; };
+static SubsetKeys subset_keys(long long n, unsigned long long seed, unsigned long long rng_offset) {
   int bits = 2;
   while ((1ull << bits) < (unsigned long long)n) bits += 2;
-  const uint32_t key0 = mix32((uint32_t)seed ^ ((uint32_t)rng_offset * 0x9E3779B1u));
-  const uint32_t key1 = mix32((uint32_t)(seed >> 32) ^ (uint32_t)(rng_offset >> 32) ^ 0x7F4A7C15u);
-  random_subset_kernel<<<(int)((count + 255) / 256), 256, 0, st>>>((uint32_t)n, count, bits / 2, key0, key1, out);
+  return {bits / 2, mix32((uint32_t)seed ^ ((uint32_t)rng_offset * 0x9E3779B1u)),
+          mix32((uint32_t)(seed >> 32) ^ (uint32_t)(rng_offset >> 32) ^ 0x7F4A7C15u)};
+}
+void launch_random_subset(long long n, long long count, unsigned long long seed, unsigned long long rng_offset,
+                          long long* out, hipStream_t st) {
+  const SubsetKeys k = subset_keys(n, seed, rng_offset);
+  random_subset_kernel<<<(int)((count + 255) / 256), 256, 0, st>>>((uint32_t)n, count, k.half, k.key0, k.key1, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -466,13 +473,9 @@ void launch_disparity_bwd(const float* depth, const float* acc, const float* d_d
 // batch gathered straight from the image stack, and torch.nn.functional.l1_loss (+ its gradient, + the MSE the trainer
 // logs as PSNR) in one pass.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_pixels_kernel(const float* __restrict__ images, const long long* __restrict__ image_rows,
-                                                            const long long* __restrict__ subset, long long B, int per,
-                                                            int num_images, float* __restrict__ out) {
-  // images [N, 3, H, W]; subset: flat (camera, y, x) indices over the K cached cameras; out [B, 3]
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B) return;
-  const long long f = subset[i];
+__device__ __forceinline__ void gather_pixel(const float* __restrict__ images, const long long* __restrict__ image_rows,
+                                             long long f, long long i, int per, int num_images, float* __restrict__ out) {
+  // images [N, 3, H, W]; f: flat (camera, y, x) index over the K cached cameras; out [B, 3]
   const long long cam = f / per, rem = f - cam * per;
   const long long row = image_rows ? image_rows[cam] : cam;
   if (row < 0 || row >= num_images) {   // a caller's bug: never read outside `images`; the NaN target shows up in the loss
@@ -484,11 +487,37 @@ __global__ __launch_bounds__(256) void gather_pixels_kernel(const float* __restr
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) out[i * 3 + ch] = src[(long long)ch * per];
 }
+__global__ __launch_bounds__(256) void gather_pixels_kernel(const float* __restrict__ images, const long long* __restrict__ image_rows,
+                                                            const long long* __restrict__ subset, long long B, int per,
+                                                            int num_images, float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  gather_pixel(images, image_rows, subset[i], i, per, num_images, out);
+}
+// batch assembly of a reconstruction iteration in ONE launch (r04): entry i of the keyed permutation (random_subset_kernel) ->
+// its ray (cast_rays_indexed_kernel) and its target pixel (gather_pixels_kernel); three launches of ~5 us each before
+__global__ __launch_bounds__(256) void recon_batch_kernel(uint32_t n, long long B, int half, uint32_t key0, uint32_t key1, int H,
+                                                          int W, float focal, int K, const float* __restrict__ poses,
+                                                          const float* __restrict__ images,
+                                                          const long long* __restrict__ image_rows, int num_images,
+                                                          long long* __restrict__ subset, float* __restrict__ rays_o,
+                                                          float* __restrict__ rays_d, float* __restrict__ target) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const long long f = (long long)feistel_permute((uint32_t)i, n, half, key0, key1);
+  subset[i] = f;
+  cast_indexed_ray(H, W, focal, K, poses, f, i, rays_o, rays_d);
+  gather_pixel(images, image_rows, f, i, H * W, num_images, target);
+}
 
 // mean |a - b| over n elements and its gradient w.r.t. a (sign(a - b) / n: torch's l1_loss backward, sign(0) = 0), plus
 // the mean squared difference; per-block partial sums in double, folded in a fixed order by l1_finalize_kernel
 __global__ __launch_bounds__(256) void l1_loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
                                                            float inv_n, float* __restrict__ d_a, double* __restrict__ partial) {
+  // blockIdx.y: render (the renders' a / d_a lie back to back, n elements each, and share the target b)
+  a += (long long)blockIdx.y * n;
+  d_a += (long long)blockIdx.y * n;
+  partial += (long long)blockIdx.y * (kRedBlocks * 2 + 8);
   double s[2] = {0, 0};
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -501,6 +530,8 @@ __global__ __launch_bounds__(256) void l1_loss_grad_kernel(const float* __restri
 }
 __global__ __launch_bounds__(256) void l1_finalize_kernel(const double* __restrict__ partial, int nblocks, double n,
                                                           float* __restrict__ out2) {
+  partial += (long long)blockIdx.x * (kRedBlocks * 2 + 8);   // blockIdx.x: render
+  out2 += 2 * blockIdx.x;
   double s[2] = {0, 0};
   for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s[0] += partial[2 * i]; s[1] += partial[2 * i + 1]; }
   __shared__ double tot[2];
@@ -514,12 +545,30 @@ void launch_gather_pixels(const float* images, const long long* image_rows, cons
   if (B <= 0) return;
   gather_pixels_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>(images, image_rows, subset, B, per, num_images, out);
 }
-size_t l1_scratch_bytes() { return sizeof(double) * (kRedBlocks * 2 + 8); }
+void launch_recon_batch(long long B, unsigned long long seed, unsigned long long rng_offset, int H, int W, float focal, int K,
+                        const float* poses, const float* images, const long long* image_rows, int num_images, long long* subset,
+                        float* rays_o, float* rays_d, float* target, hipStream_t st) {
+  if (B <= 0) return;
+  const long long n = (long long)K * H * W;
+  const SubsetKeys k = subset_keys(n, seed, rng_offset);
+  recon_batch_kernel<<<(int)((B + 255) / 256), 256, 0, st>>>((uint32_t)n, B, k.half, k.key0, k.key1, H, W, focal, K, poses, images,
+                                                             image_rows, num_images, subset, rays_o, rays_d, target);
+}
+size_t l1_scratch_bytes() { return 2 * sizeof(double) * (kRedBlocks * 2 + 8); }   // (two renders per launch: launch_l1_loss_grad2)
 void launch_l1_loss_grad(const float* a, const float* b, long long n, float* d_a, float* out2, void* scratch, hipStream_t st) {
   double* partial = (double*)scratch;
   const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
   l1_loss_grad_kernel<<<nb, 256, 0, st>>>(a, b, n, (float)(1.0 / (double)n), d_a, partial);
   l1_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, (double)n, out2);
+}
+
+// `renders` renders of n elements each, back to back in a / d_a, against the same target; out2[2 * r] = (L1, MSE) of render r
+void launch_l1_loss_grad_n(const float* a, const float* b, long long n, int renders, float* d_a, float* out2, void* scratch,
+                           hipStream_t st) {
+  double* partial = (double*)scratch;
+  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  l1_loss_grad_kernel<<<dim3((unsigned)nb, (unsigned)renders), 256, 0, st>>>(a, b, n, (float)(1.0 / (double)n), d_a, partial);
+  l1_finalize_kernel<<<renders, 256, 0, st>>>(partial, nb, (double)n, out2);
 }
 
 // ------------------------------------------------------------------------------------------------

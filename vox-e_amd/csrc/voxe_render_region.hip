@@ -91,6 +91,9 @@ constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, 
 #ifndef VOXE_REGION_STAGE_BWD_NCU
 #define VOXE_REGION_STAGE_BWD_NCU 4
 #endif
+#ifndef VOXE_REGION_STRATA
+#define VOXE_REGION_STRATA 512      // depth strata tabulated per block (BlockStrata, voxe_device.hpp) for S up to this; 0: off
+#endif
 #ifndef VOXE_REGION_SH_WC
 #define VOXE_REGION_SH_WC 7        // gradient channels per deposit pass of a view-dependent grid (window: WC x 5.9 KB of LDS).
                                    // Swept (32 400 random rays, backward ms, SH-1 / SH-2): 4 -> 1.21 / 2.56, 7 -> 1.10 / 2.48 (13 = 2 / 4
@@ -187,6 +190,11 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
   const int nseg = num_segments(c.S, c.seg_len);
   const int nrb = gridDim.x / nseg;
   const int seg = blockIdx.x / nrb;
+  // depth strata of this block's segment, tabulated once (before any lane leaves)
+  __shared__ float2 strat[64];
+  const int ks_blk = seg * c.seg_len;
+  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA ? 64 : 0, c, ks_blk, min(c.S, ks_blk + c.seg_len) - ks_blk, lane, 64);
+  __syncthreads();
   // image-ordered launches (sparse / multi-view images): a wave is an 8x8 pixel tile, so its lanes cross the same regions
   // at about the same samples and can share their counting atomics (below); unordered rays: 64 consecutive rays
   const bool coherent = c.image_width > 0;
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     ++nslots;
   };
   for (int k = k_lo; k <= k_hi; ++k) {
-    const float z = rc.dg.z(k);
+    const float z = bst.z(rc.dg, k);
     float p[3];
     rc.point(z, p);
     Footprint fp;
@@ -470,6 +478,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
     if constexpr (NCU == 1) load_window<COUT, NCM>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
     else load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
   }
+  __shared__ float2 strat[VOXE_REGION_STRATA ? VOXE_REGION_STRATA : 1];
+  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA, c, 0, c.S, tid, VOXE_REGION_BLOCK);
   __syncthreads();
   const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
   const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
@@ -483,11 +493,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
     ray_basis<NCU>(ray.d, ray.dnorm, basis);
     float csum[3] = {0.0f, 0.0f, 0.0f};
     float asum = 0.0f, dsum = 0.0f, T = 1.0f;
-    float z_next = ray.dg.z(k0);
+    float z_next = bst.z(ray.dg, k0);
     for (int k = k0; k <= k1; ++k) {
       const float z = z_next;
       const bool last = (k == c.S - 1);
-      if (!last) z_next = ray.dg.z(k + 1);
+      if (!last) z_next = bst.z(ray.dg, k + 1);
       float p[3];
       ray.point(z, p);
       Footprint fp;
@@ -666,6 +676,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
   // lane constants of the parity-class deposit
   const int lane = tid & 63;
   const int hx = (lane >> 1) & 1, hy = (lane >> 2) & 1, hz = (lane >> 3) & 1, crot = (lane & 1) | ((lane >> 3) & 2);
+  __shared__ float2 strat[VOXE_REGION_STRATA ? VOXE_REGION_STRATA : 1];
+  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA, c, 0, c.S, tid, VOXE_REGION_BLOCK);
   __syncthreads();
   const float basis0[1] = {kC0};
   const bool white = c.white && !c.attn;
@@ -697,11 +709,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
     suffix0 *= T;
     float run = 0.0f;   // sum of dL/dw_i w_i over the samples of this segment up to and including the current one
 
-    float z_next = ray.dg.z(k0);
+    float z_next = bst.z(ray.dg, k0);
     for (int k = k0; k <= k1; ++k) {
       const float z = z_next;
       const bool last = (k == c.S - 1);
-      if (!last) z_next = ray.dg.z(k + 1);
+      if (!last) z_next = bst.z(ray.dg, k + 1);
       float p[3];
       ray.point(z, p);
       Footprint fp;
@@ -845,6 +857,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
   const bool from_global = rb.generic || stage == 0;   // (see region_fwd_kernel)
   if (!from_global) load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
+  __shared__ float2 strat[VOXE_REGION_STRATA ? VOXE_REGION_STRATA : 1];
+  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA, c, 0, c.S, tid, VOXE_REGION_BLOCK);
   __syncthreads();
   const bool white = c.white && !c.attn;
   const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
@@ -869,11 +883,11 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
     if (white) suffix0 -= gsum * sb.x;
     suffix0 *= T;
     float run = 0.0f;
-    float z_next = ray.dg.z(k0);
+    float z_next = bst.z(ray.dg, k0);
     for (int k = k0; k <= k1; ++k) {
       const float z = z_next;
       const bool last = (k == c.S - 1);
-      if (!last) z_next = ray.dg.z(k + 1);
+      if (!last) z_next = bst.z(ray.dg, k + 1);
       float p[3];
       ray.point(z, p);
       Footprint fp;
@@ -945,6 +959,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_dep_kernel(
   }
   if (!rb.generic)
     for (int i = tid; i < WC * kRPlane; i += VOXE_REGION_BLOCK) win[i] = 0.0;
+  __shared__ float2 strat[VOXE_REGION_STRATA ? VOXE_REGION_STRATA : 1];
+  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA, c, 0, c.S, tid, VOXE_REGION_BLOCK);
   __syncthreads();
   const unsigned i_begin = rb.generic ? (blockIdx.x - (unsigned)nreg) * VOXE_REGION_BLOCK + tid : tid;
   const unsigned i_step = rb.generic ? kGenericBlocks * VOXE_REGION_BLOCK : VOXE_REGION_BLOCK;
@@ -965,7 +981,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_dep_kernel(
       mult[sidx] = chsel[sidx] < 0 ? 0.0f : (chsel[sidx] == COUT ? 1.0f : b);
     }
     for (int k = k0; k <= k1; ++k) {
-      const float z = ray.dg.z(k);
+      const float z = bst.z(ray.dg, k);
       float p[3];
       ray.point(z, p);
       Footprint fp;
