@@ -553,3 +553,22 @@ def test_wide_texel_conversions_whole_chunks_tail_and_accumulate(deg, dims):
                         (0, 0), accumulate=True)
     np.testing.assert_allclose(gh.n(d_d) - 0.25, gd, rtol=0, atol=2e-6 * max(1.0, float(np.abs(gd).max())))
     np.testing.assert_allclose(gh.n(d_f) + 0.5, gf, rtol=0, atol=2e-6 * max(1.0, float(np.abs(gf).max())))
+
+
+def test_region_route_beyond_the_strata_table(disp):
+    """S = 600 samples per ray: more than the space-binned kernels tabulate per block (VOXE_REGION_STRATA = 512), so they take
+    DepthGen's per-sample path -- same results as the oracle, jitter on"""
+    _region_env(disp)
+    rng = np.random.default_rng(5)
+    dims = (24, 20, 28)
+    grid = vo.Grid(rng.uniform(-1, 1, (*dims, 1)).astype(np.float32), rng.uniform(-1, 1, (*dims, 3)).astype(np.float32),
+                   [(-1.5, 1.5), (-1.2, 1.3), (-1.5, 1.4)], 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    o, d = _rays(36, 11)
+    sel = rng.permutation(o.shape[0])[:700]
+    o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
+    cfg = make_render_cfg(600, NEAR, FAR, white_bkgd=True, perturb=True, seed=3, rng_offset=4)
+    gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+    _check_forward(gh.hip_forward(grid, cfg, o, d, rng=(3, 4)), vo.render_fwd(grid, cfg, o, d))
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(3, 4))
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
