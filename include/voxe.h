@@ -144,7 +144,11 @@ typedef struct VoxeRenderCfg {
                                  states (transmittance + partial sums every VOXE_SEGMENT_SAMPLES
                                  samples) written by voxe_render_fwd for EXACTLY these rays / cfg /
                                  jitter, so the depth-segmented backward starts from them.
-                                 0: the backward first re-marches the rays to rebuild them.       */
+                                 0: the backward first re-marches the rays to rebuild them.
+                                 voxe_render_fwd reads it too: -1 = no backward of these rays will follow
+                                 (inference): the forward skips what only that backward would read (the per-sample
+                                 values of view-dependent image-ordered renders, r04); a backward after such a
+                                 forward must pass 0.                                             */
   const VoxeDispatch* dispatch; /* HOST pointer, NULL = the shipped dispatch; read during the call only (ABI v7)      */
 } VoxeRenderCfg;
 

@@ -572,3 +572,39 @@ def test_region_route_beyond_the_strata_table(disp):
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, rng=(3, 4))
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
+
+
+def test_sh_source_pass_reads_the_forwards_sample_values_or_regathers():
+    """view-dependent grids, image order (r04): the forward leaves (rad, v) of every sample for the two-phase backward's source
+    pass.  Three ways to the same gradient: forward + backward (values from the forward), an inference forward
+    (keep_for_backward=False: nothing kept) followed by a backward (which re-marches), and a backward alone"""
+    from voxe_hip import ops
+    from voxe_hip.dispatch import TILE_ALWAYS
+    rng = np.random.default_rng(21)
+    dims = (40, 36, 44)
+    dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
+    feat = rng.uniform(-1, 1, (*dims, 27)).astype(np.float32)
+    grid = vo.Grid(dens, feat, [(-1.5, 1.5)] * 3, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    hw = 48
+    o, d = _rays(hw, 17)
+    cfg = make_render_cfg(96, NEAR, FAR, white_bkgd=True, sh_degree=2, perturb=True, seed=8, rng_offset=2)
+    gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    spec, params = gh.spec_of(grid), gh.params_of(cfg, image_width=hw, dispatch=TILE_ALWAYS)
+    td, tf, to, tdir, tg = gh.t(dens), gh.t(feat), gh.t(o), gh.t(d), gh.t(gc)
+    outs = [torch.empty((o.shape[0], n), device="cuda") for n in (3, 1, 1, 1)]
+    got = []
+    for mode in ("forward_then_backward", "inference_forward_then_backward", "backward_alone"):
+        ws = ops.Workspace()
+        if mode != "backward_alone":
+            ops.render_fwd_into(spec, params, td, tf, to, tdir, None, *outs, ws, (8, 2),
+                                keep_for_backward=(mode == "forward_then_backward"))
+        else:
+            ws.invalidate()
+        assert (ws.state_key is not None) == (mode == "forward_then_backward")
+        d_d, d_f = torch.zeros_like(td), torch.zeros_like(tf)
+        ops.render_bwd_into(spec, params, td, tf, to, tdir, None, outs[0], outs[1], outs[2], tg, None, None, d_d, d_f, ws, (8, 2))
+        got.append((gh.n(d_d), gh.n(d_f)))
+        assert rel_l2(got[-1][0], rd) < GRAD_TOL and rel_l2(got[-1][1], rf) < GRAD_TOL, (mode, rel_l2(got[-1][0], rd), rel_l2(got[-1][1], rf))
+    for a, b in zip(got[0], got[1]):
+        assert rel_l2(a, b) < 2e-6

@@ -112,7 +112,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, seg_off, src_off, det_off, region_off, fwd_total, total, total_with_src;
+  size_t packed_off, grad_off, state_off, seg_off, src_off, fwdval_off, det_off, region_off, fwd_total, total, total_with_src;
   bool region;   // the space-binned backward applies to (grid, cfg, R): its scratch is part of the workspace
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
@@ -136,8 +136,12 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   // per-sample gradient sources of the two-phase backward of view-dependent grids (optional: without it the channel
   // groups re-march the segment)
   l.src_off = l.total;
-  l.total_with_src = l.total + (c ? align_up(tile_src_bytes(R, c->image_width, c->image_height, c->num_samples, c->sh_degree, c->render_diffuse,
-                                                           g->feature_kind == VOXE_FEAT_ATTN), 256) : 0);
+  const size_t srcb = c ? align_up(tile_src_bytes(R, c->image_width, c->image_height, c->num_samples, c->sh_degree, c->render_diffuse,
+                                                  g->feature_kind == VOXE_FEAT_ATTN), 256) : 0;
+  // ... and, behind the sources, the forward's per-sample (rad, v) in the same layout (r04: the source pass reads them instead of
+  // gathering the wide texels again)
+  l.fwdval_off = l.total + srcb;
+  l.total_with_src = l.total + 2 * srcb;
   // deterministic mode: the fixed-point gradient and its scales behind everything else
   l.det_off = l.total_with_src;
   if (c && c->deterministic) l.total_with_src += det_bytes((long long)nvox, g->F + 1);
@@ -302,6 +306,8 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   if ((tiled || packed_bwd) && workspace_bytes >= l.total) state = (float*)((char*)workspace + l.state_off);
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
+  if (cfg->ray_state_valid >= 0 && tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp))
+    a.sample_fwd = (float*)((char*)workspace + l.fwdval_off);   // (what render_bwd_common's two-phase backward will read)
   if (l.region && workspace_bytes >= l.total_with_src) {
     // space-binned path (unordered / sparse rays): forward through the region kernels; the segment tables and per-segment
     // states stay in the workspace for the backward of the same call (cfg->ray_state_valid)
@@ -341,8 +347,13 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp);
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
-    if (tiled && l.total_with_src > l.total && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp))
+    const bool two_phase = tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp);
+    if (two_phase) {
       a.sample_src = (float*)((char*)workspace + l.src_off);
+      // the forward of these rays (voxe_render_fwd with this workspace, or the re-march below) wrote its per-sample values when it
+      // ran the depth-segmented kernel: launch_fwd_t's condition
+      if (num_segments(cfg->num_samples, dc.seg_len) > 1) a.sample_fwd = (const float*)((char*)workspace + l.fwdval_off);
+    }
     if (cfg->deterministic) {
       if (!det_bwd_supported(dc, cfg->sh_degree, cfg->render_diffuse)) return VOXE_ERR_UNSUPPORTED;
       if (workspace_bytes < l.total_with_src) return VOXE_ERR_WORKSPACE;
@@ -352,16 +363,17 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     }
     const bool det = cfg->deterministic != 0;
     const bool region = l.region && !det && workspace_bytes >= l.total_with_src;
-    if (region && !cfg->ray_state_valid) {
+    if (region && cfg->ray_state_valid <= 0) {
       // the caller's workspace does not hold this call's segment tables / states: rebuild them (no outputs)
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       launch_fwd_region(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, (char*)workspace + l.region_off, s);
-    } else if ((tiled || packed_bwd || det) && !cfg->ray_state_valid) {
+    } else if ((tiled || packed_bwd || det) && cfg->ray_state_valid <= 0) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
                 (float*)((char*)workspace + l.seg_off)};
+      if (two_phase) f.sample_fwd = (float*)((char*)workspace + l.fwdval_off);
       launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, s);
     }
     PhaseTimer t(PH_BWD, s);
@@ -545,6 +557,7 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   // 1.15 -> see profiles/r04_recon_bench.txt.  Needs `workspace` sized for 2 B rays (voxe_workspace_bytes(grid, cfg, 2 B)).
   if (nrender == 2 && cfg->sh_degree == 0 && VOXE_RECON_PAIRED) {
     VoxeRenderCfg pc = *cfg;
+    pc.ray_state_valid = 0;
     pc.rng_offset = cfg->rng_offset + 1;
     pc.render_diffuse = 0;
     pc.linear_grad = 1;
@@ -577,6 +590,7 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   size_t wsb[2] = {workspace_bytes, workspace2_bytes};
   for (int i = 0; i < nrender; ++i) {
     rc[i].rng_offset = cfg->rng_offset + 1 + (uint64_t)i;
+    rc[i].ray_state_valid = 0;
     rc[i].render_diffuse = i == 1 ? 1 : cfg->render_diffuse;
     rc[i].linear_grad = 1;                         // both renders write ONE gradient layout, whatever kernel runs
     if (i == 1) rc[i].reuse_packed_grid = 0;       // the second workspace still holds the previous iteration's grid

@@ -12,6 +12,9 @@ struct FwdArgs {
   float *colour, *depth, *acc, *disparity;
   float* ray_state;  // per-ray depth-segment states (nullable): see ray_state_index()
   float* segbuf;     // per-ray per-segment partial results of the segmented forward (nullable)
+  // view-dependent grids, image order (r04): (rad_0..2, v) of every sample in the layout of the two-phase tile backward's source
+  // buffer (tile, depth segment, sample, lane) -- its source pass then needs no gather (nullable; tile_src_bytes())
+  float* sample_fwd = nullptr;
 };
 struct BwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc;
@@ -19,6 +22,7 @@ struct BwdArgs {
   bool want_d, want_f;
   const float* ray_state;  // states written by the forward for the same rays (tile backward only)
   float* sample_src = nullptr;   // scratch of the two-phase tile backward of view-dependent grids (tile_src_bytes())
+  const float* sample_fwd = nullptr;   // the forward's per-sample (rad, v) for the SAME rays (FwdArgs::sample_fwd), or null
   // deterministic mode (VoxeRenderCfg::deterministic): 64-bit fixed-point gradient [voxels * C] + 4 floats
   // (max |contribution| of features / density as float bits, then their power-of-two scales); see det_bytes()
   unsigned long long* gdet = nullptr;

@@ -649,7 +649,8 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
                                                              const float* __restrict__ rays_o,
                                                              const float* __restrict__ rays_d,
                                                              const float* __restrict__ jitter,
-                                                             float* __restrict__ segbuf) {
+                                                             float* __restrict__ segbuf,
+                                                             float4* __restrict__ sample_fwd) {
   constexpr int NC = COUT + 3;
   const int nseg = num_segments(c.S, c.seg_len);
   // one thread = `fseg` consecutive depth segments of one ray (fseg = 1: finest split, used for small images)
@@ -661,6 +662,7 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
   const int nrb = gridDim.x / ncoarse;  // ray blocks (a multiple of 8)
   const int cseg = blockIdx.x / nrb, rb = blockIdx.x - cseg * nrb;
   long long r;
+  long long tile_lane = -1;   // (tile * nseg) * seg_len * 64 + lane: base of this lane's slots in sample_fwd (image order only)
   {  // one wave = one 8x8 pixel tile (image order) or 64 consecutive rays
     const int lane = threadIdx.x;
     if (c.image_width > 0) {
@@ -668,6 +670,7 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
       const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
       const int t = logical_tile_of(c, rb, nrb, ntx, nty);
       if (t < 0) return;
+      tile_lane = (long long)t * nseg * c.seg_len * 64 + lane;
       const int ty = t / ntx, tx = t - ty * ntx;
       if (!tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r)) return;
     } else {
@@ -705,6 +708,11 @@ __global__ __launch_bounds__(64, VOXE_FWD_LB) void render_fwd_seg_kernel(DevGrid
         make_cell_fast(g, fp, cell);
         float v, rad[COUT];
         gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
+        if constexpr (COUT == 3 && NCU > 1) {
+          // slot of (tile, segment, sample k, lane) -- render_bwd_tile_kernel's src_base + k * 64
+          if (sample_fwd && tile_lane >= 0)
+            sample_fwd[tile_lane + ((long long)seg * c.seg_len + (k - ks)) * 64] = make_float4(rad[0], rad[1], rad[2], v);
+        }
         const float sigma = post_activate(g.post_act, v);
         const float dl = last ? kInfinity : (z_next - z);
         const float delta = dl * rc.dnorm;
@@ -1108,7 +1116,7 @@ static void launch_fwd_t(const DevGrid& g, const HostCfg& c, const FwdArgs& a, h
       launch_fwd_tile(g, c, a, st);      // texels of a tile staged in LDS (voxe_render_tile.hip)
     else
       render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
-          g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf);
+          g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf, reinterpret_cast<float4*>(a.sample_fwd));
     render_fwd_combine_kernel<COUT><<<(int)((c.R + 255) / 256), 256, 0, st>>>(
         c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
     return;

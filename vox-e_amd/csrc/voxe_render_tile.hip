@@ -112,6 +112,9 @@ struct Lat {
 #ifndef VOXE_TILE_STRATA
 #define VOXE_TILE_STRATA 1   // stratum table per depth segment (voxe_device.hpp: SegDepth) in the window forward: -2 .. -5 % forward time
 #endif
+#ifndef VOXE_TILE_STRATA_SH
+#define VOXE_TILE_STRATA_SH 0    // ... and in the two passes of the view-dependent backward
+#endif
 #ifndef VOXE_TILE_STRATA_BWD
 #define VOXE_TILE_STRATA_BWD 0   // ... and in the SH-0 tile backward: measured equal (0.478 ms either way; 80 B more scratch), off
 #endif
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     const float* __restrict__ ray_state, float* __restrict__ gpacked, const int qsplit, const int grp_begin,
     const int ngrp, float4* __restrict__ sample_src, unsigned long long* __restrict__ gdet = nullptr,
     float* __restrict__ det_scale = nullptr, const int det_phase = 0, const float fit_m = 5.5f,
-    const float fit_lat_arg = 0.0f) {
+    const float fit_lat_arg = 0.0f, const float4* __restrict__ sample_fwd = nullptr) {
   // DET: det_phase 0 measures max |contribution| per channel class into det_scale[0..1] (features, density) as
   // float bits (atomicMax: order independent); det_phase 1 deposits with the power-of-two scales det_scale[2..3].
   static_assert(!DET || MODE == 0, "the deterministic mode is the single-kernel backward");
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
     }
   }
   // r04: the strata of this depth segment, tabulated once per block (SegDepth; not with per-ray AABB bounds)
-  constexpr bool kStrata = VOXE_TILE_STRATA_BWD && CM == 4 && MODE == 0 && !DET;
+  constexpr bool kStrata = (VOXE_TILE_STRATA_BWD && CM == 4 && MODE == 0 && !DET) || (VOXE_TILE_STRATA_SH && MODE != 0);
   __shared__ float2 strat[kStrata ? 64 : 1];
   bool use_strata = false;
   if constexpr (kStrata) {
@@ -563,7 +566,16 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
             for (int ch = 0; ch <= COUT; ++ch) gsrc[ch] = 0.0f;
             if (!dead) {
               float v, rad[COUT];
-              gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
+              bool from_fwd = false;
+              if constexpr (MODE == 1 && COUT == 3) {
+                // r04: the forward of the same rays left (rad, v) of this sample in the source buffer's layout: no gather
+                if (sample_fwd) {
+                  const float4 f4 = sample_fwd[src_base + (long long)k * 64];
+                  rad[0] = f4.x; rad[1] = f4.y; rad[2] = f4.z; v = f4.w;
+                  from_fwd = true;
+                }
+              }
+              if (!from_fwd) gather<COUT, NCM, NCU>(g, packed, cell, rc.basis, v, rad);
               float sigma, dpost;
               post_activate_vg(g.post_act, v, sigma, dpost);
               const float dl = last ? kInfinity : (z_next - z);
@@ -1323,7 +1335,8 @@ static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs&
 #define VOXE_TBWD(WD, WF, MODE, KL, NB, GB, NGR)                                                 \
   render_bwd_tile_kernel<COUT, NCM, NCU, WD, WF, MODE, KL><<<NB, 64, 0, st>>>(                    \
       g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour,         \
-      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src), nullptr, nullptr, 0, fit_m, fit_lat)
+      a.d_depth, a.d_acc, a.ray_state, a.gpacked, qsplit, GB, NGR, reinterpret_cast<float4*>(a.sample_src), nullptr, nullptr, 0, fit_m, fit_lat, \
+      reinterpret_cast<const float4*>(a.sample_fwd))
   if constexpr (NGRP == 1) {
     if (a.gdet) {   // deterministic mode: measure the maxima, derive the scales, deposit in fixed point, convert
       const long long n = (long long)g.X * g.Y * g.Z * (COUT * NCM + 1);

@@ -160,8 +160,10 @@ def _next_rng():
 
 
 def render_fwd_into(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
-                    colour, depth, acc, disparity, workspace: Workspace, rng=(0, 0)) -> None:
-    """voxe_render_fwd on caller-provided output tensors (contiguous float32 on one device, no autograd)."""
+                    colour, depth, acc, disparity, workspace: Workspace, rng=(0, 0), keep_for_backward: bool = True) -> None:
+    """voxe_render_fwd on caller-provided output tensors (contiguous float32 on one device, no autograd).
+    keep_for_backward=False (inference): the forward skips what only a backward of the same rays would read (the per-sample
+    values of view-dependent grids); a later backward on this workspace re-marches."""
     device = densities.device
     ensure_gfx950(device)
     L = lib()
@@ -171,11 +173,12 @@ def render_fwd_into(spec: GridSpec, params: RenderParams, densities, features, r
     with torch.cuda.device(device):
         ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
         c.reuse_packed_grid = int(workspace.key == key)
+        c.ray_state_valid = 0 if keep_for_backward else -1
         check(L.voxe_render_fwd(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
                                 ptr(depth), ptr(acc), ptr(disparity), ptr(ws), ws.numel(),
                                 stream_ptr(device)), "voxe_render_fwd")
     workspace.key = key
-    workspace.state_key = _state_key(key, params, rays_o, rays_d, jitter, rng, _route(g, c, R))
+    workspace.state_key = _state_key(key, params, rays_o, rays_d, jitter, rng, _route(g, c, R)) if keep_for_backward else None
 
 
 def render_bwd_into(spec: GridSpec, params: RenderParams, densities, features, rays_o, rays_d, jitter,
@@ -220,7 +223,8 @@ class _RenderFn(torch.autograd.Function):
             version = (densities._version, features._version)
             workspace = workspace.for_differentiable_forward(version)
             workspace.pending, workspace.pending_version = True, version
-        render_fwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, disp, workspace, rng)
+        render_fwd_into(spec, params, dens, feat, ro, rd, jit, colour, depth, acc, disp, workspace, rng,
+                        keep_for_backward=bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         ctx.spec, ctx.params, ctx.workspace, ctx.rng = spec, params, workspace, rng
         ctx.save_for_backward(densities, features, ro, rd, jit, colour, depth, acc)
         return colour, depth, acc, disp
