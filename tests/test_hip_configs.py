@@ -574,12 +574,13 @@ def test_region_route_beyond_the_strata_table(disp):
     assert rel_l2(gd, rd) < GRAD_TOL and rel_l2(gf, rf) < GRAD_TOL, (rel_l2(gd, rd), rel_l2(gf, rf))
 
 
-def test_sh_source_pass_reads_the_forwards_sample_values_or_regathers():
-    """view-dependent grids, image order (r04): the forward leaves (rad, v) of every sample for the two-phase backward's source
-    pass.  Three ways to the same gradient: forward + backward (values from the forward), an inference forward
+@pytest.mark.parametrize("order", ["image", "random"])
+def test_sh_source_pass_reads_the_forwards_sample_values_or_regathers(order):
+    """view-dependent grids (r04): the forward leaves (rad, v) of every sample for the two-phase backward's source pass -- image
+    order: tile kernels; random order: space-binned route.  Three ways to the same gradient: forward + backward (values from the forward), an inference forward
     (keep_for_backward=False: nothing kept) followed by a backward (which re-marches), and a backward alone"""
     from voxe_hip import ops
-    from voxe_hip.dispatch import TILE_ALWAYS
+    from voxe_hip.dispatch import TILE_ALWAYS, Dispatch
     rng = np.random.default_rng(21)
     dims = (40, 36, 44)
     dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
@@ -590,7 +591,13 @@ def test_sh_source_pass_reads_the_forwards_sample_values_or_regathers():
     cfg = make_render_cfg(96, NEAR, FAR, white_bkgd=True, sh_degree=2, perturb=True, seed=8, rng_offset=2)
     gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
-    spec, params = gh.spec_of(grid), gh.params_of(cfg, image_width=hw, dispatch=TILE_ALWAYS)
+    if order == "random":
+        perm = rng.permutation(o.shape[0])
+        o, d, gc = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm]), np.ascontiguousarray(gc[perm])
+        rd, rf = vo.render_bwd(grid, cfg, o, d, gc)     # (the in-kernel jitter is keyed by the ray index)
+        spec, params = gh.spec_of(grid), gh.params_of(cfg, dispatch=Dispatch(region_min_rays=1))
+    else:
+        spec, params = gh.spec_of(grid), gh.params_of(cfg, image_width=hw, dispatch=TILE_ALWAYS)
     td, tf, to, tdir, tg = gh.t(dens), gh.t(feat), gh.t(o), gh.t(d), gh.t(gc)
     outs = [torch.empty((o.shape[0], n), device="cuda") for n in (3, 1, 1, 1)]
     got = []

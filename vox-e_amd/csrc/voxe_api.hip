@@ -306,6 +306,7 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   if ((tiled || packed_bwd) && workspace_bytes >= l.total) state = (float*)((char*)workspace + l.state_off);
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
+  a.keep_samples = cfg->ray_state_valid >= 0;
   if (cfg->ray_state_valid >= 0 && tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp))
     a.sample_fwd = (float*)((char*)workspace + l.fwdval_off);   // (what render_bwd_common's two-phase backward will read)
   if (l.region && workspace_bytes >= l.total_with_src) {

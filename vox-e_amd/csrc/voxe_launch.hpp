@@ -15,6 +15,9 @@ struct FwdArgs {
   // view-dependent grids, image order (r04): (rad_0..2, v) of every sample in the layout of the two-phase tile backward's source
   // buffer (tile, depth segment, sample, lane) -- its source pass then needs no gather (nullable; tile_src_bytes())
   float* sample_fwd = nullptr;
+  // space-binned route, view-dependent grids: keep (rad, v) of every sample in the route's own scratch for the backward's source
+  // pass (false: inference, VoxeRenderCfg::ray_state_valid = -1)
+  bool keep_samples = true;
 };
 struct BwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc;

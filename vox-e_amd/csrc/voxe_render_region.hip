@@ -94,6 +94,9 @@ constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, 
 #ifndef VOXE_REGION_STRATA
 #define VOXE_REGION_STRATA 512      // depth strata tabulated per block (BlockStrata, voxe_device.hpp) for S up to this; 0: off
 #endif
+#ifndef VOXE_REGION_FWDVAL
+#define VOXE_REGION_FWDVAL 1         // view-dependent grids: the forward keeps (rad, v) per sample for the backward's source pass
+#endif
 #ifndef VOXE_REGION_SH_WC
 #define VOXE_REGION_SH_WC 7        // gradient channels per deposit pass of a view-dependent grid (window: WC x 5.9 KB of LDS).
                                    // Swept (32 400 random rays, backward ms, SH-1 / SH-2): 4 -> 1.21 / 2.56, 7 -> 1.10 / 2.48 (13 = 2 / 4
@@ -459,7 +462,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
                                                                        const float* __restrict__ rays_o,
                                                                        const float* __restrict__ rays_d,
                                                                        const float* __restrict__ jitter, BinScratch bs,
-                                                                       const int nreg, const int stage) {
+                                                                       const int nreg, const int stage,
+                                                                       float4* __restrict__ fwdval) {
   constexpr int C = COUT + 1;
   // single-group renders (SH-0 / diffuse / attention) stage (coefficient 0 of every colour, density); view-dependent ones
   // the whole texel (dynamic LDS: 46.6 KB at degree 1, 81.6 KB at degree 2)
@@ -517,6 +521,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g
         if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
         if constexpr (NCU == 1) gather_lds<COUT>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, v, rad);
         else gather_lds_sh<COUT, NCM, NCU>(tex, (lx * kRWY + ly) * kRWZ + lz, cell, basis, v, rad);
+      }
+      if constexpr (NCU > 1 && COUT == 3) {
+        if (fwdval) fwdval[r * c.S + k] = make_float4(rad[0], rad[1], rad[2], v);   // (for region_bwd_src_kernel)
       }
       const float sigma = post_activate(g.post_act, v);
       const float dl = last ? kInfinity : (z_next - z);
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ jitter, const float* __restrict__ d_colour, const float* __restrict__ d_depth,
     const float* __restrict__ d_acc, const int want_d, const int want_f, BinScratch bs, const int nreg,
-    float4* __restrict__ src, const int stage) {
+    float4* __restrict__ src, const int stage, const float4* __restrict__ fwdval) {
   constexpr int COUT = 3;
   extern __shared__ float4 tex_dyn[];
   float* const tex = reinterpret_cast<float*>(tex_dyn);
@@ -855,7 +862,8 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
   const unsigned n = bs.start[(region + 1) * kLenClasses] - first;
   if (n == 0) return;
   const RegionBlock rb = region_block(g, blockIdx.x, nreg);
-  const bool from_global = rb.generic || stage == 0;   // (see region_fwd_kernel)
+  // fwdval: the forward of the same rays left (rad, v) of every sample -- no texels needed at all
+  const bool from_global = rb.generic || stage == 0 || fwdval != nullptr;   // (see region_fwd_kernel)
   if (!from_global) load_window_full<COUT * NCM + 1>(g, packed, tex, rb.ox, rb.oy, rb.oz, tid);
   __shared__ float2 strat[VOXE_REGION_STRATA ? VOXE_REGION_STRATA : 1];
   const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA, c, 0, c.S, tid, VOXE_REGION_BLOCK);
@@ -901,7 +909,12 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_src_kernel(
           const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
           if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
         }
-        gather<COUT, NCM, NCU>(g, packed, cell, basis, v, rad);
+        if (fwdval) {
+          const float4 f4 = fwdval[r * c.S + k];
+          rad[0] = f4.x; rad[1] = f4.y; rad[2] = f4.z; v = f4.w;
+        } else {
+          gather<COUT, NCM, NCU>(g, packed, cell, basis, v, rad);
+        }
       } else {
         const int lx = cell.i[0] - rb.ox, ly = cell.i[1] - rb.oy, lz = cell.i[2] - rb.oz;
         if ((unsigned)lx >= (unsigned)kRBX || (unsigned)ly >= (unsigned)kRBY || (unsigned)lz >= (unsigned)kRBZ) continue;
@@ -1067,7 +1080,7 @@ bool region_bwd_supported(const DevGrid& g, const HostCfg& c, int deg, int diffu
 }
 
 static inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
-struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, src, total; long long nslots, nlanes; int nreg; };
+struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, src, fwdval, total; long long nslots, nlanes; int nreg; };
 static RegionLayout region_layout(int X, int Y, int Z, long long R, int S, bool full_sh = false) {
   RegionLayout l;
   const int nseg = num_segments(S, seg_len_for(R));
@@ -1085,6 +1098,8 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S, bool 
   l.counters = off; off += 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned));   // count | start
   // view-dependent grids: the 4 gradient sources of every sample between the two phases of the backward
   l.src = off; off += full_sh ? up256((size_t)R * (size_t)S * sizeof(float4)) : 0;
+  // ... and the forward's (rad_0..2, v) of every sample, same indexing: the source pass reads them instead of gathering again (r04)
+  l.fwdval = off; off += full_sh ? up256((size_t)R * (size_t)S * sizeof(float4)) : 0;
   l.total = off;
   return l;
 }
@@ -1138,7 +1153,8 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   // degree 3: staging the 151.6 KB of a region's texels leaves one block (4 waves) per CU
   const int stage = (NCU > VOXE_REGION_STAGE_FWD_NCU) ? 0 : 1;
   const size_t lds = (NCU > 1 && stage) ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;
-  region_fwd_kernel<COUT, NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg, stage);
+  float4* fwdval = (NCU > 1 && a.keep_samples && VOXE_REGION_FWDVAL) ? (float4*)((char*)scratch + l.fwdval) : nullptr;
+  region_fwd_kernel<COUT, NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg, stage, fwdval);
   const int rays_per_block = 256 / nseg;        // (nseg <= 256: region_bwd_supported)
   region_fold_kernel<COUT><<<(int)((c.R + rays_per_block - 1) / rays_per_block), 256, 0, st>>>(
       c, bs, a.colour, a.depth, a.acc, a.disparity, rays_per_block);
@@ -1164,11 +1180,13 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
     }
   } else {
     float4* src = (float4*)((char*)scratch + l.src);
-    const int stage = (NCU > VOXE_REGION_STAGE_BWD_NCU) ? 0 : 1;
+    // the forward that filled these tables (voxe_render_fwd on this workspace, or the backward's own re-march) kept its samples
+    const float4* fwdval = VOXE_REGION_FWDVAL ? (const float4*)((char*)scratch + l.fwdval) : nullptr;
+    const int stage = (NCU > VOXE_REGION_STAGE_BWD_NCU || fwdval) ? 0 : 1;
     const size_t lds = stage ? full_tex_lds(region_bwd_src_kernel<NCM, NCU>, COUT * NCM + 1) : 0;
     region_bwd_src_kernel<NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(
         g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.d_colour, a.d_depth, a.d_acc, a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs,
-        l.nreg, src, stage);
+        l.nreg, src, stage, fwdval);
     // channel groups of VOXE_REGION_SH_WC: all of them for a feature gradient, only the one holding the density channel (the last) otherwise
     constexpr int NGRP = (COUT * NCU + 1 + VOXE_REGION_SH_WC - 1) / VOXE_REGION_SH_WC;
     const int grp_begin = a.want_f ? 0 : NGRP - 1, ngrp = a.want_f ? NGRP : 1;
