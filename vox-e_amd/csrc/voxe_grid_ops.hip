@@ -420,11 +420,16 @@ __global__ __launch_bounds__(256) void upsample_kernel(const float* __restrict__
   const float* __restrict__ p100 = at(x1, y0, z0); const float* __restrict__ p101 = at(x1, y0, z1);
   const float* __restrict__ p110 = at(x1, y1, z0); const float* __restrict__ p111 = at(x1, y1, z1);
   float* __restrict__ out = dst + ((long long)x * plane2 + e) * C;
-#pragma unroll
-  for (int ch = 0; ch < C; ++ch) {
+  auto channel = [&](int ch) {
     // (the same expression as before, operand for operand)
     out[ch] = lx0 * (ly0 * (lz0 * p000[ch] + lz1 * p001[ch]) + ly1 * (lz0 * p010[ch] + lz1 * p011[ch])) +
               lx1 * (ly0 * (lz0 * p100[ch] + lz1 * p101[ch]) + ly1 * (lz0 * p110[ch] + lz1 * p111[ch]));
+  };
+  if constexpr (CT > 0) {
+#pragma unroll
+    for (int ch = 0; ch < CT; ++ch) channel(ch);
+  } else {
+    for (int ch = 0; ch < C; ++ch) channel(ch);   // (run-time channel count: nothing to unroll)
   }
 }
 

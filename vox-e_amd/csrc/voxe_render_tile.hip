@@ -565,7 +565,7 @@ __global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE
   #pragma unroll
             for (int ch = 0; ch <= COUT; ++ch) gsrc[ch] = 0.0f;
             if (!dead) {
-              float v, rad[COUT];
+              float v = 0.0f, rad[COUT];
               bool from_fwd = false;
               if constexpr (MODE == 1 && COUT == 3) {
                 // r04: the forward of the same rays left (rad, v) of this sample in the source buffer's layout: no gather
