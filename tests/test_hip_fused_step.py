@@ -328,3 +328,49 @@ def test_density_correlation_inside_the_grid_step_equals_the_separate_pass():
                             dcl_reference=ref, dcl_weight=weight)
     with pytest.raises(ops.VoxeError):       # frozen densities have nothing to regularise
         ops.grid_adam_step_(spec, d, f, 0, ws, 1, 1e-2, state_densities=None, state_features=st_f, dcl_reference=ref, dcl_weight=weight)
+
+
+@pytest.mark.parametrize("case", ["whole", "slab", "features_frozen", "extras"])
+def test_wide_texel_grid_step_chunks_tail_and_slabs(case):
+    """view-dependent grids take the fused grid step 64 voxels at a time with 16-byte accesses (r04); the tail, x-slabs that are
+    not 16-byte aligned and bricked buffers take the element kernel: a hand-made gradient region -> the same parameters, moments
+    and packed grid as voxe_adam_step per tensor on the decoded gradient, bit for bit"""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(31)
+    dims, F = (8, 6, 6), 12                      # 36 voxels per x plane: slab [2, 6) = voxels 72 .. 215 = 2 chunks + a tail of 16
+    C = F + 1
+    spec = ops.GridSpec(aabb=((-1.5, 1.5),) * 3, density_scale=3.0, density_pre_act=abi.ACT_ABS, density_post_act=abi.ACT_SOFTPLUS)
+    dens = torch.empty((*dims, 1)).uniform_(-1, 1, generator=gen).to(dev)
+    feat = torch.empty((*dims, F)).uniform_(-1, 1, generator=gen).to(dev)
+    ws = ops.Workspace()
+    ws.ensure(4 * 2 * (dens.numel() + feat.numel()) * 2 + (1 << 16), dev)
+    ws.buf.zero_()
+    m = [torch.zeros_like(dens), torch.zeros_like(feat)]
+    v = [torch.zeros_like(dens), torch.zeros_like(feat)]
+    ref = [dens.clone(), feat.clone(), [t.clone() for t in m], [t.clone() for t in v]]
+    x_range = (2, 6) if case == "slab" else None
+    x0, x1 = x_range if x_range else (0, dims[0])
+    for step in (1, 2, 3):
+        region = ops.workspace_grad_view(spec, dens, feat, ws)
+        g = torch.empty(dens.numel() * C).normal_(generator=gen).to(dev)
+        region[: g.numel()] = g
+        ex_d = torch.empty(dens.shape).normal_(generator=gen).to(dev) if case == "extras" else None
+        ex_f = torch.empty(feat.shape).normal_(generator=gen).to(dev) if case == "extras" else None
+        d_d, d_f = _region_to_gradients(region.clone(), abi.GRAD_LINEAR, ref[0], spec, C)
+        if ex_d is not None:
+            d_d, d_f = d_d + ex_d, d_f + ex_f
+        ops.grid_adam_step_(spec, dens, feat, abi.GRAD_LINEAR, ws, step, LR, (m[0], v[0]),
+                            None if case == "features_frozen" else (m[1], v[1]), ex_d, ex_f, x_range=x_range)
+        sl = slice(x0, x1)
+        for i, (p, grad) in enumerate(((ref[0], d_d), (ref[1], d_f))):
+            if i == 1 and case == "features_frozen":
+                continue
+            ps, gs, ms, vs = (t[sl].contiguous() for t in (p, grad, ref[2][i], ref[3][i]))
+            ops.adam_step_(ps, gs, ms, vs, step, LR)
+            p[sl], ref[2][i][sl], ref[3][i][sl] = ps, ms, vs
+        for nm, a, b in (("densities", dens, ref[0]), ("features", feat, ref[1]), ("exp_avg d", m[0], ref[2][0]),
+                         ("exp_avg f", m[1], ref[2][1]), ("exp_avg_sq d", v[0], ref[3][0]), ("exp_avg_sq f", v[1], ref[3][1])):
+            assert torch.equal(a, b), (case, step, nm, float((a - b).abs().max()))
+        packed = ops.workspace_packed_view(spec, dens, feat, ws).view(*dims, C)[sl]
+        assert torch.equal(packed[..., :F], feat[sl]) and torch.equal(packed[..., F:], (dens[sl] * 3.0).abs())
+        assert float(ops.workspace_grad_view(spec, dens, feat, ws)[x0 * 36 * C: x1 * 36 * C].abs().max()) == 0.0
