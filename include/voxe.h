@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 7
+#define VOXE_ABI_VERSION 8
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -101,6 +101,12 @@ typedef struct VoxeDispatch {
                                   explicit | -1 route off                                                                     */
   float region_image_ratio;    /* image-ordered launches take the space-binned route when grid side >= this x image width:
                                   0 = 1.3 | < 0: every image-ordered launch the route accepts                                 */
+  int32_t tile_lean;           /* ABI v8.  SH-0 image-ordered backward: 0 = the lean LDS-window kernel (voxe_render_tile4.hip)
+                                  wherever it applies | -1 always the general kernel (A/B runs, parity tests)                 */
+  int32_t precise_grad;        /* ABI v8.  0 = float running sums inside a depth segment (density gradients ~1e-5 median
+                                  relative error against a double-precision backward) | 1 = the suffix sums of the
+                                  image-ordered SH-0 backward are carried in double (~2e-6, a few percent slower).  Forward
+                                  and backward of one render must agree on it (the forward saves the segment states).       */
 } VoxeDispatch;
 
 typedef struct VoxeRenderCfg {

@@ -25,15 +25,15 @@ class _DispatchPatch:
         from voxe_hip import dispatch
 
         self._mod = dispatch
-        self._saved = dispatch._override
+        self._saved = dispatch._override.get()
 
     def set(self, **fields):
         import dataclasses
 
-        self._mod._override = dataclasses.replace(self._mod.current(), **fields)
+        self._mod._override.set(dataclasses.replace(self._mod.current(), **fields))
 
     def restore(self):
-        self._mod._override = self._saved
+        self._mod._override.set(self._saved)
 
 
 @pytest.fixture

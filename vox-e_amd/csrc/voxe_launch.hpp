@@ -83,6 +83,11 @@ bool tile_bwd_supported(const HostCfg& c, int deg);
 // bytes of BwdArgs::sample_src for an image of R rays, width W, S samples (0: that render does not use it)
 size_t tile_src_bytes(long long R, int W, int H, int S, int deg, int diffuse, int attn);
 void launch_bwd_tile(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const BwdArgs& a, hipStream_t st);
+// voxe_render_tile4.hip: the lean LDS-window backward of SH-0 image-ordered renders (8-wide window); launch_bwd_tile hands it
+// the launch geometry it computed (blocks, sibling parts, fit bounds)
+bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl);
+void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int nb, int qsplit, float fit_m, float fit_lat,
+                      hipStream_t st);
 // LDS-staged forward for SH-0 image-ordered renders: writes the per-segment partials into a.segbuf (the caller then runs
 // the ordinary combine pass)
 bool fwd_tile_supported(const DevGrid& g, const HostCfg& c, int cout, int ncm);

@@ -1,0 +1,574 @@
+// voxe_render_tile4.hip -- the LDS-window backward of image-ordered SH-0 renders, rebuilt around its instruction count (r05).
+//
+// Same algorithm, same window and same results as render_bwd_tile_kernel<3, 1, 1, ., ., 0, KL> (voxe_render_tile.hip: one wave =
+// one 8x8-pixel tile x one depth segment, marching in lock step; the tile's gradient is combined in a sliding ring of voxel
+// layers held as doubles in LDS -- parity-class banked, WinMap -- and flushed with 16-byte-dense float atomics).  That kernel is
+// VALU-issue bound (PMC, profiles/r04_pmc_summary.json: ~590 VALU instructions per wave-sample, 0.85 of the launch), and a third
+// of those instructions were bookkeeping the general kernel cannot shed: 106 SGPRs wanted of 102 (v_readlane / v_writelane /
+// s_nop spill traffic in the loop), 64-bit address arithmetic, per-sample float math for the lateral origin of two window
+// layers, a per-lane modulo for the ring slot, run-time channel-group tables of the view-dependent variants.  This file holds
+// ONE configuration -- 4-channel texels, one channel group, float atomics, in-kernel jitter, launch-wide (near, far) -- written
+// so that what the loop touches is small:
+//   * depth strata (DepthGen's lower / span of sample k) live in two VGPRs, lane l = sample ks + l; all lanes are at the same k,
+//     so a sample's stratum is two v_readlane into SGPRs -- no zlin() chain per sample, no LDS;
+//   * the window's per-layer data (lateral origin, ring-slot term of the LDS address) is tabulated once per pass, 8 bytes per
+//     layer key, 64 keys (512 B: window + table = 12 800 B = ten 1 280-byte LDS granules, 12 one-wave blocks per CU as before);
+//   * texel gathers and the flush's atomics address memory as (SGPR base + 32-bit VGPR offset + immediate): the z-neighbour of a
+//     corner is an immediate, no 64-bit vector arithmetic anywhere (grids below 2 GiB of packed texels; the host checks);
+//   * the flush reads AND clears a window voxel with one ds_wrxchg_rtn_b64, its per-lane LDS / voxel offsets are constants of the
+//     pass, the layer's origin voxel is folded into the scalar base pointer: 2 VALU instructions per 16 voxels x 4 channels;
+//   * the deposit products are formed in double from 4 + 8 converted operands (32 v_mul_f64, exact) instead of 32 float products
+//     + 32 conversions; the parity-class corner order costs ~36 integer instructions per sample (layer roles from the parity of
+//     the cell's march index, so the table is read per role and nothing but the two march weights is swapped);
+//   * samples whose footprint is not inside the window go straight to global float atomics (rare; results never depend on it).
+// Everything else (footprint / cell / interpolation / activations / gradient formulas, block order, tile split, window
+// geometry, depth-segment states) is the shared device code of voxe_device.hpp / voxe_render_common.hpp, so sample positions,
+// voxel indices and masks stay bit-identical to the oracle.  Reference arithmetic: thre3d_atom/rendering/volumetric/
+// accumulate.py:49-84 (alpha, transmittance, weights), process.py:45-84, voxels.py:287-332 (trilinear sample), sample.py:44-67.
+#include <limits.h>
+
+#include <type_traits>
+
+#include "voxe_device.hpp"
+#include "voxe_launch.hpp"
+#include "voxe_render_common.hpp"
+#include "voxe_tile_window.hpp"
+
+namespace voxe {
+
+#ifndef VOXE_TILE4_LB
+#define VOXE_TILE4_LB 3
+#endif
+#ifndef VOXE_T4_DEBUG
+#define VOXE_T4_DEBUG 0   // debugging builds (tools/variants.py): 1 every sample through the per-corner path | 2 ... and no corner in the window
+#endif
+
+struct Tile4Args {
+  const float *packed, *rays_o, *rays_d, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc, *ray_state;
+  float* gpacked;
+  int qsplit;
+  float fit_m, fit_lat;
+  int want_d, want_f;
+};
+
+constexpr int kTabKeys = 64;     // layer keys tabulated per pass (re-based when the window has moved 32 layers)
+
+// byte strides of the parity-class banked window (WinMap<KL, 4>): index (doubles) = kSS (slot >> 1) + 4 (slot & 1) + kSA (a >> 1)
+// + 2 (a & 1) + kSB (b >> 1) + (b & 1) + 8 ch
+template <int KL>
+struct Pcb {
+  static_assert(WinMap<KL, 4>::kPcb, "the lean kernel needs the parity-class banked window");
+  static constexpr int SB = WinMap<KL, 4>::kSB * 8, SA = WinMap<KL, 4>::kSA * 8, SS = WinMap<KL, 4>::kSS * 8;
+  static __device__ __forceinline__ int mterm(int slot) { return (slot >> 1) * SS + ((slot & 1) << 5); }
+  // byte term of lateral coordinate x (already made even: x & ~1) along a / b
+  static __device__ __forceinline__ int aterm(int x_even) { return (x_even >> 1) * SA; }
+  static __device__ __forceinline__ int bterm(int x_even) { return (x_even >> 1) * SB; }
+};
+
+// wave-uniform geometry of a pass (not used inside the sample loop: the loop reads the table)
+struct Geo4 {
+  float Au, Bu, Av, Bv;
+  int sgn;
+};
+
+__device__ __forceinline__ int rfl(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// a * b + c on the 24-bit multiplier (full rate; the compiler turns __umul24(a, b) + c into the quarter-rate v_mad_u64_u32);
+// b wave-uniform
+__device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+  return r;
+}
+// a wave-uniform byte pointer the compiler has to keep in SGPRs (so that p + zext(32-bit lane offset) becomes the
+// `saddr + voffset` form of the global instructions instead of 64-bit vector arithmetic)
+__device__ __forceinline__ char* scalar_ptr(unsigned long long v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo);
+}
+// wave-wide integer min with the DPP operand folded into v_min_i32 (wave_min_i32 of voxe_tile_window.hpp compiles to
+// v_mov_b32_dpp + v_min_i32 + s_nop per step); all 64 lanes active
+__device__ __forceinline__ int wave_min_dpp(int v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+// One pass of one (tile, depth segment) with the march axis MA as a compile-time constant.
+template <int MA, int KL>
+__device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, const Tile4Args& a, RayCtx<3, 1, 1>& rc,
+                                           double* __restrict__ win, int2* __restrict__ tab, const int lane, const long long r,
+                                           bool has, const int k_lo, int k_hi, const int kmin, const int kmax, const int seg,
+                                           const int ks, const Geo4 geo, const float strat_lo, const float strat_sp) {
+  constexpr int UA = (MA == 0) ? 1 : 0, VA = (MA == 2) ? 1 : 2;
+  constexpr int COUT = 3;
+  constexpr int kCtr = Lat<KL>::kCentre;
+  typedef Pcb<KL> P;
+
+  // ---- per-ray constants of the backward (render_bwd_kernel, voxe_render.hip) ----------------------------------------
+  float gc[COUT], gsum = 0.0f;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) { gc[ch] = a.d_colour[r * COUT + ch]; gsum += gc[ch]; }
+  const float gdep = a.d_depth ? a.d_depth[r] : 0.0f;
+  const float gacc = a.d_acc ? a.d_acc[r] : 0.0f;
+  const bool white = c.white != 0;
+  float T = 1.0f, suffix0;
+  {
+    const float asum = a.acc[r];
+    float total = gdep * a.depth[r] + gacc * asum;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) {
+      const float csum = white ? a.colour[r * COUT + ch] - (1.0f - asum) : a.colour[r * COUT + ch];
+      total += gc[ch] * csum;
+    }
+    if (white) total -= gsum * asum;
+    suffix0 = total;
+    if (seg > 0) {   // suffix sums saved by the forward's combine pass at this segment boundary (no cancellation)
+      constexpr int NC = COUT + 3;
+      float suf_c[COUT];
+      T = a.ray_state[ray_state_index(seg, 0, NC, c.R, r)];
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) suf_c[ch] = a.ray_state[ray_state_index(seg, 1 + ch, NC, c.R, r)];
+      const float suf_a = a.ray_state[ray_state_index(seg, 1 + COUT, NC, c.R, r)];
+      const float suf_d = a.ray_state[ray_state_index(seg, 2 + COUT, NC, c.R, r)];
+      suffix0 = gdep * suf_d + gacc * suf_a;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) suffix0 += gc[ch] * suf_c[ch];
+      if (white) suffix0 -= gsum * suf_a;
+    }
+  }
+  const float gsumw = white ? gsum : 0.0f;                      // (x - 0 == x: the white-background term without a branch)
+  float gcf[COUT];                                               // d rad_c = (w g_c) (col (1 - col)) C0, C0 folded into g_c's copy
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) gcf[ch] = a.want_f ? gc[ch] : 0.0f;
+  const float dmask = a.want_d ? 1.0f : 0.0f;
+  float run = 0.0f;
+
+  // ---- lane constants of the parity-class banked deposit (WinMap) ----------------------------------------------------
+  // instruction (cc, j) of this lane goes to the corner whose window voxel has parity class cc ^ (hm, hu, hv) and to channel
+  // (j + crot) & 3: the 32 lanes of a half-wave hit 32 different bank pairs in every instruction
+  const int hm = (lane >> 1) & 1, hu = (lane >> 2) & 1, hv = (lane >> 3) & 1;
+  const int crot = (lane & 1) | ((lane >> 3) & 2);
+  const int k0u = 1 - hu, k1u = hu, k0v = 1 - hv, k1v = hv;      // the corner with parity h is (x + 1 - h) & ~1 | h
+  const int KU0 = hu << 4, KU1 = (1 - hu) << 4;                  // byte offset of the a-parity bit
+  int CH[2][4];                                                  // b-parity bit + channel of instruction j
+#pragma unroll
+  for (int cv = 0; cv < 2; ++cv)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) CH[cv][j] = ((hv ^ cv) << 3) + (((j + crot) & 3) << 6);
+  const bool c1 = crot & 1, c2 = crot & 2;
+
+  // ---- window geometry -> per-layer table -----------------------------------------------------------------------------
+  const int sgn = geo.sgn;
+  const int smask = sgn < 0 ? -1 : 0;                            // minkey(pm) = pm ^ smask  (sgn < 0: -(pm + 1) = ~pm)
+  const int sx = g.Y * g.Z, sy = g.Z;
+  const int stride_m = (MA == 0) ? sx : ((MA == 1) ? sy : 1);
+  const int stride_u = (UA == 0) ? sx : sy;
+  const int stride_v = (VA == 1) ? sy : 1;
+  auto build_tab = [&](int key0) {
+    const int key = key0 + lane, im = sgn * key;
+    const int ou = (int)floorf(geo.Au + geo.Bu * (float)im) - kCtr, ov = (int)floorf(geo.Av + geo.Bv * (float)im) - kCtr;
+    tab[lane] = make_int2((ou & 0xffff) | (ov << 16), P::mterm(ring_slot(key)));
+  };
+
+  // depth of sample k: stratum (lower, span) of the segment's table (wave-uniform: every lane is at the same k) + this ray's jitter
+  auto depth_of = [&](int k) {
+    const int j = k - ks;                                       // wave-uniform
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(strat_lo), j));
+    const float sp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(strat_sp), j));
+    const float su = sp * jitter_uniform(rc.dg.base, k);
+    return lo + su;
+  };
+  // first sample of every ray (rolling: z_cur / fp always describe sample max(k, k_lo))
+  float z_cur = 0.0f;
+  Footprint fp;
+  fp.inside = false;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = 0; fp.w[ax][0] = fp.w[ax][1] = 0.0f; }
+  int nextkey = INT_MAX;      // lowest layer key this lane's NEXT sample can write (INT_MAX: no sample left)
+  {
+    // (the first sample index differs from lane to lane: the stratum comes through ds_bpermute instead of v_readlane -- executed
+    //  by ALL lanes: a lane that is switched off supplies nothing to the permute, its readers would get 0)
+    const int j0 = (has ? (k_lo - ks) : 0) << 2;
+    const float lo0 = __int_as_float(__builtin_amdgcn_ds_bpermute(j0, __float_as_int(strat_lo)));
+    const float sp0 = __int_as_float(__builtin_amdgcn_ds_bpermute(j0, __float_as_int(strat_sp)));
+    if (has) {
+      const float su0 = sp0 * jitter_uniform(rc.dg.base, k_lo);
+      z_cur = lo0 + su0;
+      float p[3];
+      rc.point(z_cur, p);
+      footprint(g, p, fp);
+      nextkey = fp.i0[MA] ^ smask;
+    }
+  }
+  int base = wave_min_i32(nextkey);      // lowest live layer key
+  int key0 = base;                       // key of table entry 0
+  build_tab(key0);
+  __syncthreads();                       // window zeroed, table written
+
+  // flush of one layer: 16 voxels x 4 channels per instruction group, KL / 2 groups (two a-rows each)
+  const int q4 = lane >> 2, ch4 = lane & 3;
+  const int fa = q4 & 1, fb = q4 >> 1;                           // lateral cell (2 j + fa, fb) of this lane in group j
+  const int flush_lds = ((fa << 1) + (fb >> 1) * (P::SB / 8) + (fb & 1) + (ch4 << 3)) * 8;
+  const unsigned flush_vox = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
+  const unsigned long long gaddr = reinterpret_cast<unsigned long long>(a.gpacked);
+  const long long sm16 = (long long)stride_m * 16, su16 = (long long)stride_u * 16, sv16 = (long long)stride_v * 16;
+  auto flush_layer4 = [&](int key) {     // key wave-uniform
+    const int2 e = tab[key - key0];      // (broadcast read)
+    const int ex = rfl(e.x), mt = rfl(e.y);
+    const int ou = (int)(short)(ex & 0xffff), ov = ex >> 16;
+    const int im = sgn * key;
+    const unsigned long long vb = gaddr + (unsigned long long)((long long)im * sm16 + (long long)ou * su16 + (long long)ov * sv16);   // scalar
+    unsigned long long* const wl = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(win) + (flush_lds + mt));
+    unsigned long long old[KL / 2];
+#pragma unroll
+    for (int j = 0; j < KL / 2; ++j)
+      old[j] = __hip_atomic_exchange(wl + j * (P::SA / 8), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int j = 0; j < KL / 2; ++j) {
+      const double val = __longlong_as_double((long long)old[j]);
+      if (val != 0.0) {
+        char* const gb = scalar_ptr(vb + (unsigned long long)((long long)j * 2ll * su16));       // scalar base of group j
+        atomicAdd(reinterpret_cast<float*>(gb + (size_t)flush_vox), (float)val);
+      }
+    }
+  };
+  static_assert(KL == 8, "flush_layer4: the b extent of a group is the 8 lanes q4 >> 1");
+
+  const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * 16u : 0u, syb = g.Y > 1 ? (unsigned)g.Z * 16u : 0u;
+  const unsigned szb = g.Z > 1 ? 16u : 0u;
+  const unsigned sxi = (unsigned)(g.Y * g.Z) * 16u, syi = (unsigned)g.Z * 16u;   // strides of the cell's low-corner index
+  const char* const pbytes = reinterpret_cast<const char*>(a.packed);
+  char* const gbytes = reinterpret_cast<char*>(a.gpacked);
+  const int Sm1 = c.S - 1;
+  const float term_eps = c.term_eps;
+  const int nk0 = -key0;   // (re-based with the table)
+  int nkey0 = nk0;
+
+  for (int k = kmin; k <= kmax; ++k) {
+    const bool on = has && (k >= k_lo) && (k <= k_hi);
+    if (on) {
+      const float z = z_cur;
+      const bool last = (k == Sm1);        // wave-uniform
+      const float z_next = last ? z : depth_of(k + 1);
+      if (fp.inside) {
+        // the footprint with the zero-padding rule folded in (make_cell), IN PLACE: away from the faces (almost every sample;
+        // wave-uniform test) the footprint is the cell, and nothing of it is read again before the next footprint() overwrites it
+        if (__builtin_amdgcn_ballot_w64(!cell_is_interior(g, fp)) != 0ull) {
+          Cell cf;
+          make_cell(g, fp, cf);
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = cf.i[ax]; fp.w[ax][0] = cf.w[ax][0]; fp.w[ax][1] = cf.w[ax][1]; }
+        }
+        Cell cell;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
+        // ---- gather: 8 texels as (scalar base + 32-bit offset); the z-neighbour is the immediate --------------------
+        const unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
+        float4 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+          t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+        }
+        float f0, f1, f2, v;
+        interp_texels4(t, cell, f0, f1, f2, v);
+        const float rad[COUT] = {kC0 * f0, kC0 * f1, kC0 * f2};
+        float sigma, dpost;
+        post_activate_vg(g.post_act, v, sigma, dpost);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float wk = alpha * T;
+        float col[COUT], dldw = fmaf(gdep, z, gacc);
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
+        dldw -= gsumw;
+        run = fmaf(dldw, wk, run);
+        const float suffix = last ? 0.0f : (suffix0 - run);
+        const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+        const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+        float gch[4];
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) gch[ch] = ((wk * gcf[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0;
+        gch[3] = (dsig * dpost) * dmask;
+        T = T * om;
+        if (term_eps > 0.0f && T < term_eps) k_hi = k;   // gradient truncation (not in the reference)
+
+        if (wk != 0.0f || gch[3] != 0.0f) {
+          // ---- the cell in (march, lateral u, lateral v) order ---------------------------------------------------------
+          const int pm = cell.i[MA], pu = cell.i[UA], pv = cell.i[VA];
+          const float wm0 = cell.w[MA][0], wm1 = cell.w[MA][1];
+          const float wu0 = cell.w[UA][0], wu1 = cell.w[UA][1], wv0 = cell.w[VA][0], wv1 = cell.w[VA][1];
+          // layer roles: "A" = the layer whose ring slot has parity hm (slot parity == key parity == parity of the march index:
+          // the ring depth is even), "B" the other one
+          const int tm = (pm ^ hm) & 1;
+          const int imA = pm + tm, imB = pm + 1 - tm;
+          const int relA = ((imA ^ smask) - smask) + nkey0, relB = ((imB ^ smask) - smask) + nkey0;   // sgn * im - key0
+          const int2 eA = tab[relA & (kTabKeys - 1)], eB = tab[relB & (kTabKeys - 1)];
+          const int ouA = (int)(short)(eA.x & 0xffff), ovA = eA.x >> 16, ouB = (int)(short)(eB.x & 0xffff), ovB = eB.x >> 16;
+          const int PU0 = pu + k0u, PU1 = pu + k1u, PV0 = pv + k0v, PV1 = pv + k1v;
+          const int xA0 = PU0 - ouA, xA1 = PU1 - ouA, yA0 = PV0 - ovA, yA1 = PV1 - ovA;   // {a, a + 1}, {b, b + 1} of layer A
+          const int xB0 = PU0 - ouB, xB1 = PU1 - ouB, yB0 = PV0 - ovB, yB1 = PV1 - ovB;
+          // window test: both layers inside the ring, every lateral coordinate inside [0, KL)
+          const int klrel = min(relA, relB);
+          bool fits = (unsigned)(klrel - (base + nkey0)) < (unsigned)(kRing - 1);   // (base - key0 <= 32: both entries are tabulated)
+          if constexpr (KL == 8) fits = fits && ((unsigned)(xA0 | xA1 | yA0 | yA1 | xB0 | xB1 | yB0 | yB1) < 8u);
+          else fits = fits && (max(max(max((unsigned)xA0, (unsigned)xA1), max((unsigned)yA0, (unsigned)yA1)),
+                                   max(max((unsigned)xB0, (unsigned)xB1), max((unsigned)yB0, (unsigned)yB1))) < (unsigned)KL);
+          if (VOXE_T4_DEBUG & 3) fits = false;
+          if (fits) {
+            // weights in role order: x0 = weight of the corner with parity h (the low corner iff its coordinate has parity h)
+            const float wmA = tm ? wm1 : wm0, wmB = tm ? wm0 : wm1;
+            auto pick2 = [](int x1, float w0, float w1, float& o0, float& o1) {   // x1 = coordinate + h: odd <=> the HIGH corner has parity h
+              const bool hi = x1 & 1;
+              o0 = hi ? w1 : w0;
+              o1 = hi ? w0 : w1;
+            };
+            float wuA[2], wuB[2], wvA[2], wvB[2];
+            pick2(xA1, wu0, wu1, wuA[0], wuA[1]);
+            pick2(xB1, wu0, wu1, wuB[0], wuB[1]);
+            pick2(yA1, wv0, wv1, wvA[0], wvA[1]);
+            pick2(yB1, wv0, wv1, wvB[0], wvB[1]);
+            const float wmuA[2] = {wmA * wuA[0], wmA * wuA[1]}, wmuB[2] = {wmB * wuB[0], wmB * wuB[1]};
+            // byte addresses: slot term (table) + a term + b term + parity bits + channel
+            const int MA0 = eA.y + KU0, MA1 = eA.y + KU1, MB0 = eB.y + KU0, MB1 = eB.y + KU1;
+            const int muA[2] = {P::aterm(xA0 & ~1) + MA0, P::aterm(xA1 & ~1) + MA1};
+            const int muB[2] = {P::aterm(xB0 & ~1) + MB0, P::aterm(xB1 & ~1) + MB1};
+            const int bvA[2] = {P::bterm(yA0 & ~1), P::bterm(yA1 & ~1)}, bvB[2] = {P::bterm(yB0 & ~1), P::bterm(yB1 & ~1)};
+            // gr[j] = gch[(j + crot) & 3], as doubles
+            const float q0 = c1 ? gch[1] : gch[0], q1 = c1 ? gch[2] : gch[1], q2 = c1 ? gch[3] : gch[2], q3 = c1 ? gch[0] : gch[3];
+            const double gr[4] = {(double)(c2 ? q2 : q0), (double)(c2 ? q3 : q1), (double)(c2 ? q0 : q2), (double)(c2 ? q1 : q3)};
+            char* const wb = reinterpret_cast<char*>(win);
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+              const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;   // compile-time bits of this instruction
+              const double wgt = (double)((bm ? wmuB[bu] : wmuA[bu]) * (bm ? wvB[bv] : wvA[bv]));
+              const int idx = (bm ? muB[bu] : muA[bu]) + (bm ? bvB[bv] : bvA[bv]);
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                __hip_atomic_fetch_add(reinterpret_cast<double*>(wb + (idx + CH[bv][j])), gr[j] * wgt, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          } else {
+            // Some corner outside the window (oblique tile borders, ring overflow, grid faces): per corner, in natural order --
+            // inside the window the LDS add (bank conflicts do not matter here), else a global float atomic.
+            const int brel = base + nkey0;
+            const int2 e0 = tm ? eB : eA, e1 = tm ? eA : eB;                    // table entries of layers pm, pm + 1
+            const int rel0 = tm ? relB : relA, rel1 = tm ? relA : relB;
+            const unsigned vo = (unsigned)((pm * stride_m + pu * stride_u + pv * stride_v) * 16);
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+              const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
+              const float wgt = ((cm ? wm1 : wm0) * (cu ? wu1 : wu0)) * (cv ? wv1 : wv0);
+              if (wgt != 0.0f) {
+                const int2 es = cm ? e1 : e0;
+                const int aa = pu + cu - (int)(short)(es.x & 0xffff), bb = pv + cv - (es.x >> 16);
+                const bool inwin = !(VOXE_T4_DEBUG & 2) && ((unsigned)((cm ? rel1 : rel0) - brel) < (unsigned)kRing) &&
+                                   ((unsigned)aa < (unsigned)KL) && ((unsigned)bb < (unsigned)KL);
+                if (inwin) {
+                  double* const wp = reinterpret_cast<double*>(reinterpret_cast<char*>(win) +
+                                                               (es.y + (aa >> 1) * P::SA + ((aa & 1) << 4) + (bb >> 1) * P::SB + ((bb & 1) << 3)));
+#pragma unroll
+                  for (int ch = 0; ch < 4; ++ch)
+                    __hip_atomic_fetch_add(wp + ch * 8, (double)(gch[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                  float* const gp = reinterpret_cast<float*>(gbytes + (size_t)(vo + (unsigned)((cm * stride_m + cu * stride_u + cv * stride_v) * 16)));
+#pragma unroll
+                  for (int ch = 0; ch < 4; ++ch) atomicAdd(gp + ch, gch[ch] * wgt);
+                }
+              }
+            }
+          }
+        }
+      }
+      // ---- the next sample's footprint (after the deposit: nothing of it is live across the 32 LDS adds) -------------------
+      nextkey = INT_MAX;
+      if (!last && k < k_hi) {
+        float pn[3];
+        rc.point(z_next, pn);
+        footprint(g, pn, fp);
+        z_cur = z_next;
+        nextkey = fp.i0[MA] ^ smask;
+      }
+    }
+    // ---- slide the window: flush every layer no lane can reach any more -------------------------------------------------
+    // (one compare per iteration: does ANY lane's next sample still reach layer `base`?)
+    if (__ballot(nextkey <= base) == 0ull) {   // wave-uniform
+      int n = 0;
+      do { flush_layer4(base + n); ++n; } while (n < kRing && __ballot(nextkey <= base + n) == 0ull);
+      base = (n == kRing) ? wave_min_dpp(nextkey) : base + n;
+      if (base != INT_MAX && base + nkey0 > kTabKeys / 2) {   // re-base the table (everything below `base` is flushed)
+        key0 = base;
+        nkey0 = -key0;
+        build_tab(key0);
+      }
+    }
+  }
+  if (base != INT_MAX) {
+    for (int i = 0; i < kRing; ++i) flush_layer4(base + i);
+  }
+}
+
+template <int KL>
+__global__ __launch_bounds__(64, VOXE_TILE4_LB) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a) {
+  __shared__ double win[WinMap<KL, 4>::kDoubles];
+  __shared__ int2 tab[kTabKeys];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < WinMap<KL, 4>::kDoubles; i += 64) win[i] = 0.0;
+
+  // ---- block -> (pixel tile, depth segment[, part]): the block order of render_bwd_tile_kernel ---------------------------
+  const int W = c.image_width;
+  const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int ntp = gridDim.x / (nseg * a.qsplit);
+  const int part = blockIdx.x / ntp;
+  const int quad = part / nseg, seg = part - quad * nseg;
+  const int tile = logical_tile_of(c, blockIdx.x % ntp, ntp, ntx, nty);
+  if (tile < 0) return;  // launch padding (wave-uniform)
+  const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  long long r_px;
+  const bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  const long long r = alive ? r_px : 0;
+
+  RayCtx<3, 1, 1> rc;
+  rc.init(g, c, r, a.rays_o, a.rays_d, nullptr);
+
+  // ---- does the 8x8 tile fit the lateral window?  (the split decision of render_bwd_tile_kernel) -------------------------
+  int split = 0;
+  {
+    const unsigned long long am = __ballot(alive);
+    if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
+      const int N[3] = {g.X, g.Y, g.Z};
+      const float zref = readlane_f32(rc.dg.zlin(ke), 0);
+      float d0[3], ex3[3], ey3[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float s = g.scale[ax] * 0.5f * (float)N[ax];
+        const float da = readlane_f32(rc.d[ax], 0);
+        d0[ax] = fabsf(da * s);
+        ex3[ax] = fabsf((readlane_f32(rc.d[ax], 1) - da) * s * zref);
+        ey3[ax] = fabsf((readlane_f32(rc.d[ax], 8) - da) * s * zref);
+      }
+      const int m = (d0[0] >= d0[1] && d0[0] >= d0[2]) ? 0 : ((d0[1] >= d0[2]) ? 1 : 2);
+      const float fit_lat = a.fit_lat > 0.0f ? a.fit_lat : (float)KL - 2.5f;
+      auto fits_pass = [&](float wx, float wy) {
+        float lat = 0.0f, alongm = 0.0f;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+          const float e = wx * ex3[ax] + wy * ey3[ax];
+          if (ax == m) alongm = e; else lat = fmaxf(lat, e);
+        }
+        return lat <= fit_lat && alongm <= a.fit_m;
+      };
+      if (!fits_pass(7.0f, 7.0f)) {
+        const bool hx = fits_pass(3.0f, 7.0f), hy = fits_pass(7.0f, 3.0f);
+        const float sx = ex3[0] + ex3[1] + ex3[2], sy = ey3[0] + ey3[1] + ey3[2];
+        if (hx && hy) split = (sx >= sy) ? 1 : 2;
+        else split = hx ? 1 : (hy ? 2 : 3);
+      }
+    }
+  }
+  // the strata of this depth segment: lane l holds (lower, span) of sample ks + l (DepthGen's own expressions)
+  float strat_lo = 0.0f, strat_sp = 0.0f;
+  if (ks + lane < c.S && lane <= ke + 1 - ks) {
+    const float2 st = depth_stratum(rc.dg, ks + lane);
+    strat_lo = st.x; strat_sp = st.y;
+  }
+
+  auto run_pass = [&](const bool alive_q, const int centre_lane, const int centre_lane2) {
+    const int k_lo = max(rc.k_lo, ks);
+    int k_hi = alive_q ? min(rc.k_hi, ke) : k_lo - 1;
+    bool has = k_lo <= k_hi;
+    if (has && seg > 0 && c.term_eps > 0.0f) {   // gradient truncation: nothing behind T < term_eps receives a gradient
+      if (a.ray_state[ray_state_index(seg, 0, 6, c.R, r)] < c.term_eps) { has = false; k_hi = k_lo - 1; }
+    }
+    const int kmin = wave_min_i32(has ? k_lo : INT_MAX);
+    const int kmax = wave_max_i32(has ? k_hi : -1);
+    if (kmin > kmax) return;  // wave-uniform: no ray of this pass meets the volume in this segment
+    // ---- window geometry from the reference ray (render_bwd_tile_kernel) ----
+    Geo4 geo;
+    int m;
+    {
+      const unsigned long long hmk = __ballot(has);
+      const int ref = ((hmk >> centre_lane) & 1ull) ? centre_lane : (__ffsll((long long)hmk) - 1);
+      const int ref2 = (VOXE_TILE_CENTRE2 && ref == centre_lane && ((hmk >> centre_lane2) & 1ull)) ? centre_lane2 : ref;
+      const int N[3] = {g.X, g.Y, g.Z};
+      float U0[3], DU[3];
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float ro = readlane_f32(rc.o[ax], ref), rd = 0.5f * (readlane_f32(rc.d[ax], ref) + readlane_f32(rc.d[ax], ref2));
+        const float half = 0.5f * (float)N[ax];
+        U0[ax] = ((ro * g.scale[ax] + g.bias[ax]) + 1.0f) * half - 0.5f;
+        DU[ax] = rd * g.scale[ax] * half;
+      }
+      const float ax_ = fabsf(DU[0]), ay_ = fabsf(DU[1]), az_ = fabsf(DU[2]);
+      m = (ax_ >= ay_ && ax_ >= az_) ? 0 : ((ay_ >= az_) ? 1 : 2);
+      const int u = (m == 0) ? 1 : 0, v = (m == 2) ? 1 : 2;
+      const float DUm = (m == 0) ? DU[0] : ((m == 1) ? DU[1] : DU[2]);
+      const float U0m = (m == 0) ? U0[0] : ((m == 1) ? U0[1] : U0[2]);
+      const float DUu = (u == 0) ? DU[0] : DU[1], U0u = (u == 0) ? U0[0] : U0[1];
+      const float DUv = (v == 1) ? DU[1] : DU[2], U0v = (v == 1) ? U0[1] : U0[2];
+      geo.sgn = (DUm < 0.0f) ? -1 : 1;
+      const float inv = (DUm != 0.0f) ? 1.0f / DUm : 0.0f;
+      geo.Bu = DUu * inv; geo.Au = U0u - geo.Bu * U0m;
+      geo.Bv = DUv * inv; geo.Av = U0v - geo.Bv * U0m;
+    }
+    if (m == 0) bwd4_march<0, KL>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+    else if (m == 1) bwd4_march<1, KL>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+    else bwd4_march<2, KL>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+  };
+  auto in_part = [&](int q) {
+    const int hx = (lane >> 2) & 1, hy = (lane >> 5) & 1;
+    return split == 0 ? true : (split == 1 ? hx == q : (split == 2 ? hy == q : hx + 2 * hy == q));
+  };
+  auto centre_of = [&](int q) {
+    return split == 0 ? 27 : (split == 1 ? 26 + 4 * q : (split == 2 ? 19 + 32 * q : 18 + 4 * (q & 1) + 32 * (q >> 1)));
+  };
+  auto centre2_of = [&](int q) {
+    return split == 0 ? 36 : (split == 1 ? 33 + 4 * q : (split == 2 ? 12 + 32 * q : 9 + 4 * (q & 1) + 32 * (q >> 1)));
+  };
+  const int nparts = split == 0 ? 1 : (split == 3 ? 4 : 2);
+  const int q_begin = a.qsplit == 4 ? quad : 0;
+  const int q_end = a.qsplit == 4 ? min(quad + 1, nparts) : nparts;
+  for (int q = q_begin; q < q_end; ++q) {
+    run_pass(alive && in_part(q), centre_of(q), centre2_of(q));
+    __syncthreads();
+  }
+}
+
+// The lean kernel takes: SH-0 grids (4-channel texels), the 8-wide parity-class banked window, float atomics, in-kernel jitter
+// (no caller-supplied uniforms), launch-wide (near, far) (no per-ray AABB bounds), depth segments that fit the strata
+// registers, packed grids below 2 GiB (32-bit byte offsets).  VoxeDispatch::tile_lean = -1 switches it off (A/B, parity tests).
+bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl) {
+  if (c.disp.tile_lean < 0) return false;
+  if (kl != 8 || a.gdet || a.jitter || c.aabb_clip || c.attn || c.image_width <= 0) return false;
+  if (c.seg_len + 1 > 64) return false;
+  const long long bytes = (long long)g.X * g.Y * g.Z * 16;
+  return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);   // (mad24 operands)
+}
+
+void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int nb, int qsplit, float fit_m, float fit_lat,
+                      hipStream_t st) {
+  Tile4Args t;
+  t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
+  t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
+  t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = a.want_d ? 1 : 0; t.want_f = a.want_f ? 1 : 0;
+  render_bwd_tile4_kernel<8><<<nb, 64, 0, st>>>(g, c, t);
+}
+
+}  // namespace voxe

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # VoxeStatus
 OK = 0
@@ -69,6 +69,8 @@ class VoxeDispatch(C.Structure):
         ("fwd_segments_per_thread", C.c_int32),
         ("region_min_rays", C.c_int64),
         ("region_image_ratio", C.c_float),
+        ("tile_lean", C.c_int32),
+        ("precise_grad", C.c_int32),
     ]
 
 

@@ -1,11 +1,11 @@
-"""Which kernels render a call, and with which tuning parameters: the Python face of `VoxeDispatch` (include/voxe.h, ABI v7).
+"""Which kernels render a call, and with which tuning parameters: the Python face of `VoxeDispatch` (include/voxe.h, ABI v8).
 
 The library itself holds no dispatch state and reads no environment on the render path: every render call carries a pointer
 to one of these structs (`VoxeRenderCfg::dispatch`; NULL = the shipped dispatch).  This module
 
   * resolves the process's VOXE_* environment switches ONCE, on first use, into a `Dispatch` (`from_env()`): the A/B shell
-    scripts under tools/ keep working (`VOXE_TILE_KL=10 python bench.py ...`), but changing the environment afterwards has no
-    effect and nothing is re-read per launch;
+    scripts under tools/ (`ab_env.sh`, `ab_env_bench.sh`: `VOXE_TILE_KL=10 python bench.py ...`) set them before the process
+    starts; changing the environment afterwards has no effect and nothing is re-read per launch;
   * lets a caller ask for another dispatch per call (`RenderParams(dispatch=Dispatch(...))`) or for a scope
     (`with dispatch.override(region_min_rays=1): ...`), e.g. parity tests that must reach the LDS-window backward with a
     48x48 image.
@@ -13,6 +13,7 @@ to one of these structs (`VoxeRenderCfg::dispatch`; NULL = the shipped dispatch)
 Forward and backward of one render have to use the same dispatch; `ops` keys the per-ray states on it.
 """
 import contextlib
+import contextvars
 import dataclasses
 import functools
 import os
@@ -41,6 +42,8 @@ class Dispatch:
     fwd_segments_per_thread: int = 0
     region_min_rays: int = 0         # 0 = 16384 | > 0 | -1: route off
     region_image_ratio: float = 0.0  # 0 = 1.3 | < 0: every image-ordered launch the route accepts
+    tile_lean: int = 0               # 0 lean SH-0 tile backward where it applies | -1 always the general kernel
+    precise_grad: int = 0            # 0 float in-segment suffix sums | 1 double (image-ordered SH-0 backward)
 
     def struct(self) -> abi.VoxeDispatch:
         return _struct_of(self)
@@ -109,25 +112,31 @@ def from_env() -> Dispatch:
     f = _env_float("VOXE_REGION_IMAGE_RATIO")
     if f is not None:
         kw["region_image_ratio"] = -1.0 if f <= 0.0 else f
+    if os.environ.get("VOXE_TILE_LEAN", "")[:1] == "0":
+        kw["tile_lean"] = -1
+    if os.environ.get("VOXE_PRECISE_GRAD", "")[:1] == "1":
+        kw["precise_grad"] = 1
     return Dispatch(**kw)
 
 
-_override: Optional[Dispatch] = None
+# the override of the CURRENT context (thread / asyncio task): a render issued from another thread -- a DataLoader or feedback
+# thread -- inside someone else's override() block keeps the process dispatch
+_override: contextvars.ContextVar = contextvars.ContextVar("voxe_dispatch_override", default=None)
 
 
 def current() -> Dispatch:
     """the dispatch a render call uses when its RenderParams name none"""
-    return _override if _override is not None else from_env()
+    o = _override.get()
+    return o if o is not None else from_env()
 
 
 @contextlib.contextmanager
 def override(base: Optional[Dispatch] = None, **fields):
     """`with override(region_min_rays=1):` -- renders inside the block default to the current dispatch with these fields
     replaced (or to `base`); Python-side state only, handed to the library call by call"""
-    global _override
-    saved = _override
-    _override = dataclasses.replace(base if base is not None else current(), **fields)
+    new = dataclasses.replace(base if base is not None else current(), **fields)
+    token = _override.set(new)
     try:
-        yield _override
+        yield new
     finally:
-        _override = saved
+        _override.reset(token)

@@ -294,6 +294,10 @@ def render(spec: GridSpec, params: RenderParams, densities: torch.Tensor, featur
         workspace = Workspace()
     if rng is None:
         rng = _next_rng() if (params.perturb and jitter is None) else (0, 0)
+    if params.dispatch is None:
+        # resolve the dispatch HERE, once: the backward runs on autograd's engine thread, where a `dispatch.override()` of the
+        # calling context is not visible, and forward and backward of one render must use the same routes
+        params = dataclasses.replace(params, dispatch=_dispatch.current())
     return _RenderFn.apply(densities, features, rays_o, rays_d, jitter, spec, params, workspace, rng)
 
 
