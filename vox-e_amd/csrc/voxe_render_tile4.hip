@@ -39,6 +39,10 @@ namespace voxe {
 #ifndef VOXE_TILE4_LB
 #define VOXE_TILE4_LB 3
 #endif
+#ifndef VOXE_T4_EXP
+#define VOXE_T4_EXP 0     // timing experiments, WRONG RESULTS by construction (tools/variants.py): 1 every lane gathers the same texels |
+                          // 2 no LDS adds (products kept) | 4 no flush | 8 flush without the global atomics | 16 no deposit at all
+#endif
 #ifndef VOXE_T4_DEBUG
 #define VOXE_T4_DEBUG 0   // debugging builds (tools/variants.py): 1 every sample through the per-corner path | 2 ... and no corner in the window
 #endif
@@ -79,12 +83,24 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
   return r;
 }
-// a wave-uniform byte pointer the compiler has to keep in SGPRs (so that p + zext(32-bit lane offset) becomes the
-// `saddr + voffset` form of the global instructions instead of 64-bit vector arithmetic)
-__device__ __forceinline__ char* scalar_ptr(unsigned long long v) {
+// a wave-uniform GLOBAL byte pointer the compiler has to keep in SGPRs (so that p + zext(32-bit lane offset) becomes the
+// `saddr + voffset` form of the global instructions instead of 64-bit vector arithmetic).  The explicit address space matters:
+// an integer that went through a loop-carried variable comes back as a generic pointer, i.e. FLAT instructions, whose
+// out-of-order lgkmcnt forces s_waitcnt lgkmcnt(0) in front of every LDS result of the loop.
+typedef __attribute__((address_space(1))) char gchar;
+typedef __attribute__((address_space(1))) float gfloat;
+__device__ __forceinline__ gchar* scalar_ptr(unsigned long long v) {
   unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
   asm volatile("" : "+s"(lo), "+s"(hi));
-  return reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo);
+  return reinterpret_cast<gchar*>(((unsigned long long)hi << 32) | lo);
+}
+// float atomic add (no return) at scalar base + 32-bit lane offset.  The compiler has to see the instruction (an inline-asm
+// atomic is invisible to its wait-count pass, which then waits for MORE than the loads it means).  The lane offset is made
+// opaque at every use: once its zero extension is hoisted out of the loop as a 64-bit pair the instruction selector falls
+// back to v_lshl_add_u64 + a 64-bit vector address instead of `saddr + voffset`.
+__device__ __forceinline__ void global_add_f32(gchar* base, unsigned voff, float x) {
+  asm volatile("" : "+v"(voff));
+  __hip_atomic_fetch_add(reinterpret_cast<gfloat*>(base + (size_t)voff), x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wave-wide integer min with the DPP operand folded into v_min_i32 (wave_min_i32 of voxe_tile_window.hpp compiles to
 // v_mov_b32_dpp + v_min_i32 + s_nop per step); all 64 lanes active
@@ -224,27 +240,40 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   const unsigned flush_vox = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
   const unsigned long long gaddr = reinterpret_cast<unsigned long long>(a.gpacked);
   const long long sm16 = (long long)stride_m * 16, su16 = (long long)stride_u * 16, sv16 = (long long)stride_v * 16;
-  auto flush_layer4 = [&](int key) {     // key wave-uniform
+  // The flush of a layer is split in two: flush_issue() reads-and-clears the layer (ds_wrxchg_rtn_b64) and keeps the returned
+  // values pending in registers, flush_consume() -- one iteration later, while the next sample's texels are on their way --
+  // converts them and issues the global atomics.  Issued and consumed in one go the wave sat through the LDS queue (the 32 adds
+  // of the sample in front of the exchange) once per iteration: 0.077 of 0.41 ms (timing experiment, profiles/r05_lean_experiments.txt).
+  unsigned long long pend[KL / 2];
+#pragma unroll
+  for (int j = 0; j < KL / 2; ++j) pend[j] = 0ull;
+  unsigned long long pend_vb = 0ull;     // scalar: global byte address of the pending layer's origin voxel
+  bool have_pend = false;                // wave-uniform
+  auto flush_issue = [&](int key) {      // key wave-uniform
+    if (VOXE_T4_EXP & 4) return;
     const int2 e = tab[key - key0];      // (broadcast read)
     const int ex = rfl(e.x), mt = rfl(e.y);
     const int ou = (int)(short)(ex & 0xffff), ov = ex >> 16;
     const int im = sgn * key;
-    const unsigned long long vb = gaddr + (unsigned long long)((long long)im * sm16 + (long long)ou * su16 + (long long)ov * sv16);   // scalar
+    pend_vb = gaddr + (unsigned long long)((long long)im * sm16 + (long long)ou * su16 + (long long)ov * sv16);   // scalar
     unsigned long long* const wl = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(win) + (flush_lds + mt));
-    unsigned long long old[KL / 2];
 #pragma unroll
     for (int j = 0; j < KL / 2; ++j)
-      old[j] = __hip_atomic_exchange(wl + j * (P::SA / 8), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pend[j] = __hip_atomic_exchange(wl + j * (P::SA / 8), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    have_pend = true;
+  };
+  auto flush_consume = [&]() {
+    if (!have_pend) return;              // wave-uniform
 #pragma unroll
     for (int j = 0; j < KL / 2; ++j) {
-      const double val = __longlong_as_double((long long)old[j]);
-      if (val != 0.0) {
-        char* const gb = scalar_ptr(vb + (unsigned long long)((long long)j * 2ll * su16));       // scalar base of group j
-        atomicAdd(reinterpret_cast<float*>(gb + (size_t)flush_vox), (float)val);
+      const double val = __longlong_as_double((long long)pend[j]);
+      if (!(VOXE_T4_EXP & 8) && val != 0.0) {
+        global_add_f32(scalar_ptr(pend_vb + (unsigned long long)((long long)j * 2ll * su16)), flush_vox, (float)val);   // scalar base of group j
       }
     }
+    have_pend = false;
   };
-  static_assert(KL == 8, "flush_layer4: the b extent of a group is the 8 lanes q4 >> 1");
+  static_assert(KL == 8, "flush_issue: the b extent of a group is the 8 lanes q4 >> 1");
 
   const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * 16u : 0u, syb = g.Y > 1 ? (unsigned)g.Z * 16u : 0u;
   const unsigned szb = g.Z > 1 ? 16u : 0u;
@@ -258,32 +287,52 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
 
   for (int k = kmin; k <= kmax; ++k) {
     const bool on = has && (k >= k_lo) && (k <= k_hi);
+    const bool live = on && fp.inside;
+    // ---- phase 1: the cell of this sample, its 8 texel loads and the two window-table reads go out -- in STRAIGHT-LINE code,
+    // executed by every lane (lanes without a sample gather texel 0 and read table entry 0): the compiler's wait-count pass is
+    // not path sensitive, loads issued under one `if` and consumed under a later one leave it with "possibly outstanding" at
+    // the loop's back edge, which it resolves with s_waitcnt vmcnt(0) in front of the next iteration's loads -- and that wait
+    // also covers the flush's global atomics.
+    if (live) {
+      // the footprint with the zero-padding rule folded in (make_cell), IN PLACE: away from the faces (almost every sample;
+      // wave-uniform test) the footprint is the cell, and nothing of it is read again before the next footprint() overwrites it
+      if (__builtin_amdgcn_ballot_w64(!cell_is_interior(g, fp)) != 0ull) {
+        Cell cf;
+        make_cell(g, fp, cf);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = cf.i[ax]; fp.w[ax][0] = cf.w[ax][0]; fp.w[ax][1] = cf.w[ax][1]; }
+      }
+    }
+    Cell cell;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
+    // gather: 8 texels as (scalar base + 32-bit offset); the z-neighbour is the immediate
+    unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
+    if (!live || (VOXE_T4_EXP & 1)) off0 = 0u;
+    float4 t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+      t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+    }
+    // layer roles of the deposit: "A" = the layer whose ring slot has parity hm (slot parity == key parity == parity of the
+    // march index: the ring depth is even), "B" the other one; their table entries
+    const int tm = (cell.i[MA] ^ hm) & 1;
+    const int imA = cell.i[MA] + tm, imB = cell.i[MA] + 1 - tm;
+    const int relA = ((imA ^ smask) - smask) + nkey0, relB = ((imB ^ smask) - smask) + nkey0;   // sgn * im - key0
+    const int2 eA = tab[relA & (kTabKeys - 1)], eB = tab[relB & (kTabKeys - 1)];
+    float f0, f1, f2, v;
+    interp_texels4(t, cell, f0, f1, f2, v);
+    asm volatile("" ::"v"(f0), "v"(f1), "v"(f2), "v"(v));   // (consumed HERE, by every lane: see phase 1)
+    // ---- the layer flushed at the end of the previous iteration: its values have long arrived.  The global atomics go out
+    // AFTER this sample's texels are in: vmcnt counts in order, so loads behind an atomic would wait for it, and atomics issued
+    // between the loads and their use make the wait-count pass wait for the atomics as well (they sit in conditional blocks).
+    flush_consume();
     if (on) {
       const float z = z_cur;
       const bool last = (k == Sm1);        // wave-uniform
       const float z_next = last ? z : depth_of(k + 1);
       if (fp.inside) {
-        // the footprint with the zero-padding rule folded in (make_cell), IN PLACE: away from the faces (almost every sample;
-        // wave-uniform test) the footprint is the cell, and nothing of it is read again before the next footprint() overwrites it
-        if (__builtin_amdgcn_ballot_w64(!cell_is_interior(g, fp)) != 0ull) {
-          Cell cf;
-          make_cell(g, fp, cf);
-#pragma unroll
-          for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = cf.i[ax]; fp.w[ax][0] = cf.w[ax][0]; fp.w[ax][1] = cf.w[ax][1]; }
-        }
-        Cell cell;
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
-        // ---- gather: 8 texels as (scalar base + 32-bit offset); the z-neighbour is the immediate --------------------
-        const unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
-        float4 t[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
-          t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
-        }
-        float f0, f1, f2, v;
-        interp_texels4(t, cell, f0, f1, f2, v);
         const float rad[COUT] = {kC0 * f0, kC0 * f1, kC0 * f2};
         float sigma, dpost;
         post_activate_vg(g.post_act, v, sigma, dpost);
@@ -308,17 +357,11 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
         T = T * om;
         if (term_eps > 0.0f && T < term_eps) k_hi = k;   // gradient truncation (not in the reference)
 
-        if (wk != 0.0f || gch[3] != 0.0f) {
+        if (!(VOXE_T4_EXP & 16) && (wk != 0.0f || gch[3] != 0.0f)) {
           // ---- the cell in (march, lateral u, lateral v) order ---------------------------------------------------------
           const int pm = cell.i[MA], pu = cell.i[UA], pv = cell.i[VA];
           const float wm0 = cell.w[MA][0], wm1 = cell.w[MA][1];
           const float wu0 = cell.w[UA][0], wu1 = cell.w[UA][1], wv0 = cell.w[VA][0], wv1 = cell.w[VA][1];
-          // layer roles: "A" = the layer whose ring slot has parity hm (slot parity == key parity == parity of the march index:
-          // the ring depth is even), "B" the other one
-          const int tm = (pm ^ hm) & 1;
-          const int imA = pm + tm, imB = pm + 1 - tm;
-          const int relA = ((imA ^ smask) - smask) + nkey0, relB = ((imB ^ smask) - smask) + nkey0;   // sgn * im - key0
-          const int2 eA = tab[relA & (kTabKeys - 1)], eB = tab[relB & (kTabKeys - 1)];
           const int ouA = (int)(short)(eA.x & 0xffff), ovA = eA.x >> 16, ouB = (int)(short)(eB.x & 0xffff), ovB = eB.x >> 16;
           const int PU0 = pu + k0u, PU1 = pu + k1u, PV0 = pv + k0v, PV1 = pv + k1v;
           const int xA0 = PU0 - ouA, xA1 = PU1 - ouA, yA0 = PV0 - ovA, yA1 = PV1 - ovA;   // {a, a + 1}, {b, b + 1} of layer A
@@ -359,9 +402,11 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
               const double wgt = (double)((bm ? wmuB[bu] : wmuA[bu]) * (bm ? wvB[bv] : wvA[bv]));
               const int idx = (bm ? muB[bu] : muA[bu]) + (bm ? bvB[bv] : bvA[bv]);
 #pragma unroll
-              for (int j = 0; j < 4; ++j)
+              for (int j = 0; j < 4; ++j) {
+                if (VOXE_T4_EXP & 2) { const double pr = gr[j] * wgt; const int ad = idx + CH[bv][j]; asm volatile("" ::"v"(pr), "v"(ad)); continue; }
                 __hip_atomic_fetch_add(reinterpret_cast<double*>(wb + (idx + CH[bv][j])), gr[j] * wgt, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
             }
           } else {
             // Some corner outside the window (oblique tile borders, ring overflow, grid faces): per corner, in natural order --
@@ -409,7 +454,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
     // (one compare per iteration: does ANY lane's next sample still reach layer `base`?)
     if (__ballot(nextkey <= base) == 0ull) {   // wave-uniform
       int n = 0;
-      do { flush_layer4(base + n); ++n; } while (n < kRing && __ballot(nextkey <= base + n) == 0ull);
+      do { flush_consume(); flush_issue(base + n); ++n; } while (n < kRing && __ballot(nextkey <= base + n) == 0ull);
       base = (n == kRing) ? wave_min_dpp(nextkey) : base + n;
       if (base != INT_MAX && base + nkey0 > kTabKeys / 2) {   // re-base the table (everything below `base` is flushed)
         key0 = base;
@@ -418,8 +463,9 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
       }
     }
   }
+  flush_consume();
   if (base != INT_MAX) {
-    for (int i = 0; i < kRing; ++i) flush_layer4(base + i);
+    for (int i = 0; i < kRing; ++i) { flush_issue(base + i); flush_consume(); }
   }
 }
 
