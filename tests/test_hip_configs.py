@@ -468,13 +468,16 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, di
     if case == "lindisp":
         kw.update(linear_disparity=True)
     cfg = make_render_cfg(S_, NEAR, FAR, **kw)
-    disp.set(fwd_window=-1)
+    disp.set(fwd_window=-1, tile_lean=-1)                 # the ray-ordered forward (render_fwd_seg_kernel)
     a = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
-    disp.set(fwd_window=0)
+    disp.set(fwd_window=0, tile_lean=-1)                  # the LDS-window forward (render_fwd_tile_kernel)
     b = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
-    for key in ("colour", "depth", "acc"):
-        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
-    np.testing.assert_array_equal(np.isnan(a["disparity"]), np.isnan(b["disparity"]))
+    disp.set(fwd_window=0, tile_lean=0)                   # r05: the lean tile-ordered forward where it applies (shipped)
+    b5 = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+    for other in (b, b5):
+        for key in ("colour", "depth", "acc"):
+            np.testing.assert_array_equal(a[key], other[key], err_msg=key)
+        np.testing.assert_array_equal(np.isnan(a["disparity"]), np.isnan(other["disparity"]))
     _check_forward(b, vo.render_fwd(grid, cfg, o, d, jitter=jit))
     # the backward consumes the forward's depth-segment states: gradients unchanged
     if case in ("400", "266_oblique"):

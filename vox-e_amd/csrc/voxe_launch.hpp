@@ -86,8 +86,11 @@ void launch_bwd_tile(const DevGrid& g, const HostCfg& c, int deg, int diffuse, c
 // voxe_render_tile4.hip: the lean LDS-window backward of SH-0 image-ordered renders (8-wide window); launch_bwd_tile hands it
 // the launch geometry it computed (blocks, sibling parts, fit bounds)
 bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl);
-void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int nb, int qsplit, float fit_m, float fit_lat,
+void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl, int nb, int qsplit, float fit_m, float fit_lat,
                       hipStream_t st);
+// ... and the forward built the same way (no LDS; per-segment partials into a.segbuf, then the ordinary combine pass)
+bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, int cout, int ncm);
+void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st);
 // LDS-staged forward for SH-0 image-ordered renders: writes the per-segment partials into a.segbuf (the caller then runs
 // the ordinary combine pass)
 bool fwd_tile_supported(const DevGrid& g, const HostCfg& c, int cout, int ncm);

@@ -1201,7 +1201,9 @@ static void launch_fwd_t(const DevGrid& g, const HostCfg& c, const FwdArgs& a, h
     const int nrb64 = c.image_width > 0
                           ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
                           : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64);
-    if (NCU == 1 && fseg == 1 && fwd_tile_supported(g, c, COUT, NCM))
+    if (NCU == 1 && fseg == 1 && fwd_tile4_supported(g, c, a, COUT, NCM))
+      launch_fwd_tile4(g, c, a, st);     // r05: the lean tile-ordered forward (voxe_render_tile4.hip)
+    else if (NCU == 1 && fseg == 1 && fwd_tile_supported(g, c, COUT, NCM))
       launch_fwd_tile(g, c, a, st);      // texels of a tile staged in LDS (voxe_render_tile.hip)
     else
       render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(

@@ -1243,7 +1243,7 @@ static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs&
     } while (0)
     if constexpr (COUT == 3 && NCM == 1 && NCU == 1) {
       if (tile4_bwd_supported(g, c, a, kl)) {   // r05: the lean kernel (voxe_render_tile4.hip), same launch geometry
-        launch_bwd_tile4(g, c, a, nb, qsplit, fit_m, fit_lat, st);
+        launch_bwd_tile4(g, c, a, kl, nb, qsplit, fit_m, fit_lat, st);
         return;
       }
     }

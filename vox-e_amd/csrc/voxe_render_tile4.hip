@@ -121,6 +121,26 @@ __device__ __forceinline__ int wave_min_dpp(int v) {
   return min(min(a, b), min(c, d));
 }
 
+// Orientation of a tile in its wave (wave-uniform): do the 8 consecutive lanes of a row run along the image rows (false) or down
+// the image columns (true)?  The texel gathers are bound by the texture-address / L1 path (~45 clk per divergent 16-byte wave
+// load; profiles/r05_lean_experiments.txt), and what that path sees is how many cache lines a quad / a row of lanes touches: z
+// runs fastest in memory, so consecutive lanes should step along the image axis whose world step has the larger z share (8 pixels
+// x ~0.4 voxel along z = one 128-byte line instead of eight).  Same forward, bit for bit (results are per ray); the backward's
+// parity-class deposit is conflict free for ANY lane -> pixel map.  d0 / dx / dy: directions of pixels (0, 0), (1, 0), (0, 1).
+__device__ __forceinline__ bool tile_lanes_down_columns(const DevGrid& g, const float (&d0)[3], const float (&dx)[3], const float (&dy)[3]) {
+  float ex[3], ey[3];
+  const int N[3] = {g.X, g.Y, g.Z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float s = g.scale[a] * (float)N[a];
+    ex[a] = (dx[a] - d0[a]) * s;
+    ey[a] = (dy[a] - d0[a]) * s;
+  }
+  const float lat_x = ex[0] * ex[0] + ex[1] * ex[1], lat_y = ey[0] * ey[0] + ey[1] * ey[1];
+  // the z share of the column step beats the row step's:  ey.z^2 / lat_y > ex.z^2 / lat_x
+  return (ey[2] * ey[2]) * lat_x > (ex[2] * ex[2]) * lat_y;
+}
+
 // One pass of one (tile, depth segment) with the march axis MA as a compile-time constant.
 template <int MA, int KL>
 __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, const Tile4Args& a, RayCtx<3, 1, 1>& rc,
@@ -213,40 +233,50 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
 #pragma unroll
   for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = 0; fp.w[ax][0] = fp.w[ax][1] = 0.0f; }
   int nextkey = INT_MAX;      // lowest layer key this lane's NEXT sample can write (INT_MAX: no sample left)
-  {
-    // (the first sample index differs from lane to lane: the stratum comes through ds_bpermute instead of v_readlane -- executed
-    //  by ALL lanes: a lane that is switched off supplies nothing to the permute, its readers would get 0)
-    const int j0 = (has ? (k_lo - ks) : 0) << 2;
-    const float lo0 = __int_as_float(__builtin_amdgcn_ds_bpermute(j0, __float_as_int(strat_lo)));
-    const float sp0 = __int_as_float(__builtin_amdgcn_ds_bpermute(j0, __float_as_int(strat_sp)));
-    if (has) {
-      const float su0 = sp0 * jitter_uniform(rc.dg.base, k_lo);
-      z_cur = lo0 + su0;
-      float p[3];
-      rc.point(z_cur, p);
-      footprint(g, p, fp);
-      nextkey = fp.i0[MA] ^ smask;
-    }
+  if (has) {   // (the first sample index differs from lane to lane: its stratum is evaluated per lane, DepthGen's expressions)
+    const float2 st0 = depth_stratum(rc.dg, k_lo);
+    const float su0 = st0.y * jitter_uniform(rc.dg.base, k_lo);
+    z_cur = st0.x + su0;
+    float p[3];
+    rc.point(z_cur, p);
+    footprint(g, p, fp);
+    nextkey = fp.i0[MA] ^ smask;
   }
   int base = wave_min_i32(nextkey);      // lowest live layer key
   int key0 = base;                       // key of table entry 0
   build_tab(key0);
   __syncthreads();                       // window zeroed, table written
 
-  // flush of one layer: 16 voxels x 4 channels per instruction group, KL / 2 groups (two a-rows each)
+  // flush of one layer: 16 voxels x 4 channels per instruction group.  KL == 8: KL / 2 groups of two a-rows each, dealt to the
+  // lanes as 2 x 2 blocks (a layer has ONE slot parity: 2-way bank conflicts are the floor); the LDS / voxel offsets of group j
+  // are those of group 0 plus j times a constant (an immediate / a scalar add).  Other widths: group j = lateral cells
+  // 16 j .. 16 j + 15 in row-major order, per-lane offsets tabulated per pass (the wide window runs at 2 waves per SIMD: the
+  // registers are there).
   const int q4 = lane >> 2, ch4 = lane & 3;
-  const int fa = q4 & 1, fb = q4 >> 1;                           // lateral cell (2 j + fa, fb) of this lane in group j
-  const int flush_lds = ((fa << 1) + (fb >> 1) * (P::SB / 8) + (fb & 1) + (ch4 << 3)) * 8;
-  const unsigned flush_vox = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
+  constexpr int NJ = (KL == 8) ? KL / 2 : (KL * KL + 15) / 16;
+  int fl_lds[KL == 8 ? 1 : NJ];
+  unsigned fl_vox[KL == 8 ? 1 : NJ];
+  if constexpr (KL == 8) {
+    const int fa = q4 & 1, fb = q4 >> 1;                           // lateral cell (2 j + fa, fb) of this lane in group j
+    fl_lds[0] = ((fa << 1) + (fb >> 1) * (P::SB / 8) + (fb & 1) + (ch4 << 3)) * 8;
+    fl_vox[0] = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int ab = j * 16 + q4, fa = ab / KL, fb = ab - fa * KL;
+      const bool cell_live = ab < KL * KL;
+      fl_lds[j] = cell_live ? ((fa >> 1) * P::SA + ((fa & 1) << 4) + (fb >> 1) * P::SB + ((fb & 1) << 3) + (ch4 << 6)) : -1;
+      fl_vox[j] = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
+    }
+  }
   const unsigned long long gaddr = reinterpret_cast<unsigned long long>(a.gpacked);
   const long long sm16 = (long long)stride_m * 16, su16 = (long long)stride_u * 16, sv16 = (long long)stride_v * 16;
   // The flush of a layer is split in two: flush_issue() reads-and-clears the layer (ds_wrxchg_rtn_b64) and keeps the returned
-  // values pending in registers, flush_consume() -- one iteration later, while the next sample's texels are on their way --
-  // converts them and issues the global atomics.  Issued and consumed in one go the wave sat through the LDS queue (the 32 adds
-  // of the sample in front of the exchange) once per iteration: 0.077 of 0.41 ms (timing experiment, profiles/r05_lean_experiments.txt).
-  unsigned long long pend[KL / 2];
+  // values pending in registers, flush_consume() -- one iteration later, after the next sample's texels are in -- converts them
+  // and issues the global atomics (vmcnt counts in order: loads behind an atomic wait for it).
+  unsigned long long pend[NJ];
 #pragma unroll
-  for (int j = 0; j < KL / 2; ++j) pend[j] = 0ull;
+  for (int j = 0; j < NJ; ++j) pend[j] = 0ull;
   unsigned long long pend_vb = 0ull;     // scalar: global byte address of the pending layer's origin voxel
   bool have_pend = false;                // wave-uniform
   auto flush_issue = [&](int key) {      // key wave-uniform
@@ -256,24 +286,35 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
     const int ou = (int)(short)(ex & 0xffff), ov = ex >> 16;
     const int im = sgn * key;
     pend_vb = gaddr + (unsigned long long)((long long)im * sm16 + (long long)ou * su16 + (long long)ov * sv16);   // scalar
-    unsigned long long* const wl = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(win) + (flush_lds + mt));
+    char* const wb = reinterpret_cast<char*>(win);
 #pragma unroll
-    for (int j = 0; j < KL / 2; ++j)
-      pend[j] = __hip_atomic_exchange(wl + j * (P::SA / 8), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int j = 0; j < NJ; ++j) {
+      if constexpr (KL == 8) {
+        pend[j] = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(wb + (fl_lds[0] + mt)) + j * (P::SA / 8), 0ull,
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        pend[j] = 0ull;
+        if (fl_lds[j] >= 0)
+          pend[j] = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(wb + (fl_lds[j] + mt)), 0ull, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
     have_pend = true;
   };
   auto flush_consume = [&]() {
     if (!have_pend) return;              // wave-uniform
 #pragma unroll
-    for (int j = 0; j < KL / 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const double val = __longlong_as_double((long long)pend[j]);
       if (!(VOXE_T4_EXP & 8) && val != 0.0) {
-        global_add_f32(scalar_ptr(pend_vb + (unsigned long long)((long long)j * 2ll * su16)), flush_vox, (float)val);   // scalar base of group j
+        if constexpr (KL == 8)
+          global_add_f32(scalar_ptr(pend_vb + (unsigned long long)((long long)j * 2ll * su16)), fl_vox[0], (float)val);   // scalar base of group j
+        else
+          global_add_f32(scalar_ptr(pend_vb), fl_vox[j], (float)val);
       }
     }
     have_pend = false;
   };
-  static_assert(KL == 8, "flush_issue: the b extent of a group is the 8 lanes q4 >> 1");
 
   const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * 16u : 0u, syb = g.Y > 1 ? (unsigned)g.Z * 16u : 0u;
   const unsigned szb = g.Z > 1 ? 16u : 0u;
@@ -470,7 +511,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
 }
 
 template <int KL>
-__global__ __launch_bounds__(64, VOXE_TILE4_LB) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a) {
+__global__ __launch_bounds__(64, KL >= 9 ? 2 : VOXE_TILE4_LB) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a) {
   __shared__ double win[WinMap<KL, 4>::kDoubles];
   __shared__ int2 tab[kTabKeys];
   const int lane = threadIdx.x;
@@ -488,11 +529,27 @@ __global__ __launch_bounds__(64, VOXE_TILE4_LB) void render_bwd_tile4_kernel(con
   const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
   const int ty = tile / ntx, tx = tile - ty * ntx;
   long long r_px;
-  const bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
-  const long long r = alive ? r_px : 0;
+  bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  long long r = alive ? r_px : 0;
 
   RayCtx<3, 1, 1> rc;
   rc.init(g, c, r, a.rays_o, a.rays_d, nullptr);
+#ifndef VOXE_T4_ORIENT
+#define VOXE_T4_ORIENT 1   // 0: lanes always along the pixel rows
+#endif
+  if (VOXE_T4_ORIENT) {   // lanes along the image rows or down the columns (tile_lanes_down_columns): fewer cache lines per gather
+    const unsigned long long am0 = __ballot(alive);
+    if ((am0 & 1ull) && (am0 >> 1 & 1ull) && (am0 >> 8 & 1ull)) {
+      const float d0[3] = {readlane_f32(rc.d[0], 0), readlane_f32(rc.d[1], 0), readlane_f32(rc.d[2], 0)};
+      const float dx[3] = {readlane_f32(rc.d[0], 1), readlane_f32(rc.d[1], 1), readlane_f32(rc.d[2], 1)};
+      const float dy[3] = {readlane_f32(rc.d[0], 8), readlane_f32(rc.d[1], 8), readlane_f32(rc.d[2], 8)};
+      if (tile_lanes_down_columns(g, d0, dx, dy)) {   // wave-uniform
+        alive = tile_pixel_ray(c, ty, lane & 7, (tx << 3) + (lane >> 3), 8, r_px);
+        r = alive ? r_px : 0;
+        rc.init(g, c, r, a.rays_o, a.rays_d, nullptr);
+      }
+    }
+  }
 
   // ---- does the 8x8 tile fit the lateral window?  (the split decision of render_bwd_tile_kernel) -------------------------
   int split = 0;
@@ -597,24 +654,178 @@ __global__ __launch_bounds__(64, VOXE_TILE4_LB) void render_bwd_tile4_kernel(con
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The forward of the same renders, built the same way (r05): one wave = (8x8-pixel tile, depth segment), all lanes at the same
+// sample index, strata from two VGPRs through v_readlane, gathers as scalar base + 32-bit offset, loads and interpolation in
+// straight-line code.  No LDS: the timing experiments on the backward (profiles/r05_lean_experiments.txt) price its march +
+// per-sample math at 0.13 ms with ~200 VALU instructions per wave-sample and the divergent gathers at 0.02 ms, against 0.21 ms
+// of render_fwd_tile_kernel (LDS texel window: 230 VALU instructions per wave-sample, 4 waves per SIMD by its LDS).  Outputs
+// are the per-segment partials (T, csum, asum, dsum) of render_fwd_seg_kernel, bit for bit: the same expressions in the same
+// order (interp_texels4, post_activate, fast_exp, sigmoidf; depth = stratum lower + span * jitter as SegDepth<true>).
+// ------------------------------------------------------------------------------------------------------------------------
+#ifndef VOXE_FWD4_LB
+#define VOXE_FWD4_LB 4
+#endif
+__global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(const DevGrid g, const DevCfg c,
+                                                                            const float* __restrict__ packed,
+                                                                            const float* __restrict__ rays_o,
+                                                                            const float* __restrict__ rays_d,
+                                                                            float* __restrict__ segbuf) {
+  constexpr int COUT = 3, NC = COUT + 3;
+  const int lane = threadIdx.x;
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nrb = gridDim.x / nseg;                    // tile slots (segment-major block order, like render_fwd_seg_kernel)
+  const int seg = blockIdx.x / nrb, rb = blockIdx.x - seg * nrb;
+  const int W = c.image_width;
+  const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
+  const int tile = logical_tile_of(c, rb, nrb, ntx, nty);
+  if (tile < 0) return;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  long long r_px;
+#ifndef VOXE_F4_EXP
+#define VOXE_F4_EXP 0   // timing experiments: 1 lanes always down the pixel columns | 4 always along the rows | 2 (wrong results) the four z-neighbour loads dropped
+#endif
+  bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  long long r = alive ? r_px : 0;
+  RayCtx<3, 1, 1> rc;
+  rc.init(g, c, r, rays_o, rays_d, nullptr);
+  {
+    const unsigned long long am = __ballot(alive);
+    bool cols = (VOXE_F4_EXP & 1) != 0;
+    if (!(VOXE_F4_EXP & 5) && (am & 1ull) && (am >> 1 & 1ull) && (am >> 8 & 1ull)) {
+      const float d0[3] = {readlane_f32(rc.d[0], 0), readlane_f32(rc.d[1], 0), readlane_f32(rc.d[2], 0)};
+      const float dx[3] = {readlane_f32(rc.d[0], 1), readlane_f32(rc.d[1], 1), readlane_f32(rc.d[2], 1)};
+      const float dy[3] = {readlane_f32(rc.d[0], 8), readlane_f32(rc.d[1], 8), readlane_f32(rc.d[2], 8)};
+      cols = tile_lanes_down_columns(g, d0, dx, dy);
+    }
+    if (cols) {   // wave-uniform
+      alive = tile_pixel_ray(c, ty, lane & 7, (tx << 3) + (lane >> 3), 8, r_px);
+      r = alive ? r_px : 0;
+      rc.init(g, c, r, rays_o, rays_d, nullptr);
+    }
+  }
+  const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
+  const int k_lo = max(rc.k_lo, ks);
+  const int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
+  const bool has = k_lo <= k_hi;
+  const int kmin = wave_min_dpp(has ? k_lo : INT_MAX);
+  const int kmax = -wave_min_dpp(has ? -k_hi : INT_MAX);
+  float csum[COUT] = {0.0f, 0.0f, 0.0f};
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  if (kmin <= kmax) {   // wave-uniform
+    // the strata of this depth segment: lane l holds (lower, span) of sample ks + l (DepthGen's own expressions)
+    float strat_lo = 0.0f, strat_sp = 0.0f;
+    if (ks + lane < c.S && lane <= ke + 1 - ks) {
+      const float2 st = depth_stratum(rc.dg, ks + lane);
+      strat_lo = st.x; strat_sp = st.y;
+    }
+    float z_next = 0.0f;
+    if (has) {   // (the first sample index differs from lane to lane: its stratum is evaluated per lane)
+      const float2 st = depth_stratum(rc.dg, k_lo);
+      const float su = st.y * jitter_uniform(rc.dg.base, k_lo);
+      z_next = st.x + su;
+    }
+    const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * 16u : 0u, syb = g.Y > 1 ? (unsigned)g.Z * 16u : 0u;
+    const unsigned szb = g.Z > 1 ? 16u : 0u;
+    const unsigned sxi = (unsigned)(g.Y * g.Z) * 16u, syi = (unsigned)g.Z * 16u;
+    const char* const pbytes = reinterpret_cast<const char*>(packed);
+    const int Sm1 = c.S - 1;
+    for (int k = kmin; k <= kmax; ++k) {
+      const bool on = has && (k >= k_lo) && (k <= k_hi);
+      const bool last = (k == Sm1);        // wave-uniform
+      const float z = z_next;
+      if (on && !last) {
+        const int j = k + 1 - ks;          // wave-uniform
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(strat_lo), j));
+        const float sp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(strat_sp), j));
+        const float su = sp * jitter_uniform(rc.dg.base, k + 1);
+        z_next = lo + su;
+      }
+      float p[3];
+      rc.point(z, p);
+      Footprint fp;
+      footprint(g, p, fp);
+      const bool live = on && fp.inside;
+      if (__builtin_amdgcn_ballot_w64(live && !cell_is_interior(g, fp)) != 0ull) {   // (rare: a sample next to a grid face)
+        Cell cf;
+        make_cell(g, fp, cf);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = cf.i[ax]; fp.w[ax][0] = cf.w[ax][0]; fp.w[ax][1] = cf.w[ax][1]; }
+      }
+      Cell cell;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
+      unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
+      if (!live) off0 = 0u;
+      float4 t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+        if ((VOXE_F4_EXP & 2) && (q & 4)) { t[q] = t[q - 4]; continue; }
+        t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+      }
+      float f0, f1, f2, v;
+      interp_texels4(t, cell, f0, f1, f2, v);
+      asm volatile("" ::"v"(f0), "v"(f1), "v"(f2), "v"(v));   // (loads consumed by every lane, in straight-line code: see the backward)
+      if (live) {
+        const float rad[COUT] = {kC0 * f0, kC0 * f1, kC0 * f2};
+        const float sigma = post_activate(g.post_act, v);
+        const float dl = last ? kInfinity : (z_next - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        const float alpha = 1.0f - e;
+        const float om = 1.0f - alpha;
+        const float w = alpha * T;
+        T = T * om;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), w, csum[ch]);
+        asum = asum + w;
+        dsum = fmaf(z, w, dsum);
+      }
+    }
+  }
+  if (!alive) return;
+  const long long base = (long long)seg * NC;
+  segbuf[(base + 0) * c.R + r] = T;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) segbuf[(base + 1 + ch) * c.R + r] = csum[ch];
+  segbuf[(base + 1 + COUT) * c.R + r] = asum;
+  segbuf[(base + 2 + COUT) * c.R + r] = dsum;
+}
+
+// the lean forward takes what the lean backward takes (the window width does not matter to it)
+bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, int cout, int ncm) {
+  if (c.disp.tile_lean < 0 || cout != 3 || ncm != 1) return false;
+  if (a.jitter || c.aabb_clip || c.attn || c.image_width <= 0 || !a.segbuf) return false;
+  if (c.seg_len + 1 > 64) return false;
+  const long long bytes = (long long)g.X * g.Y * g.Z * 16;
+  return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);
+}
+void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st) {
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
+  render_fwd_tile4_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf);
+}
+
 // The lean kernel takes: SH-0 grids (4-channel texels), the 8-wide parity-class banked window, float atomics, in-kernel jitter
 // (no caller-supplied uniforms), launch-wide (near, far) (no per-ray AABB bounds), depth segments that fit the strata
 // registers, packed grids below 2 GiB (32-bit byte offsets).  VoxeDispatch::tile_lean = -1 switches it off (A/B, parity tests).
 bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl) {
   if (c.disp.tile_lean < 0) return false;
-  if (kl != 8 || a.gdet || a.jitter || c.aabb_clip || c.attn || c.image_width <= 0) return false;
+  if ((kl != 8 && kl != 10) || a.gdet || a.jitter || c.aabb_clip || c.attn || c.image_width <= 0) return false;
   if (c.seg_len + 1 > 64) return false;
   const long long bytes = (long long)g.X * g.Y * g.Z * 16;
   return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);   // (mad24 operands)
 }
 
-void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int nb, int qsplit, float fit_m, float fit_lat,
+void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl, int nb, int qsplit, float fit_m, float fit_lat,
                       hipStream_t st) {
   Tile4Args t;
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
   t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = a.want_d ? 1 : 0; t.want_f = a.want_f ? 1 : 0;
-  render_bwd_tile4_kernel<8><<<nb, 64, 0, st>>>(g, c, t);
+  if (kl == 10) render_bwd_tile4_kernel<10><<<nb, 64, 0, st>>>(g, c, t);
+  else render_bwd_tile4_kernel<8><<<nb, 64, 0, st>>>(g, c, t);
 }
 
 }  // namespace voxe
