@@ -534,11 +534,12 @@ def main():
         secondary["recon_iteration"] = recon_iteration_bench(max(args.steps, 20))
 
     # ---- same-GPU baseline: a plain PyTorch restatement of the path (the reference's execution model: ~40 ATen ops with
-    # [rays x samples] temporaries + autograd + torch.optim.Adam; voxe_hip/torch_baseline.py, pinned to the reference's
+    # [rays x samples] temporaries + autograd + torch.optim.Adam; tools/torch_baseline.py, pinned to the reference's
     # outputs and gradients by tests/test_torch_baseline.py) under PyTorch-ROCm on this very GPU, outside the timed region ----
     gpu_baseline = None
     if rank == 0 and world == 1 and not args.no_gpu_baseline:
-        from voxe_hip import torch_baseline as tb
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import torch_baseline as tb
 
         torch.cuda.empty_cache()
 

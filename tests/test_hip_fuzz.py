@@ -109,7 +109,8 @@ def test_random_configuration(seed):
     rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, d_acc=gacc, jitter=jitter)
     gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, g_acc=gacc, jitter=jitter, image_width=width)
     for name, got_g, ref_g in (("densities", gd, rd), ("features", gf, rf)):
-        _close(name, got_g, ref_g, far=cfg.far if name == "densities" else 1.0)
+        # (the floor scales with `far` only where a depth gradient is applied: that is what makes the cancelling terms large)
+        _close(name, got_g, ref_g, far=cfg.far if (name == "densities" and np.any(gdep != 0.0)) else 1.0)
 
 
 @pytest.mark.parametrize("seed", range(max(12, int(os.environ.get("VOXE_FUZZ_SEEDS", "40")) // 4)))

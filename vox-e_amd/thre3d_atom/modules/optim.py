@@ -92,6 +92,11 @@ class FusedGridAdam(torch.optim.Optimizer):
         self._dcl = None          # (reference densities, weight): density-correlation regulariser evaluated inside step()
         self.dcl_loss = None      # device scalar: its unweighted value at the last step()
 
+    @property
+    def trains_densities(self) -> bool:
+        """the density tensor of the attached grid receives gradients (set_density_correlation needs it)"""
+        return bool(self._train[0])
+
     def set_density_correlation(self, regular_density, weight: float) -> None:
         """evaluate the SDS edit's density-correlation regulariser (modules/sds_trainer.py:507-524: 1 - corr(densities,
         `regular_density`), times `weight`) INSIDE step(): no autograd node, no [X,Y,Z,1] gradient tensor, no separate gradient

@@ -183,10 +183,12 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
     lr_scheduler = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=lr_gamma)
     # the default regulariser of the edit (density correlation with the pretrained field, sds_trainer.py:305-309 of the
     # reference) is evaluated INSIDE the fused grid step: no autograd node, no gradient tensor, no extra pass over the grid
+    # (only with trainable densities: a features-only edit keeps the autograd term, whose gradient simply goes nowhere; the fused
+    #  step runs with world == 1, where the regularisers' 1 / world scale is 1 -- passed anyway, so the two paths cannot diverge)
     dcl_in_step = (isinstance(optimizer, FusedGridAdam) and not uncoupled_mode and not l2_mode and not l1_mode
-                   and density_correlation_weight != 0.0)
+                   and density_correlation_weight != 0.0 and optimizer.trains_densities)
     if dcl_in_step:
-        optimizer.set_density_correlation(regular_density, density_correlation_weight)
+        optimizer.set_density_correlation(regular_density, density_correlation_weight * (1.0 / world))
     extra_info = {CAMERA_BOUNDS: camera_bounds, CAMERA_INTRINSICS: camera_intrinsics, HEMISPHERICAL_RADIUS: extra_radius}
 
     log.info(f"SDS editing: grid {grid.grid_dims}, image [{im_h} x {im_w}], {num_iterations} iterations")
