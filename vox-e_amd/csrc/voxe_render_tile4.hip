@@ -90,7 +90,9 @@ __device__ __forceinline__ unsigned mad24(unsigned a, unsigned b, unsigned c) {
 typedef __attribute__((address_space(1))) char gchar;
 typedef __attribute__((address_space(1))) float gfloat;
 __device__ __forceinline__ gchar* scalar_ptr(unsigned long long v) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  // (readfirstlane: a no-op for a value the compiler already holds in SGPRs; where its uniformity analysis gave up on a
+  //  loop-carried scalar it is what moves the value there)
+  unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   asm volatile("" : "+s"(lo), "+s"(hi));
   return reinterpret_cast<gchar*>(((unsigned long long)hi << 32) | lo);
 }
@@ -274,19 +276,57 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   // The flush of a layer is split in two: flush_issue() reads-and-clears the layer (ds_wrxchg_rtn_b64) and keeps the returned
   // values pending in registers, flush_consume() -- one iteration later, after the next sample's texels are in -- converts them
   // and issues the global atomics (vmcnt counts in order: loads behind an atomic wait for it).
+  //
+  // Tiles that march along z (kPair): a layer is an (x, y) plane, every one of its voxels sits in its own cache line, and the
+  // memory side retires atomic REQUESTS (lines per instruction; profiles/r01_microbench_atomics.md) -- the flush of such a tile
+  // costs 4 - 8x the requests of an x / y march, whose 8-voxel b-runs are whole lines (camera 12: 0.135 of 0.57 ms, timing
+  // experiment).  Two consecutive layers are z-neighbours, i.e. the SAME lines: the pending layer therefore waits for the next
+  // one, layers with an odd key are read with the two b-halves of the lane map swapped, and one atomic instruction carries
+  // (8 voxels) x (2 layers) x 4 channels -- 32 contiguous bytes per voxel pair, half the requests.
+#ifndef VOXE_T4_ZPAIR
+#define VOXE_T4_ZPAIR 1
+#endif
+  constexpr bool kPair = VOXE_T4_ZPAIR && MA == 2 && KL == 8;
   unsigned long long pend[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) pend[j] = 0ull;
   unsigned long long pend_vb = 0ull;     // scalar: global byte address of the pending layer's origin voxel
-  bool have_pend = false;                // wave-uniform
-  auto flush_issue = [&](int key) {      // key wave-uniform
+  int npend = 0;                         // wave-uniform: pending layers (0 / 1; kPair: up to 2)
+  // (kPair) the second pending layer, the keys' parities, this lane's voxel offsets under both lane maps
+  unsigned long long pendB[kPair ? NJ : 1];
+  unsigned long long pendB_vb = 0ull;
+  int oddA = 0, oddB = 0;
+  const bool lane_hi = lane >= 32;
+  const unsigned step4 = (unsigned)(4 * stride_v * 16);
+  const unsigned vox_b03 = kPair ? fl_vox[0] - (lane_hi ? step4 : 0u) : 0u;   // this lane's voxel with b reduced to 0..3
+  auto flush_issue = [&](int key) __attribute__((always_inline)) {      // key wave-uniform
     if (VOXE_T4_EXP & 4) return;
     const int2 e = tab[key - key0];      // (broadcast read)
     const int ex = rfl(e.x), mt = rfl(e.y);
     const int ou = (int)(short)(ex & 0xffff), ov = ex >> 16;
     const int im = sgn * key;
-    pend_vb = gaddr + (unsigned long long)((long long)im * sm16 + (long long)ou * su16 + (long long)ov * sv16);   // scalar
+    const unsigned long long vb = gaddr + (unsigned long long)((long long)im * sm16 + (long long)ou * su16 + (long long)ov * sv16);   // scalar
     char* const wb = reinterpret_cast<char*>(win);
+    if constexpr (kPair) {
+      const int odd = key & 1;
+      const int lo = (fl_lds[0] ^ (odd ? 2 * P::SB : 0)) + mt;    // odd keys: b <-> b ^ 4  ((b >> 1) * SB: bit 1 of b >> 1)
+      if (npend == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          pend[j] = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(wb + lo) + j * (P::SA / 8), 0ull, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_WORKGROUP);
+        pend_vb = vb; oddA = odd;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          pendB[j] = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(wb + lo) + j * (P::SA / 8), 0ull, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        pendB_vb = vb; oddB = odd;
+      }
+      ++npend;
+      return;
+    }
+    pend_vb = vb;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if constexpr (KL == 8) {
@@ -299,21 +339,56 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
                                           __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
-    have_pend = true;
+    npend = 1;
   };
-  auto flush_consume = [&]() {
-    if (!have_pend) return;              // wave-uniform
+  // one pending layer on its own (kPair: under the lane map its key's parity chose)
+  auto consume_single = [&](const unsigned long long (&pv)[NJ], unsigned long long vb, int odd) __attribute__((always_inline)) {
+    const unsigned vox = kPair ? vox_b03 + ((lane_hi != (odd != 0)) ? step4 : 0u) : fl_vox[0];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const double val = __longlong_as_double((long long)pend[j]);
+      const double val = __longlong_as_double((long long)pv[j]);
       if (!(VOXE_T4_EXP & 8) && val != 0.0) {
         if constexpr (KL == 8)
-          global_add_f32(scalar_ptr(pend_vb + (unsigned long long)((long long)j * 2ll * su16)), fl_vox[0], (float)val);   // scalar base of group j
+          global_add_f32(scalar_ptr(vb + (unsigned long long)((long long)j * 2ll * su16)), vox, (float)val);   // scalar base of group j
         else
-          global_add_f32(scalar_ptr(pend_vb), fl_vox[j], (float)val);
+          global_add_f32(scalar_ptr(vb), fl_vox[j], (float)val);
       }
     }
-    have_pend = false;
+  };
+  // `force`: the march is over (or a third layer is on its way): whatever is pending goes out
+  auto flush_consume = [&](bool force = false) __attribute__((always_inline)) {
+    if (npend == 0) return;              // wave-uniform
+    if constexpr (kPair) {
+      if (npend == 1) {
+        if (!force) return;              // wait for the z-neighbour layer
+        consume_single(pend, pend_vb, oddA);
+        npend = 0;
+        return;
+      }
+      if (oddA == oddB) {                // (not neighbours: the window jumped)
+        consume_single(pend, pend_vb, oddA);
+        consume_single(pendB, pendB_vb, oddB);
+      } else {
+        // lanes with m set carry layer A in the instruction of b 0..3 and layer B in the instruction of b 4..7 (the others
+        // the other way round): A's lanes of b 0..3 are the low half when its key is even, the high half when it is odd
+        const bool m = lane_hi == (oddA != 0);
+        const unsigned long long vmin = pend_vb < pendB_vb ? pend_vb : pendB_vb;
+        const unsigned dA = (unsigned)(pend_vb - vmin), dB = (unsigned)(pendB_vb - vmin);     // scalar, small
+        const unsigned off1 = vox_b03 + (m ? dA : dB), off2 = vox_b03 + step4 + (m ? dB : dA);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const float fA = (float)__longlong_as_double((long long)pend[j]), fB = (float)__longlong_as_double((long long)pendB[j]);
+          const float v1 = m ? fA : fB, v2 = m ? fB : fA;
+          gchar* const gb = scalar_ptr(vmin + (unsigned long long)((long long)j * 2ll * su16));
+          if (!(VOXE_T4_EXP & 8) && v1 != 0.0f) global_add_f32(gb, off1, v1);
+          if (!(VOXE_T4_EXP & 8) && v2 != 0.0f) global_add_f32(gb, off2, v2);
+        }
+      }
+      npend = 0;
+      return;
+    }
+    consume_single(pend, pend_vb, 0);
+    npend = 0;
   };
 
   const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * 16u : 0u, syb = g.Y > 1 ? (unsigned)g.Z * 16u : 0u;
@@ -495,7 +570,12 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
     // (one compare per iteration: does ANY lane's next sample still reach layer `base`?)
     if (__ballot(nextkey <= base) == 0ull) {   // wave-uniform
       int n = 0;
-      do { flush_consume(); flush_issue(base + n); ++n; } while (n < kRing && __ballot(nextkey <= base + n) == 0ull);
+      do {
+        if (!kPair || npend == 2) flush_consume(true);   // (room for the layer about to be read)
+        flush_issue(base + n);
+        if (VOXE_T4_ZPAIR == 2 && kPair && npend == 2) flush_consume(true);   // (experiment: the pair goes out at once, pendB is not loop carried)
+        ++n;
+      } while (n < kRing && __ballot(nextkey <= base + n) == 0ull);
       base = (n == kRing) ? wave_min_dpp(nextkey) : base + n;
       if (base != INT_MAX && base + nkey0 > kTabKeys / 2) {   // re-base the table (everything below `base` is flushed)
         key0 = base;
@@ -504,9 +584,13 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
       }
     }
   }
-  flush_consume();
+  flush_consume(true);
   if (base != INT_MAX) {
-    for (int i = 0; i < kRing; ++i) { flush_issue(base + i); flush_consume(); }
+    for (int i = 0; i < kRing; ++i) {
+      flush_issue(base + i);
+      if (!kPair || npend == 2) flush_consume(true);
+    }
+    flush_consume(true);
   }
 }
 
