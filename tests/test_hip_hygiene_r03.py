@@ -85,6 +85,37 @@ def test_gradient_error_per_magnitude_band_at_bench_size(route, disp):
         assert stray.size == 0 or float(stray.max()) <= 1e-12 * float(np.abs(ref).max()), (route, name, float(stray.max()))
 
 
+# VoxeDispatch::precise_grad (r05, lean tile kernels): the density bars of the reference-accuracy mode -- <= 3e-6 median per band
+# (measured 2.0e-6 / 1.4e-6 / 1.6e-6, profiles/r05_band_probe.txt; default mode 9.6e-6 / 8.0e-6 / 9.3e-6), 99th percentile
+# per band <= 1e-4 / 3e-4 / 1e-3 (measured 4.7e-5 / 1.1e-4 / 5.6e-4; default 2.9e-4 / 1.0e-3 / 5.2e-3).  What is left comes from
+# the float states at the segment boundaries; the reference's own float32 autograd holds 4e-7 against the same oracle.
+PRECISE_DENSITY_MEDIAN = 3e-6
+PRECISE_DENSITY_P99 = {(1e-3, 1.0): 1e-4, (1e-6, 1e-3): 3e-4, (1e-9, 1e-6): 1e-3}
+
+
+def test_precise_grad_density_bands_at_bench_size(disp):
+    """VoxeDispatch::precise_grad = 1 on the image-ordered SH-0 render: density gradients per magnitude band at the tighter
+    bars, forward outputs bit-identical to the default mode, features unchanged"""
+    grid = _grid()
+    o, d = _rays(400, 3)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=42, rng_offset=7)
+    gc_ = np.random.default_rng(43).standard_normal((o.shape[0], 3)).astype(np.float32)
+    f0 = gh.hip_forward(grid, cfg, o, d, rng=(42, 7), image_width=400)
+    disp.set(precise_grad=1)
+    f1 = gh.hip_forward(grid, cfg, o, d, rng=(42, 7), image_width=400)
+    for key in ("colour", "depth", "acc"):
+        np.testing.assert_array_equal(f0[key], f1[key], err_msg=key)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc_, rng=(42, 7), image_width=400)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc_)
+    assert rel_l2(gd, rd) < 1e-5 and rel_l2(gf, rf) < 1e-5
+    bands = band_errors(gd, rd, list(BAND_BARS["densities"]))
+    assert len(bands) == 3, bands
+    for (lo, hi), (count, median, p99) in bands.items():
+        assert count > 1000 and median < PRECISE_DENSITY_MEDIAN and p99 < PRECISE_DENSITY_P99[(lo, hi)], ((lo, hi), count, median, p99)
+    for (lo, hi), (count, median, p99) in band_errors(gf, rf, list(BAND_BARS["features"])).items():
+        assert median < BAND_BARS["features"][(lo, hi)], ("features", (lo, hi), median)
+
+
 @pytest.mark.parametrize("case", ["random_batch", "sparse_image", "generic_bin"])
 def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, disp):
     """the segment tables the production forward writes: (a) every sample the ORACLE's probe calls inside belongs to

@@ -21,6 +21,9 @@ inv = np.argsort(perm)
 rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
 res = {}
 res["tile"] = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, 7), image_width=400)
+# VoxeDispatch::precise_grad (r05): the in-segment suffix sums from the forward's segment-local sums in double
+res["tile_precise"] = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, 7), image_width=400, dispatch=Dispatch(precise_grad=1))
+res["tile_general_kernel"] = gh.hip_backward(grid, cfg, o, d, gc, rng=(42, 7), image_width=400, dispatch=Dispatch(tile_lean=-1))
 # NOTE: the in-kernel jitter is keyed by ray index: a permuted batch draws other jitter -> compare permuted runs with an oracle run on the permuted rays
 op, dp, gp = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm]), np.ascontiguousarray(gc[perm])
 rdp, rfp = vo.render_bwd(grid, cfg, op, dp, gp)
@@ -28,7 +31,7 @@ res["region"] = gh.hip_backward(grid, cfg, op, dp, gp, rng=(42, 7), dispatch=Dis
 res["scatter"] = gh.hip_backward(grid, cfg, op, dp, gp, rng=(42, 7), dispatch=Dispatch(region_min_rays=-1))
 bands = [(1e-3, 1.0), (1e-6, 1e-3), (1e-9, 1e-6)]
 for k, (gd, gf) in res.items():
-    r_d, r_f = (rd, rf) if k == "tile" else (rdp, rfp)
+    r_d, r_f = (rd, rf) if k.startswith("tile") else (rdp, rfp)
     print(k, "rel_l2", rel_l2(gd, r_d), rel_l2(gf, r_f))
     for nm, got, ref in (("dens", gd, r_d), ("feat", gf, r_f)):
         print("  ", nm, {b: tuple(f"{x:.2e}" if isinstance(x, float) else x for x in v) for b, v in band_errors(got, ref, bands).items()})

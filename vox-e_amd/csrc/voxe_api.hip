@@ -112,7 +112,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, seg_off, src_off, fwdval_off, det_off, region_off, fwd_total, total, total_with_src;
+  size_t packed_off, grad_off, state_off, seg_off, prec_off, src_off, fwdval_off, det_off, region_off, fwd_total, total, total_with_src;
   bool region;   // the space-binned backward applies to (grid, cfg, R): its scratch is part of the workspace
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
@@ -132,7 +132,11 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   const size_t seg = align_up((size_t)nseg * (size_t)(cout + 3) * (size_t)(R > 0 ? R : 0) * sizeof(float), 256);
   l.seg_off = bytes + gbytes + state;
   l.fwd_total = bytes;  // the forward alone needs only the packed grid (states / segments are used when they fit)
-  l.total = bytes + gbytes + state + seg;
+  // VoxeDispatch::precise_grad: segment-local sums of the forward in double, nseg x 5 doubles per ray (lean tile kernels)
+  const bool precise = c && disp_of(c).precise_grad > 0 && c->image_width > 0 && cout == 3;
+  const size_t prec = precise ? align_up((size_t)nseg * 5 * (size_t)(R > 0 ? R : 0) * sizeof(double), 256) : 0;
+  l.prec_off = bytes + gbytes + state + seg;
+  l.total = bytes + gbytes + state + seg + prec;
   // per-sample gradient sources of the two-phase backward of view-dependent grids (optional: without it the channel
   // groups re-march the segment)
   l.src_off = l.total;
@@ -307,6 +311,7 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
   a.keep_samples = cfg->ray_state_valid >= 0;
+  if (segbuf && l.total > l.prec_off && cfg->ray_state_valid >= 0) a.segsum_d = (double*)((char*)workspace + l.prec_off);
   if (cfg->ray_state_valid >= 0 && tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp))
     a.sample_fwd = (float*)((char*)workspace + l.fwdval_off);   // (what render_bwd_common's two-phase backward will read)
   if (l.region && workspace_bytes >= l.total_with_src) {
@@ -348,6 +353,7 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp);
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
+    if (l.total > l.prec_off) a.segsum_d = (const double*)((char*)workspace + l.prec_off);
     const bool two_phase = tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp);
     if (two_phase) {
       a.sample_src = (float*)((char*)workspace + l.src_off);
@@ -375,6 +381,7 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
                 (float*)((char*)workspace + l.seg_off)};
       if (two_phase) f.sample_fwd = (float*)((char*)workspace + l.fwdval_off);
+      if (l.total > l.prec_off) f.segsum_d = (double*)((char*)workspace + l.prec_off);
       launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, s);
     }
     PhaseTimer t(PH_BWD, s);

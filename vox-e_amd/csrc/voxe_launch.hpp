@@ -18,6 +18,9 @@ struct FwdArgs {
   // space-binned route, view-dependent grids: keep (rad, v) of every sample in the route's own scratch for the backward's source
   // pass (false: inference, VoxeRenderCfg::ray_state_valid = -1)
   bool keep_samples = true;
+  // VoxeDispatch::precise_grad (lean tile kernels): per (segment, component, ray) the segment-LOCAL sums (csum[3], asum, dsum) of
+  // the forward accumulated in double over the exact products (nullable)
+  double* segsum_d = nullptr;
 };
 struct BwdArgs {
   const float *packed, *rays_o, *rays_d, *jitter, *colour, *depth, *acc, *d_colour, *d_depth, *d_acc;
@@ -30,6 +33,7 @@ struct BwdArgs {
   // (max |contribution| of features / density as float bits, then their power-of-two scales); see det_bytes()
   unsigned long long* gdet = nullptr;
   float* det_scale = nullptr;
+  const double* segsum_d = nullptr;   // FwdArgs::segsum_d of the forward of the SAME rays (VoxeDispatch::precise_grad), or null
 };
 // Launch-constant device config + the dispatch decisions of THIS call (VoxeRenderCfg::dispatch, NULL = all defaults): kernels
 // take the DevCfg base by value, host-side predicates and launchers read `disp` through the accessors below (0 = default).

@@ -53,6 +53,7 @@ struct Tile4Args {
   int qsplit;
   float fit_m, fit_lat;
   int want_d, want_f;
+  const double* segsum;   // PREC kernels: the forward's segment-local sums in double (FwdArgs::segsum_d)
 };
 
 constexpr int kTabKeys = 64;     // layer keys tabulated per pass (re-based when the window has moved 32 layers)
@@ -144,7 +145,13 @@ __device__ __forceinline__ bool tile_lanes_down_columns(const DevGrid& g, const 
 }
 
 // One pass of one (tile, depth segment) with the march axis MA as a compile-time constant.
-template <int MA, int KL>
+// PREC (VoxeDispatch::precise_grad): the suffix sum behind sample k, sum_{j > k} dL/dw_j w_j, is what remains of the segment's
+// LOCAL sums (double, from the forward: the same float products, subtracted here in the same order -- exact to 1e-16 of the
+// segment's sum, whatever the transmittance does inside the segment) scaled by the transmittance at the segment start, plus
+// the saved suffix of the NEXT boundary (summed back to front by the combine pass: accurate relative to itself).  The default
+// path takes (suffix at the segment start) - (float running sum): relative error 1e-7 / (T_k / T_start), i.e. the density
+// gradients of samples behind a dense stretch of the same segment are off by 1e-5 (median, profiles/r05_band_probe.txt).
+template <int MA, int KL, bool PREC>
 __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, const Tile4Args& a, RayCtx<3, 1, 1>& rc,
                                            double* __restrict__ win, int2* __restrict__ tab, const int lane, const long long r,
                                            bool has, const int k_lo, int k_hi, const int kmin, const int kmax, const int seg,
@@ -185,6 +192,30 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
       for (int ch = 0; ch < COUT; ++ch) suffix0 += gc[ch] * suf_c[ch];
       if (white) suffix0 -= gsum * suf_a;
     }
+  }
+  float suffix_next = 0.0f, T_start = 1.0f, Tl = 1.0f;
+  double rem = 0.0;     // what is left of the segment's local sum of dL/dw_j w_j (double; ONE value: five would not fit the registers)
+  if constexpr (PREC) {
+    constexpr int NC = COUT + 3;
+    const int nseg_p = num_segments(c.S, c.seg_len);
+    T_start = T;
+    if (seg + 1 < nseg_p) {
+      suffix_next = gdep * a.ray_state[ray_state_index(seg + 1, 2 + COUT, NC, c.R, r)] +
+                    gacc * a.ray_state[ray_state_index(seg + 1, 1 + COUT, NC, c.R, r)];
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) suffix_next += gc[ch] * a.ray_state[ray_state_index(seg + 1, 1 + ch, NC, c.R, r)];
+      if (white) suffix_next -= gsum * a.ray_state[ray_state_index(seg + 1, 1 + COUT, NC, c.R, r)];
+    }
+    // the segment's sum of dL/dw_j w_j (local weights) from the forward's component sums, in double; the march subtracts
+    // dL/dw_j w_j sample by sample with dL/dw_j ALSO formed in double from the same float inputs: what remains is exact to
+    // 1e-16 of the component sums
+    const double* const ss = a.segsum + (long long)seg * 5 * c.R + r;
+    const double sa = ss[3 * c.R];
+    rem = (double)gdep * ss[4 * c.R] + ((double)gacc - (double)(white ? gsum : 0.0f)) * sa;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) rem = fma((double)gc[ch], ss[(long long)ch * c.R], rem);
+    // (the suffix behind the segment rides along in local units: suffix_k = T_start (rem_k + suffix_next / T_start))
+    rem += T_start > 0.0f ? (double)suffix_next / (double)T_start : 0.0;
   }
   const float gsumw = white ? gsum : 0.0f;                      // (x - 0 == x: the white-background term without a branch)
   float gcf[COUT];                                               // d rad_c = (w g_c) (col (1 - col)) C0, C0 folded into g_c's copy
@@ -457,28 +488,50 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
         const float e = fast_exp(-(sigma * delta));
         const float alpha = 1.0f - e;
         const float om = 1.0f - alpha;
-        const float wk = alpha * T;
-        float col[COUT], dldw = fmaf(gdep, z, gacc);
+        float col[COUT], dldw, wk, suffix, Tk;
 #pragma unroll
-        for (int ch = 0; ch < COUT; ++ch) { col[ch] = sigmoidf(rad[ch]); dldw = fmaf(gc[ch], col[ch], dldw); }
-        dldw -= gsumw;
-        run = fmaf(dldw, wk, run);
-        const float suffix = last ? 0.0f : (suffix0 - run);
+        for (int ch = 0; ch < COUT; ++ch) col[ch] = sigmoidf(rad[ch]);
+        if constexpr (PREC) {
+          const float wl = alpha * Tl;                       // the forward's local weight, bit for bit
+          double dd = fma((double)gdep, (double)z, (double)gacc);
+#pragma unroll
+          for (int ch = 0; ch < COUT; ++ch) dd = fma((double)gc[ch], (double)col[ch], dd);
+          dd -= (double)gsumw;
+          rem = fma(-dd, (double)wl, rem);
+          dldw = (float)dd;
+          suffix = last ? 0.0f : T_start * (float)rem;
+          Tk = T_start * Tl;
+          wk = T_start * wl;
+          Tl = Tl * om;
+        } else {
+          dldw = fmaf(gdep, z, gacc);
+#pragma unroll
+          for (int ch = 0; ch < COUT; ++ch) dldw = fmaf(gc[ch], col[ch], dldw);
+          dldw -= gsumw;
+          Tk = T;
+          wk = alpha * T;
+          run = fmaf(dldw, wk, run);
+          suffix = last ? 0.0f : (suffix0 - run);
+        }
         const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
-        const float dsig = (delta * e) * fmaf(T, dldw, -tail);
+        const float dsig = (delta * e) * fmaf(Tk, dldw, -tail);
         float gch[4];
 #pragma unroll
         for (int ch = 0; ch < COUT; ++ch) gch[ch] = ((wk * gcf[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0;
         gch[3] = (dsig * dpost) * dmask;
-        T = T * om;
-        if (term_eps > 0.0f && T < term_eps) k_hi = k;   // gradient truncation (not in the reference)
+        if constexpr (PREC) { if (term_eps > 0.0f && Tk * om < term_eps) k_hi = k; }
+        else { T = T * om; if (term_eps > 0.0f && T < term_eps) k_hi = k; }   // gradient truncation (not in the reference)
 
         if (!(VOXE_T4_EXP & 16) && (wk != 0.0f || gch[3] != 0.0f)) {
           // ---- the cell in (march, lateral u, lateral v) order ---------------------------------------------------------
           const int pm = cell.i[MA], pu = cell.i[UA], pv = cell.i[VA];
           const float wm0 = cell.w[MA][0], wm1 = cell.w[MA][1];
           const float wu0 = cell.w[UA][0], wu1 = cell.w[UA][1], wv0 = cell.w[VA][0], wv1 = cell.w[VA][1];
-          const int ouA = (int)(short)(eA.x & 0xffff), ovA = eA.x >> 16, ouB = (int)(short)(eB.x & 0xffff), ovB = eB.x >> 16;
+          // (the table entries stay packed until HERE: left alone the compiler derives the eight window coordinates right behind
+          //  the LDS reads of phase 1 and carries them -- eight registers for two -- across the whole per-sample math)
+          int eAx = eA.x, eBx = eB.x;
+          asm volatile("" : "+v"(eAx), "+v"(eBx));
+          const int ouA = (int)(short)(eAx & 0xffff), ovA = eAx >> 16, ouB = (int)(short)(eBx & 0xffff), ovB = eBx >> 16;
           const int PU0 = pu + k0u, PU1 = pu + k1u, PV0 = pv + k0v, PV1 = pv + k1v;
           const int xA0 = PU0 - ouA, xA1 = PU1 - ouA, yA0 = PV0 - ovA, yA1 = PV1 - ovA;   // {a, a + 1}, {b, b + 1} of layer A
           const int xB0 = PU0 - ouB, xB1 = PU1 - ouB, yB0 = PV0 - ovB, yB1 = PV1 - ovB;
@@ -594,8 +647,11 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   }
 }
 
-template <int KL>
-__global__ __launch_bounds__(64, KL >= 9 ? 2 : VOXE_TILE4_LB) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a) {
+template <int KL, bool PREC>
+#ifndef VOXE_TILE4_LB_PREC
+#define VOXE_TILE4_LB_PREC 2   // the precise kernels at 3 waves per SIMD spill inside the sample loop (0.64 vs 0.50 ms on the bench camera)
+#endif
+__global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE_TILE4_LB)) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a) {
   __shared__ double win[WinMap<KL, 4>::kDoubles];
   __shared__ int2 tab[kTabKeys];
   const int lane = threadIdx.x;
@@ -715,9 +771,9 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : VOXE_TILE4_LB) void render_bwd_ti
       geo.Bu = DUu * inv; geo.Au = U0u - geo.Bu * U0m;
       geo.Bv = DUv * inv; geo.Av = U0v - geo.Bv * U0m;
     }
-    if (m == 0) bwd4_march<0, KL>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
-    else if (m == 1) bwd4_march<1, KL>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
-    else bwd4_march<2, KL>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+    if (m == 0) bwd4_march<0, KL, PREC>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+    else if (m == 1) bwd4_march<1, KL, PREC>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+    else bwd4_march<2, KL, PREC>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
   };
   auto in_part = [&](int q) {
     const int hx = (lane >> 2) & 1, hy = (lane >> 5) & 1;
@@ -750,11 +806,16 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : VOXE_TILE4_LB) void render_bwd_ti
 #ifndef VOXE_FWD4_LB
 #define VOXE_FWD4_LB 4
 #endif
+// PREC (VoxeDispatch::precise_grad): besides the float partials (unchanged, bit for bit) the segment-LOCAL sums of w col_c, w and
+// z w are accumulated in double over the exact products and stored per (segment, component, ray): the backward subtracts the
+// same products in the same order and gets the in-segment suffix sums without cancellation (see bwd4_march).
+template <bool PREC>
 __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(const DevGrid g, const DevCfg c,
                                                                             const float* __restrict__ packed,
                                                                             const float* __restrict__ rays_o,
                                                                             const float* __restrict__ rays_d,
-                                                                            float* __restrict__ segbuf) {
+                                                                            float* __restrict__ segbuf,
+                                                                            double* __restrict__ segsum) {
   constexpr int COUT = 3, NC = COUT + 3;
   const int lane = threadIdx.x;
   const int nseg = num_segments(c.S, c.seg_len);
@@ -796,6 +857,7 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
   const int kmax = -wave_min_dpp(has ? -k_hi : INT_MAX);
   float csum[COUT] = {0.0f, 0.0f, 0.0f};
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  double csum_d[COUT] = {0.0, 0.0, 0.0}, asum_d = 0.0, dsum_d = 0.0;
   if (kmin <= kmax) {   // wave-uniform
     // the strata of this depth segment: lane l holds (lower, span) of sample ks + l (DepthGen's own expressions)
     float strat_lo = 0.0f, strat_sp = 0.0f;
@@ -862,13 +924,25 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
         const float w = alpha * T;
         T = T * om;
 #pragma unroll
-        for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(sigmoidf(rad[ch]), w, csum[ch]);
+        for (int ch = 0; ch < COUT; ++ch) {
+          const float col = sigmoidf(rad[ch]);
+          csum[ch] = fmaf(col, w, csum[ch]);
+          if constexpr (PREC) csum_d[ch] = fma((double)col, (double)w, csum_d[ch]);
+        }
         asum = asum + w;
         dsum = fmaf(z, w, dsum);
+        if constexpr (PREC) { asum_d += (double)w; dsum_d = fma((double)z, (double)w, dsum_d); }
       }
     }
   }
   if (!alive) return;
+  if constexpr (PREC) {
+    const long long pb = (long long)seg * 5;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) segsum[(pb + ch) * c.R + r] = csum_d[ch];
+    segsum[(pb + 3) * c.R + r] = asum_d;
+    segsum[(pb + 4) * c.R + r] = dsum_d;
+  }
   const long long base = (long long)seg * NC;
   segbuf[(base + 0) * c.R + r] = T;
 #pragma unroll
@@ -888,7 +962,8 @@ bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, i
 void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
-  render_fwd_tile4_kernel<<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf);
+  if (a.segsum_d) render_fwd_tile4_kernel<true><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, a.segsum_d);
+  else render_fwd_tile4_kernel<false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr);
 }
 
 // The lean kernel takes: SH-0 grids (4-channel texels), the 8-wide parity-class banked window, float atomics, in-kernel jitter
@@ -908,8 +983,12 @@ void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int 
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
   t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = a.want_d ? 1 : 0; t.want_f = a.want_f ? 1 : 0;
-  if (kl == 10) render_bwd_tile4_kernel<10><<<nb, 64, 0, st>>>(g, c, t);
-  else render_bwd_tile4_kernel<8><<<nb, 64, 0, st>>>(g, c, t);
+  t.segsum = a.segsum_d;
+  if (a.segsum_d) {   // VoxeDispatch::precise_grad
+    if (kl == 10) render_bwd_tile4_kernel<10, true><<<nb, 64, 0, st>>>(g, c, t);
+    else render_bwd_tile4_kernel<8, true><<<nb, 64, 0, st>>>(g, c, t);
+  } else if (kl == 10) render_bwd_tile4_kernel<10, false><<<nb, 64, 0, st>>>(g, c, t);
+  else render_bwd_tile4_kernel<8, false><<<nb, 64, 0, st>>>(g, c, t);
 }
 
 }  // namespace voxe
