@@ -533,6 +533,99 @@ def main():
 
         secondary["recon_iteration"] = recon_iteration_bench(max(args.steps, 20))
 
+        # BASELINE.json configs[2]: one SDS-edit iteration without the UNet -- the 266x266 render the edit loop draws per step
+        # (modules/sds_trainer.py:283-340 of the reference: render -> [score distillation: dL/dcolour from the UNet, PyTorch-ROCm]
+        # -> backward -> density-correlation regulariser (weight 200) -> Adam), with a fixed dL/dcolour in place of the network
+        def sds_iteration_bench(iters, hw3=266):
+            d3, f3 = dens.clone(), feat.clone()
+            ref3 = dens.clone()
+            st_d, st_f = (torch.zeros_like(d3), torch.zeros_like(d3)), (torch.zeros_like(f3), torch.zeros_like(f3))
+            p_i = pose_spherical(*synth_pose_angles(args.camera, 100), RADIUS)
+            ro3, rd3 = ops.cast_rays(hw3, hw3, focal_for(hw3), p_i.rotation, p_i.translation, dev)
+            R3 = ro3.shape[0]
+            p3 = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw3)
+            g3 = torch.randn((R3, 3), generator=torch.Generator().manual_seed(46)).to(dev)
+            out3 = [torch.empty((R3, n), dtype=torch.float32, device=dev) for n in (3, 1, 1, 1)]
+            ws3 = ops.Workspace()
+            loss3 = torch.zeros((), dtype=torch.float32, device=dev)
+            cnt = [0]
+
+            def it():
+                cnt[0] += 1
+                rng = (43, cnt[0])
+                ops.render_fwd_into(spec, p3, d3, f3, ro3, rd3, None, *out3, ws3, rng)
+                layout = ops.render_bwd_acc(spec, p3, d3, f3, ro3, rd3, None, out3[0], out3[1], out3[2], g3, None, None, ws3, rng,
+                                            zero_first=(cnt[0] == 1))
+                ops.grid_adam_step_(spec, d3, f3, layout, ws3, cnt[0], 1e-4, state_densities=st_d, state_features=st_f,
+                                    dcl_reference=ref3, dcl_weight=200.0, dcl_loss=loss3)
+
+            gc.collect()
+            gc.disable()
+            for _ in range(10):
+                it()
+            ops.profile_enable(True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(iters):
+                it()
+            torch.cuda.synchronize()
+            e3 = (time.perf_counter() - t3) / iters
+            gc.enable()
+            pr3 = ops.profile_read()
+            ops.profile_enable(False)
+            return {"workload": f"SDS-edit iteration without the UNet: {hw3}x{hw3} render forward + backward (fixed dL/dcolour), "
+                                "density-correlation regulariser inside the fused grid step (BASELINE.json configs[2])",
+                    "ms_per_iteration": round(1e3 * e3, 4), "value": round(R3 / e3, 1), "unit": "rays/s",
+                    "fwd_ms": round(pr3["ms_fwd"] / max(pr3["n_fwd"], 1), 4), "bwd_ms": round(pr3["ms_bwd"] / max(pr3["n_bwd"], 1), 4)}
+
+        # BASELINE.json configs[3]: one iteration of the attention-grid refinement without the UNet
+        # (modules/attn_grid_trainer.py:335-378 of the reference: the two attention renders, masked L1 against the cross-attention
+        # maps, TV on both attention grids, Adam), with fixed maps in place of the network's
+        def refine_iteration_bench(iters, hw3=266):
+            from thre3d_atom.modules.optim import VoxeAdam
+            from thre3d_atom.modules.refinement_functions import calc_loss_on_attn_grid
+
+            spec_a = ops.GridSpec(aabb=((-1.5, 1.5),) * 3, density_scale=100.0 / 3.0, density_pre_act=abi.ACT_IDENTITY,
+                                  density_post_act=abi.ACT_SOFTPLUS, feature_kind=abi.FEAT_ATTN)
+            grids = [torch.full((dens.shape[0], dens.shape[1], dens.shape[2], 1), -2.0, device=dev).requires_grad_(True) for _ in range(2)]
+            opts = [VoxeAdam([{"params": [a_], "lr": 0.035}], betas=(0.9, 0.999)) for a_ in grids]
+            p_i = pose_spherical(*synth_pose_angles(args.camera, 100), RADIUS)
+            ro3, rd3 = ops.cast_rays(hw3, hw3, focal_for(hw3), p_i.rotation, p_i.translation, dev)
+            p3 = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=hw3)
+            maps = [torch.rand((hw3, hw3), generator=torch.Generator().manual_seed(47 + i)).to(dev) for i in range(2)]
+            wss = [ops.Workspace(), ops.Workspace()]
+
+            def it():
+                for a_, o_, m_, w_ in zip(grids, opts, maps, wss):
+                    att, _, _, _ = ops.render(spec_a, p3, dens, a_, ro3, rd3, workspace=w_)
+                    loss = calc_loss_on_attn_grid(att, m_) + ops.tv_loss_on_grid(a_) * 0.01
+                    loss.backward()
+                    o_.step()
+                    o_.zero_grad()
+
+            gc.collect()
+            gc.disable()
+            for _ in range(5):
+                it()
+            ops.profile_enable(True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(iters):
+                it()
+            torch.cuda.synchronize()
+            e3 = (time.perf_counter() - t3) / iters
+            gc.enable()
+            pr3 = ops.profile_read()
+            ops.profile_enable(False)
+            return {"workload": f"attention-refinement iteration without the UNet: two {hw3}x{hw3} attention renders (forward + backward), "
+                                "masked L1, TV on both attention grids, Adam (BASELINE.json configs[3]; torch autograd glue included)",
+                    "ms_per_iteration": round(1e3 * e3, 4), "value": round(2 * hw3 * hw3 / e3, 1), "unit": "rendered rays/s (2 renders, fwd + bwd)",
+                    "fwd_ms_per_render": round(pr3["ms_fwd"] / max(pr3["n_fwd"], 1), 4),
+                    "bwd_ms_per_render": round(pr3["ms_bwd"] / max(pr3["n_bwd"], 1), 4)}
+
+        secondary["sds_iteration"] = sds_iteration_bench(max(args.steps, 20))
+        secondary["refine_iteration"] = refine_iteration_bench(max(args.steps, 20))
+
     # ---- same-GPU baseline: a plain PyTorch restatement of the path (the reference's execution model: ~40 ATen ops with
     # [rays x samples] temporaries + autograd + torch.optim.Adam; tools/torch_baseline.py, pinned to the reference's
     # outputs and gradients by tests/test_torch_baseline.py) under PyTorch-ROCm on this very GPU, outside the timed region ----

@@ -202,7 +202,7 @@ def test_cfg5_row_bands_of_8_ranks_sum_to_the_whole_image(grid256):
 
 # ---- configs[3]: attention-grid render of the refinement loop, 160^3, 266x266 (800 / 3) ---------------------------------
 @pytest.mark.parametrize("hw,cam", [(266, 12), (400, 40)])
-def test_cfg4_attention_render_160_vs_oracle(hw, cam):
+def test_cfg4_attention_render_160_vs_oracle(hw, cam, disp):
     dens, _ = sphere_grid(160)
     attn = (np.random.default_rng(4).standard_normal((160, 160, 160, 1)) - 1.0).astype(np.float32)
     grid = vo.Grid(dens.numpy(), attn, AABB, 100.0 / 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_ATTN)
@@ -210,6 +210,12 @@ def test_cfg4_attention_render_160_vs_oracle(hw, cam):
     cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=3, rng_offset=9)
     out, ref = gh.hip_forward(grid, cfg, o, d, rng=(3, 9), image_width=hw), vo.render_fwd(grid, cfg, o, d)
     _check_forward(out, ref)
+    # r05: the lean tile-ordered forward renders attention grids too (2-channel texels): bit-identical to the ray-ordered forward
+    disp.set(tile_lean=-1)
+    out_ro = gh.hip_forward(grid, cfg, o, d, rng=(3, 9), image_width=hw)
+    disp.set(tile_lean=0)
+    for key in ("colour", "depth", "acc"):
+        np.testing.assert_array_equal(out[key], out_ro[key], err_msg=key)
     ga = np.random.default_rng(5).standard_normal((o.shape[0], 1)).astype(np.float32)
     gd, gf = gh.hip_backward(grid, cfg, o, d, ga, rng=(3, 9), image_width=hw)
     rd, rf = vo.render_bwd(grid, cfg, o, d, ga)

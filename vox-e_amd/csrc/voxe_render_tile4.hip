@@ -809,14 +809,16 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
 // PREC (VoxeDispatch::precise_grad): besides the float partials (unchanged, bit for bit) the segment-LOCAL sums of w col_c, w and
 // z w are accumulated in double over the exact products and stored per (segment, component, ray): the backward subtracts the
 // same products in the same order and gets the in-segment suffix sums without cancellation (see bwd4_march).
-template <bool PREC>
+// COUT = 3: SH-0 colour grids (4-channel texels); COUT = 1: attention grids (2-channel texels: attention value, density)
+template <int COUT, bool PREC>
 __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(const DevGrid g, const DevCfg c,
                                                                             const float* __restrict__ packed,
                                                                             const float* __restrict__ rays_o,
                                                                             const float* __restrict__ rays_d,
                                                                             float* __restrict__ segbuf,
                                                                             double* __restrict__ segsum) {
-  constexpr int COUT = 3, NC = COUT + 3;
+  constexpr int NC = COUT + 3;
+  static_assert(!PREC || COUT == 3, "precise_grad: SH-0 colour renders");
   const int lane = threadIdx.x;
   const int nseg = num_segments(c.S, c.seg_len);
   const int nrb = gridDim.x / nseg;                    // tile slots (segment-major block order, like render_fwd_seg_kernel)
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
 #endif
   bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
   long long r = alive ? r_px : 0;
-  RayCtx<3, 1, 1> rc;
+  RayCtx<COUT, 1, 1> rc;
   rc.init(g, c, r, rays_o, rays_d, nullptr);
   {
     const unsigned long long am = __ballot(alive);
@@ -855,9 +857,12 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
   const bool has = k_lo <= k_hi;
   const int kmin = wave_min_dpp(has ? k_lo : INT_MAX);
   const int kmax = -wave_min_dpp(has ? -k_hi : INT_MAX);
-  float csum[COUT] = {0.0f, 0.0f, 0.0f};
+  float csum[COUT];
+  double csum_d[COUT];
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) { csum[ch] = 0.0f; csum_d[ch] = 0.0; }
   float asum = 0.0f, dsum = 0.0f, T = 1.0f;
-  double csum_d[COUT] = {0.0, 0.0, 0.0}, asum_d = 0.0, dsum_d = 0.0;
+  double asum_d = 0.0, dsum_d = 0.0;
   if (kmin <= kmax) {   // wave-uniform
     // the strata of this depth segment: lane l holds (lower, span) of sample ks + l (DepthGen's own expressions)
     float strat_lo = 0.0f, strat_sp = 0.0f;
@@ -871,9 +876,10 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
       const float su = st.y * jitter_uniform(rc.dg.base, k_lo);
       z_next = st.x + su;
     }
-    const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * 16u : 0u, syb = g.Y > 1 ? (unsigned)g.Z * 16u : 0u;
-    const unsigned szb = g.Z > 1 ? 16u : 0u;
-    const unsigned sxi = (unsigned)(g.Y * g.Z) * 16u, syi = (unsigned)g.Z * 16u;
+    constexpr unsigned TB = (COUT + 1) * 4;   // bytes of a packed texel
+    const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * TB : 0u, syb = g.Y > 1 ? (unsigned)g.Z * TB : 0u;
+    const unsigned szb = g.Z > 1 ? TB : 0u;
+    const unsigned sxi = (unsigned)(g.Y * g.Z) * TB, syi = (unsigned)g.Z * TB;
     const char* const pbytes = reinterpret_cast<const char*>(packed);
     const int Sm1 = c.S - 1;
     for (int k = kmin; k <= kmax; ++k) {
@@ -901,20 +907,43 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
       Cell cell;
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
-      unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
+      unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] * TB));
       if (!live) off0 = 0u;
-      float4 t[8];
+      float fch[COUT], v;
+      if constexpr (COUT == 3) {
+        float4 t[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
-        if ((VOXE_F4_EXP & 2) && (q & 4)) { t[q] = t[q - 4]; continue; }
-        t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+        for (int q = 0; q < 8; ++q) {
+          const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+          if ((VOXE_F4_EXP & 2) && (q & 4)) { t[q] = t[q - 4]; continue; }
+          t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+        }
+        interp_texels4(t, cell, fch[0], fch[1], fch[2], v);
+        asm volatile("" ::"v"(fch[0]), "v"(fch[1]), "v"(fch[2]), "v"(v));   // (loads consumed by every lane, in straight-line code: see the backward)
+      } else {
+        // 2-channel texels: the products and FMA order of gather<1, 1, 1>() (render_fwd_seg_kernel)
+        float2 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+          t[q] = *reinterpret_cast<const float2*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+        }
+        float wxy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wxy[q] = cell.w[0][q & 1] * cell.w[1][q >> 1];
+        fch[0] = 0.0f; v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float w = wxy[q & 3] * cell.w[2][q >> 2];
+          fch[0] = fmaf(t[q].x, w, fch[0]);
+          v = fmaf(t[q].y, w, v);
+        }
+        asm volatile("" ::"v"(fch[0]), "v"(v));
       }
-      float f0, f1, f2, v;
-      interp_texels4(t, cell, f0, f1, f2, v);
-      asm volatile("" ::"v"(f0), "v"(f1), "v"(f2), "v"(v));   // (loads consumed by every lane, in straight-line code: see the backward)
       if (live) {
-        const float rad[COUT] = {kC0 * f0, kC0 * f1, kC0 * f2};
+        float rad[COUT];
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) rad[ch] = kC0 * fch[ch];
         const float sigma = post_activate(g.post_act, v);
         const float dl = last ? kInfinity : (z_next - z);
         const float delta = dl * rc.dnorm;
@@ -939,7 +968,7 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
   if constexpr (PREC) {
     const long long pb = (long long)seg * 5;
 #pragma unroll
-    for (int ch = 0; ch < COUT; ++ch) segsum[(pb + ch) * c.R + r] = csum_d[ch];
+    for (int ch = 0; ch < COUT; ++ch) segsum[(pb + ch) * c.R + r] = csum_d[ch];   // (COUT == 3)
     segsum[(pb + 3) * c.R + r] = asum_d;
     segsum[(pb + 4) * c.R + r] = dsum_d;
   }
@@ -953,8 +982,8 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
 
 // the lean forward takes what the lean backward takes (the window width does not matter to it)
 bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, int cout, int ncm) {
-  if (c.disp.tile_lean < 0 || cout != 3 || ncm != 1) return false;
-  if (a.jitter || c.aabb_clip || c.attn || c.image_width <= 0 || !a.segbuf) return false;
+  if (c.disp.tile_lean < 0 || ncm != 1 || !((cout == 3 && !c.attn) || (cout == 1 && c.attn))) return false;
+  if (a.jitter || c.aabb_clip || c.image_width <= 0 || !a.segbuf) return false;
   if (c.seg_len + 1 > 64) return false;
   const long long bytes = (long long)g.X * g.Y * g.Z * 16;
   return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);
@@ -962,8 +991,9 @@ bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, i
 void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
-  if (a.segsum_d) render_fwd_tile4_kernel<true><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, a.segsum_d);
-  else render_fwd_tile4_kernel<false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr);
+  if (c.attn) render_fwd_tile4_kernel<1, false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr);
+  else if (a.segsum_d) render_fwd_tile4_kernel<3, true><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, a.segsum_d);
+  else render_fwd_tile4_kernel<3, false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr);
 }
 
 // The lean kernel takes: SH-0 grids (4-channel texels), the 8-wide parity-class banked window, float atomics, in-kernel jitter
