@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 8
+#define VOXE_ABI_VERSION 9
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -107,6 +107,8 @@ typedef struct VoxeDispatch {
                                   relative error against a double-precision backward) | 1 = the suffix sums of the
                                   image-ordered SH-0 backward are carried in double (~2e-6, a few percent slower).  Forward
                                   and backward of one render must agree on it (the forward saves the segment states).       */
+  int32_t region_lds_ranks;    /* ABI v9.  Space-binned route, segment pass: 0 = segments are ranked per block in an LDS table
+                                  (no global atomic; grids up to ~200^3) | -1 one returning global atomic per segment (r02)   */
 } VoxeDispatch;
 
 typedef struct VoxeRenderCfg {

@@ -116,12 +116,14 @@ def test_precise_grad_density_bands_at_bench_size(disp):
         assert median < BAND_BARS["features"][(lo, hi)], ("features", (lo, hi), median)
 
 
+@pytest.mark.parametrize("ranks", ["lds_ranks", "global_ranks"])
 @pytest.mark.parametrize("case", ["random_batch", "sparse_image", "generic_bin"])
-def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, disp):
+def test_region_route_every_inside_sample_owned_by_exactly_one_segment(case, ranks, disp):
     """the segment tables the production forward writes: (a) every sample the ORACLE's probe calls inside belongs to
     exactly one segment of its ray; (b) a segment's samples all start in the segment's region (generic bin excepted);
-    (c) the counting sort is a permutation: `sorted` lists every used slot once, inside its region's range"""
-    disp.set(region_min_rays=1)
+    (c) the counting sort is a permutation: `sorted` lists every used slot once, inside its region's range -- with the
+    segments ranked per block in LDS (r05, shipped) and with one returning global atomic per segment (grids above ~200^3)"""
+    disp.set(region_min_rays=1, region_lds_ranks=0 if ranks == "lds_ranks" else -1)
     grid = _grid(96)
     Sn = 128
     if case == "random_batch":

@@ -42,6 +42,7 @@ struct HostCfg : DevCfg {
 };
 inline long long disp_tile_min_rays(const VoxeDispatch& d) { return d.tile_min_rays == 0 ? 8192ll : (d.tile_min_rays < 0 ? 0ll : (long long)d.tile_min_rays); }
 inline long long disp_region_min_rays(const VoxeDispatch& d) { return d.region_min_rays == 0 ? 16384ll : (long long)d.region_min_rays; }   // (< 0: route off)
+inline bool disp_region_lds_ranks(const VoxeDispatch& d) { return d.region_lds_ranks >= 0; }
 inline float disp_region_image_ratio(const VoxeDispatch& d) { return d.region_image_ratio == 0.0f ? 1.3f : (d.region_image_ratio < 0.0f ? 0.0f : d.region_image_ratio); }
 inline float disp_or(float v, float dflt) { return v == 0.0f ? dflt : v; }
 
@@ -111,7 +112,7 @@ void launch_bwd_packed_scatter(const DevGrid& g, const DevCfg& c, int deg, int d
 // window of a region live in LDS)
 bool region_bwd_supported(const DevGrid& g, const HostCfg& c, int deg, int diffuse, bool tiled);
 size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S, bool full_sh);   // full_sh: SH degree 1 / 2, not diffuse
-void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
+void launch_fwd_region(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
                        hipStream_t st);   // segment tables + forward; leaves the per-segment states in `scratch`
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
                        hipStream_t st);   // needs the tables / states of launch_fwd_region for the same rays

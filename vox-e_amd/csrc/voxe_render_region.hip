@@ -129,6 +129,8 @@ struct BinScratch {
   unsigned* count;        // [(nreg + 1) * 4 + 1] segments per (region, length class) (+ generic bin; last entry stays 0)
   unsigned* start;        // [(nreg + 1) * 4 + 1] exclusive scan of `count`: first position in `sorted`; a region's segments are
                           // start[region * 4] .. start[(region + 1) * 4]
+  unsigned long long* blockhist;  // [NB][nreg + 1] region_seg_lds_kernel's per-block counters (4 x 16 bits per region); null: global ranks
+  uint4* blockoff;        // [NB][nreg + 1] per class: segments of the region in the blocks before this one
 };
 
 __device__ __forceinline__ size_t slot_of(size_t lane, unsigned j, long long nlanes) { return (size_t)j * (size_t)nlanes + lane; }
@@ -186,31 +188,37 @@ struct SegRay {
 };
 
 // ---- pass 1: segments (index math only) ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, const float* __restrict__ rays_o,
-                                                        const float* __restrict__ rays_d, const float* __restrict__ jitter,
-                                                        BinScratch bs, const int nreg) {
-  const int lane = threadIdx.x;
+// One UNIT of the pass = one wave = 64 rays (an 8x8 pixel tile of an image-ordered launch) x one depth segment; `vb` numbers the
+// units as the blocks of the r02 launch did (segment-major), `rank(region, class)` hands out the segment's rank.
+//   * region_seg_kernel       (r02)  one unit per 64-thread block; rank = one RETURNING global atomic per segment on the
+//                             (region, class) counters.  The memory side retires ~20 G atomic requests/s whatever the scope
+//                             (profiles/r01_microbench_atomics.md): 1.9 M segments of a reconstruction batch = 139 us, of which the
+//                             index math is 53 (profiles/r05_recon_experiments.txt).  Kept for grids whose region table does not
+//                             fit in LDS (above ~184^3).
+//   * region_seg_lds_kernel   (r05)  1024-thread blocks, each wave walks a run of units; the block ranks its segments in an LDS
+//                             table -- one 64-bit word per region, four 16-bit class counters, ds_add_rtn_u64 -- and leaves the
+//                             table in `blockhist[block][region]`; region_colscan_kernel turns the NB tables into per-block
+//                             offsets and the (region, class) totals.  No global atomic anywhere in the pass.
+template <typename Rank>
+__device__ __forceinline__ void seg_unit(const DevGrid& g, const DevCfg& c, const float* __restrict__ rays_o,
+                                         const float* __restrict__ rays_d, const float* __restrict__ jitter, const BinScratch& bs,
+                                         const int nreg, const int vb, const int nvb, const int lane, const BlockStrata& bst,
+                                         Rank&& rank) {
   const int nseg = num_segments(c.S, c.seg_len);
-  const int nrb = gridDim.x / nseg;
-  const int seg = blockIdx.x / nrb;
-  // depth strata of this block's segment, tabulated once (before any lane leaves)
-  __shared__ float2 strat[64];
-  const int ks_blk = seg * c.seg_len;
-  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA ? 64 : 0, c, ks_blk, min(c.S, ks_blk + c.seg_len) - ks_blk, lane, 64);
-  __syncthreads();
+  const int nrb = nvb / nseg;
+  const int seg = vb / nrb;
   // image-ordered launches (sparse / multi-view images): a wave is an 8x8 pixel tile, so its lanes cross the same regions
-  // at about the same samples and can share their counting atomics (below); unordered rays: 64 consecutive rays
-  const bool coherent = c.image_width > 0;
+  // at about the same samples; unordered rays: 64 consecutive rays
   long long r;
-  if (coherent) {
+  if (c.image_width > 0) {
     const int ntx = (c.image_width + 7) >> 3, nty = (int)tile_rows_total(c, 8);
-    const int t = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, ntx, nty);
+    const int t = logical_tile_of(c, vb - seg * nrb, nrb, ntx, nty);
     if (t < 0) return;
     const int ty = t / ntx, tx = t - ty * ntx;
     if (!tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r)) return;
   } else {
     const int nt = (int)((c.R + 63) / 64);
-    const int logical = logical_tile_of(c, blockIdx.x - seg * nrb, nrb, 1, nt);
+    const int logical = logical_tile_of(c, vb - seg * nrb, nrb, 1, nt);
     if (logical < 0) return;
     r = (long long)logical * 64 + lane;
     if (r >= c.R) return;
@@ -235,34 +243,7 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
     const size_t sl = slot_of((size_t)lane_id, (unsigned)nslots, nlanes);
     bs.slot_region[sl] = cur | (cls << 24);
     bs.slot_seg[sl] = make_uint2((unsigned)r, (unsigned)k0 | ((unsigned)k_end << 16));
-    const unsigned key = cur * kLenClasses + cls;
-    unsigned pos;
-    if (coherent) {
-      // wave-aggregated ranking: the lanes that close a segment in the same loop trip group by counter; one returning
-      // atomic per group (its first lane) instead of one per lane -- the memory side retires ~20 G atomic requests/s and
-      // this pass is bound by exactly that (2.3 M segments on the 8-camera launch)
-      unsigned long long todo = __ballot(1);
-      int leader = lane;
-      unsigned rank = 0, size = 1;
-      while (todo) {
-        const int l = __ffsll((long long)todo) - 1;
-        const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)key, l);
-        const unsigned long long m = __ballot(key == key_l) & todo;
-        if (key == key_l) {
-          leader = l;
-          rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-          size = (unsigned)__popcll(m);
-        }
-        todo &= ~m;
-      }
-      unsigned base = 0;
-      if (lane == leader) base = atomicAdd(bs.count + key, size);
-      base = (unsigned)__shfl((int)base, leader, 64);
-      pos = base + rank;
-    } else {
-      pos = atomicAdd(bs.count + key, 1u);   // rank inside (region, class)
-    }
-    bs.slot_pos[sl] = pos;
+    bs.slot_pos[sl] = rank(cur, cls);
     ++nslots;
   };
   for (int k = k_lo; k <= k_hi; ++k) {
@@ -285,6 +266,124 @@ __global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, con
   }
   emit(k_prev);
   bs.lane_n[lane_id] = (unsigned)nslots;
+}
+
+__global__ __launch_bounds__(64) void region_seg_kernel(DevGrid g, DevCfg c, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, const float* __restrict__ jitter,
+                                                        BinScratch bs, const int nreg) {
+  const int lane = threadIdx.x;
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int seg = blockIdx.x / (gridDim.x / nseg);
+  // depth strata of this block's segment, tabulated once (before any lane leaves)
+  __shared__ float2 strat[64];
+  const int ks_blk = seg * c.seg_len;
+  const BlockStrata bst = build_block_strata(strat, VOXE_REGION_STRATA ? 64 : 0, c, ks_blk, min(c.S, ks_blk + c.seg_len) - ks_blk, lane, 64);
+  __syncthreads();
+  const bool coherent = c.image_width > 0;
+  seg_unit(g, c, rays_o, rays_d, jitter, bs, nreg, (int)blockIdx.x, (int)gridDim.x, lane, bst, [&](unsigned cur, unsigned cls) {
+    const unsigned key = cur * kLenClasses + cls;
+    unsigned pos;
+    if (coherent) {
+      // wave-aggregated ranking: the lanes that close a segment in the same loop trip group by counter; one returning
+      // atomic per group (its first lane) instead of one per lane
+      unsigned long long todo = __ballot(1);
+      int leader = lane;
+      unsigned rank = 0, size = 1;
+      while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const unsigned key_l = (unsigned)__builtin_amdgcn_readlane((int)key, l);
+        const unsigned long long m = __ballot(key == key_l) & todo;
+        if (key == key_l) {
+          leader = l;
+          rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+          size = (unsigned)__popcll(m);
+        }
+        todo &= ~m;
+      }
+      unsigned base = 0;
+      if (lane == leader) base = atomicAdd(bs.count + key, size);
+      base = (unsigned)__shfl((int)base, leader, 64);
+      pos = base + rank;
+    } else {
+      pos = atomicAdd(bs.count + key, 1u);   // rank inside (region, class)
+    }
+    return pos;
+  });
+}
+
+// r05: block-local ranking in LDS.  slot_pos = rank inside (block, region, class) | block << 16; the fill pass adds
+// blockoff[block][region].class and start[region, class].  A block never sees 65 536 segments (the host bounds its lanes).
+constexpr int kSegLdsThreads = 1024, kSegLdsWaves = kSegLdsThreads / 64;
+__global__ __launch_bounds__(kSegLdsThreads) void region_seg_lds_kernel(DevGrid g, DevCfg c, const float* __restrict__ rays_o,
+                                                                        const float* __restrict__ rays_d,
+                                                                        const float* __restrict__ jitter, BinScratch bs,
+                                                                        const int nreg, const int nvb, const int units_per_wave) {
+  extern __shared__ unsigned long long seg_hist[];   // [nreg + 1]: class c of a region in bits 16 c .. 16 c + 15
+  __shared__ float2 strat_all[kSegLdsWaves][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i <= nreg; i += kSegLdsThreads) seg_hist[i] = 0ull;
+  __syncthreads();
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nrb = nvb / nseg;
+  const int u0 = ((int)blockIdx.x * kSegLdsWaves + wave) * units_per_wave;
+  int seg_tab = -1;
+  float2* const strat = strat_all[wave];
+  BlockStrata bst{strat, 0, false};
+  for (int u = u0; u < min(nvb, u0 + units_per_wave); ++u) {
+    const int seg = u / nrb;
+    if (seg != seg_tab) {   // (wave-uniform; the wave's lanes have re-converged here)
+      seg_tab = seg;
+      const int ks_blk = seg * c.seg_len;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      bst = build_block_strata(strat, VOXE_REGION_STRATA ? 64 : 0, c, ks_blk, min(c.S, ks_blk + c.seg_len) - ks_blk, lane, 64);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    seg_unit(g, c, rays_o, rays_d, jitter, bs, nreg, u, nvb, lane, bst, [&](unsigned cur, unsigned cls) {
+      const unsigned long long old = atomicAdd(&seg_hist[cur], 1ull << (16 * cls));
+      return ((unsigned)(old >> (16 * cls)) & 0xFFFFu) | ((unsigned)blockIdx.x << 16);
+    });
+  }
+  __syncthreads();
+  unsigned long long* __restrict__ out = bs.blockhist + (size_t)blockIdx.x * (size_t)(nreg + 1);
+  for (int i = tid; i <= nreg; i += kSegLdsThreads) out[i] = seg_hist[i];
+}
+
+// Per-block offsets and totals from the NB block tables: thread = (region, chunk of NB / 16 consecutive blocks); the 16 chunk
+// sums of a region meet in LDS.  blockoff[b][region] = segments of (region, class) in blocks < b; count[region * 4 + class] = total.
+constexpr int kColRegions = 64, kColChunks = 16;
+__global__ __launch_bounds__(kColRegions * kColChunks) void region_colscan_kernel(BinScratch bs, const int nreg, const int nb) {
+  __shared__ uint4 chunk_sum[kColChunks][kColRegions];
+  const int rl = threadIdx.x % kColRegions, q = threadIdx.x / kColRegions;
+  const int region = (int)blockIdx.x * kColRegions + rl;
+  const int per = nb / kColChunks;               // (the host launches a multiple of 16 blocks)
+  const bool live = region <= nreg;
+  const size_t stride = (size_t)(nreg + 1);
+  const unsigned long long* __restrict__ h = bs.blockhist + (size_t)(q * per) * stride + (size_t)region;
+  uint4 sum = make_uint4(0u, 0u, 0u, 0u);
+  if (live) {
+#pragma unroll 4
+    for (int i = 0; i < per; ++i) {
+      const unsigned long long v = h[(size_t)i * stride];
+      sum.x += (unsigned)v & 0xFFFFu; sum.y += (unsigned)(v >> 16) & 0xFFFFu;
+      sum.z += (unsigned)(v >> 32) & 0xFFFFu; sum.w += (unsigned)(v >> 48);
+    }
+  }
+  chunk_sum[q][rl] = sum;
+  __syncthreads();
+  if (!live) return;
+  uint4 run = make_uint4(0u, 0u, 0u, 0u);
+  for (int j = 0; j < q; ++j) { const uint4 t = chunk_sum[j][rl]; run.x += t.x; run.y += t.y; run.z += t.z; run.w += t.w; }
+  uint4* __restrict__ o = bs.blockoff + (size_t)(q * per) * stride + (size_t)region;
+#pragma unroll 4
+  for (int i = 0; i < per; ++i) {
+    const unsigned long long v = h[(size_t)i * stride];    // (second read: L2)
+    o[(size_t)i * stride] = run;
+    run.x += (unsigned)v & 0xFFFFu; run.y += (unsigned)(v >> 16) & 0xFFFFu;
+    run.z += (unsigned)(v >> 32) & 0xFFFFu; run.w += (unsigned)(v >> 48);
+  }
+  if (q == kColChunks - 1) reinterpret_cast<uint4*>(bs.count)[region] = run;   // (kLenClasses == 4)
 }
 
 // ---- pass 2: counting sort of the segments by region ---------------------------------------------------------------------
@@ -331,17 +430,42 @@ __global__ __launch_bounds__(1024) void region_scan_kernel(const unsigned* __res
   }
 }
 
-__global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long long nlanes) {
-  // one thread per (ray, depth segment) lane: its USED slots only (mean ~4 of 16)
+__global__ __launch_bounds__(256) void region_fill_kernel(BinScratch bs, long long nlanes, const int nreg, const int lds_ranks) {
+  // one thread per (ray, depth segment) lane: its USED slots only (mean ~4 of 16).  Three rounds of independent loads (slot
+  // records; start + block offset; -) instead of a dependent chain per slot: 47 -> 2x us on a reconstruction batch (r05).
   const long long lane = (long long)blockIdx.x * 256 + threadIdx.x;
   if (lane >= nlanes) return;
   const unsigned n = bs.lane_n[lane];
-  for (unsigned j = 0; j < n; ++j) {
-    const size_t sl = slot_of((size_t)lane, j, nlanes);
-    const unsigned rc = bs.slot_region[sl];
-    const unsigned pos = bs.start[(rc & kRegionMask) * kLenClasses + (rc >> 24)] + bs.slot_pos[sl];
-    const uint2 sg = bs.slot_seg[sl];
-    bs.sorted[pos] = make_uint4(sg.x, sg.y, (unsigned)sl, 0u);
+  unsigned rcv[kSlotsPerLane], posv[kSlotsPerLane];
+  uint2 sgv[kSlotsPerLane];
+#pragma unroll
+  for (int j = 0; j < kSlotsPerLane; ++j) {
+    if ((unsigned)j < n) {
+      const size_t sl = slot_of((size_t)lane, (unsigned)j, nlanes);
+      rcv[j] = bs.slot_region[sl];
+      posv[j] = bs.slot_pos[sl];
+      sgv[j] = bs.slot_seg[sl];
+    }
+  }
+  unsigned base[kSlotsPerLane];
+#pragma unroll
+  for (int j = 0; j < kSlotsPerLane; ++j) {
+    if ((unsigned)j < n) {
+      const unsigned region = rcv[j] & kRegionMask, cls = rcv[j] >> 24;
+      base[j] = bs.start[region * kLenClasses + cls];
+      if (lds_ranks) {   // (slot_pos = rank inside the block | block << 16: region_seg_lds_kernel)
+        const unsigned* __restrict__ off = reinterpret_cast<const unsigned*>(bs.blockoff + (size_t)(posv[j] >> 16) * (size_t)(nreg + 1) + region);
+        base[j] += off[cls];
+        posv[j] &= 0xFFFFu;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kSlotsPerLane; ++j) {
+    if ((unsigned)j < n) {
+      const size_t sl = slot_of((size_t)lane, (unsigned)j, nlanes);
+      bs.sorted[base[j] + posv[j]] = make_uint4(sgv[j].x, sgv[j].y, (unsigned)sl, 0u);
+    }
   }
 }
 
@@ -766,6 +890,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
       any = any || (gch[COUT] != 0.0f);
       T = T * om;
       if (!any) continue;
+#if defined(VOXE_REGION_EXP) && (VOXE_REGION_EXP & 4)
+      if (gch[0] != 12345.0f) continue;   // timing experiment: no deposit at all
+#endif
       if (rb.generic) {
         const CellAddr ad = cell_addr(g, cell);
 #pragma unroll
@@ -809,6 +936,9 @@ __global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
           // (a frozen tensor's channels deposit exact zeros: skipped by the flush)
 #pragma unroll
           for (int ch = 0; ch < 4; ++ch)
+#if defined(VOXE_REGION_EXP) && (VOXE_REGION_EXP & 2)
+            if (gr[ch] * w == 12345.0f && idx == 77)   // timing experiment: products and addresses formed, no LDS add
+#endif
             __hip_atomic_fetch_add(&win[choff[ch] + idx], (double)(gr[ch] * w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       } else {
@@ -1080,7 +1210,17 @@ bool region_bwd_supported(const DevGrid& g, const HostCfg& c, int deg, int diffu
 }
 
 static inline size_t up256(size_t x) { return (x + 255) / 256 * 256; }
-struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, src, fwdval, total; long long nslots, nlanes; int nreg; };
+struct RegionLayout { size_t slot_region, slot_pos, slot_seg, sorted, part, state, lane_n, counters, src, fwdval, blockhist, blockoff, total; long long nslots, nlanes; int nreg, seg_blocks; };
+// blocks of region_seg_lds_kernel for a launch of `nlanes` (ray, depth segment) lanes (a multiple of 16: region_colscan_kernel): one
+// unit per wave while that takes at most one block per CU, two from there on; 0: the region table does not fit in LDS
+constexpr size_t kSegLdsMaxBytes = 128 * 1024;
+static int seg_lds_blocks(long long nlanes, int nreg) {
+  if ((size_t)(nreg + 1) * sizeof(unsigned long long) > kSegLdsMaxBytes) return 0;
+  auto up16 = [](long long x) { return (x + 15) / 16 * 16; };
+  long long nb = up16((nlanes + 1023) / 1024);             // one unit (64 lanes) per wave ...
+  if (nb > 256) { nb = up16((nlanes + 2047) / 2048); if (nb < 256) nb = 256; }   // ... two once that takes more than a block per CU
+  return (int)(nb < 16 ? 16 : (nb > 1024 ? 1024 : nb));
+}
 static RegionLayout region_layout(int X, int Y, int Z, long long R, int S, bool full_sh = false) {
   RegionLayout l;
   const int nseg = num_segments(S, seg_len_for(R));
@@ -1100,6 +1240,10 @@ static RegionLayout region_layout(int X, int Y, int Z, long long R, int S, bool 
   l.src = off; off += full_sh ? up256((size_t)R * (size_t)S * sizeof(float4)) : 0;
   // ... and the forward's (rad_0..2, v) of every sample, same indexing: the source pass reads them instead of gathering again (r04)
   l.fwdval = off; off += full_sh ? up256((size_t)R * (size_t)S * sizeof(float4)) : 0;
+  // r05: block tables of the LDS-ranked segment pass
+  l.seg_blocks = seg_lds_blocks(l.nlanes, l.nreg);
+  l.blockhist = off; off += up256((size_t)l.seg_blocks * (size_t)(l.nreg + 1) * sizeof(unsigned long long));
+  l.blockoff = off; off += up256((size_t)l.seg_blocks * (size_t)(l.nreg + 1) * sizeof(uint4));
   l.total = off;
   return l;
 }
@@ -1119,6 +1263,8 @@ static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
   bs.lane_n = (unsigned*)(base + l.lane_n);
   bs.count = (unsigned*)(base + l.counters);
   bs.start = bs.count + up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)) / sizeof(unsigned);
+  bs.blockhist = l.seg_blocks ? (unsigned long long*)(base + l.blockhist) : nullptr;
+  bs.blockoff = (uint4*)(base + l.blockoff);
   return bs;
 }
 
@@ -1140,16 +1286,28 @@ static size_t full_tex_lds(K kernel, int cm) {
 }
 
 template <int COUT, int NCM, int NCU>
-static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st) {
+static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st, bool lds_ok) {
   const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, NCU > 1);
   const BinScratch bs = bin_scratch(l, scratch);
   (void)hipMemsetAsync(bs.count, 0, 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)), st);
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = (c.image_width > 0 ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
                                     : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64)) * nseg;
-  region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  // segment ranks: block-local in LDS (r05) when the region table fits and no block can see 65 536 segments of one counter
+  // (<= 4 units of 64 lanes per wave x 16 waves x 15 slots); one returning global atomic per segment otherwise
+  const int units_per_wave = l.seg_blocks ? (nb + l.seg_blocks * kSegLdsWaves - 1) / (l.seg_blocks * kSegLdsWaves) : 0;
+  const bool lds_ranks = l.seg_blocks > 0 && units_per_wave <= 4 && lds_ok;
+  if (lds_ranks) {
+    const size_t hist_bytes = (size_t)(l.nreg + 1) * sizeof(unsigned long long);
+    if (hist_bytes > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)region_seg_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes);
+    region_seg_lds_kernel<<<l.seg_blocks, kSegLdsThreads, hist_bytes, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg, nb, units_per_wave);
+    region_colscan_kernel<<<(l.nreg + 1 + kColRegions - 1) / kColRegions, kColRegions * kColChunks, 0, st>>>(bs, l.nreg, l.seg_blocks);
+  } else {
+    region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+  }
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
-  region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes);
+  region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes, l.nreg, lds_ranks ? 1 : 0);
   // degree 3: staging the 151.6 KB of a region's texels leaves one block (4 waves) per CU
   const int stage = (NCU > VOXE_REGION_STAGE_FWD_NCU) ? 0 : 1;
   const size_t lds = (NCU > 1 && stage) ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;
@@ -1206,9 +1364,9 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
 
 // forward of the space-binned path: fills the segment tables + per-segment states in `scratch` (the backward reuses them
 // when the caller says they belong to this call: VoxeRenderCfg::ray_state_valid) and the outputs that are not null
-void launch_fwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
+void launch_fwd_region(const DevGrid& g, const HostCfg& c, int deg, int diffuse, const FwdArgs& a, void* scratch,
                        hipStream_t st) {
-  VOXE_REGION_DISPATCH(launch_fwd_region_t, g, c, a, scratch, st);
+  VOXE_REGION_DISPATCH(launch_fwd_region_t, g, c, a, scratch, st, disp_region_lds_ranks(c.disp));
 }
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
                        hipStream_t st) {

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # VoxeStatus
 OK = 0
@@ -71,6 +71,7 @@ class VoxeDispatch(C.Structure):
         ("region_image_ratio", C.c_float),
         ("tile_lean", C.c_int32),
         ("precise_grad", C.c_int32),
+        ("region_lds_ranks", C.c_int32),
     ]
 
 

@@ -44,6 +44,7 @@ class Dispatch:
     region_image_ratio: float = 0.0  # 0 = 1.3 | < 0: every image-ordered launch the route accepts
     tile_lean: int = 0               # 0 lean SH-0 tile backward where it applies | -1 always the general kernel
     precise_grad: int = 0            # 0 float in-segment suffix sums | 1 double (image-ordered SH-0 backward)
+    region_lds_ranks: int = 0        # 0 block-local LDS ranks in the space-binned segment pass | -1 global returning atomics
 
     def struct(self) -> abi.VoxeDispatch:
         return _struct_of(self)
@@ -116,6 +117,8 @@ def from_env() -> Dispatch:
         kw["tile_lean"] = -1
     if os.environ.get("VOXE_PRECISE_GRAD", "")[:1] == "1":
         kw["precise_grad"] = 1
+    if os.environ.get("VOXE_REGION_LDS_RANKS", "")[:1] == "0":
+        kw["region_lds_ranks"] = -1
     return Dispatch(**kw)
 
 
