@@ -1,0 +1,75 @@
+"""r05: an OPAQUE scene -- rays whose transmittance underflows to exactly 0.0f behind a dense surface.  Everything behind the
+surface contributes exact zeros in the oracle (weights alpha * 0, suffix sums of zeros: accumulate.py:63-84); the kernels march
+those samples like any others (an exact early termination was built and measured: profiles/r05_early_exit.txt, not shipped) and
+must leave nothing but rounding-sized values there."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l2
+from synth import FAR, NEAR, RADIUS, focal_for, synth_pose_angles
+from voxe_hip import abi
+from voxe_hip.desc import make_render_cfg
+
+from oracle import voxe_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import gpu_helpers as gh
+    from thre3d_atom.utils.imaging_utils import pose_spherical
+
+AABB = [(-1.5, 1.5)] * 3
+
+
+def _opaque_grid(side, post_act):
+    """a dense ball (sigma * delta ~ 60 per sample: T underflows after two samples) in a faint random medium"""
+    rng = np.random.default_rng(11)
+    x = np.linspace(-1.5, 1.5, side, dtype=np.float32)
+    rr = np.sqrt(x[:, None, None] ** 2 + x[None, :, None] ** 2 + x[None, None, :] ** 2)
+    dens = np.where(rr < 0.8, 60.0, 0.02).astype(np.float32)[..., None] * (1.0 + 0.1 * rng.standard_normal((side,) * 3 + (1,)).astype(np.float32))
+    feat = rng.uniform(-1, 1, (side,) * 3 + (3,)).astype(np.float32)
+    return vo.Grid(dens, feat, AABB, 100.0, abi.ACT_IDENTITY, post_act)
+
+
+def _rays(hw, i):
+    yaw, pitch = synth_pose_angles(i, 100)
+    pose = pose_spherical(yaw, pitch, RADIUS)
+    return vo.cast_rays(hw, hw, focal_for(hw), pose.rotation.numpy(), pose.translation.numpy())
+
+
+@pytest.mark.parametrize("route", ["tile_lean", "tile_lean_precise", "region_random_batch"])
+@pytest.mark.parametrize("post_act", [abi.ACT_SOFTPLUS, abi.ACT_RELU])
+def test_opaque_scene_matches_the_oracle(route, post_act, disp):
+    grid = _opaque_grid(96, post_act)
+    S = 192
+    hw = 120
+    o, d = _rays(hw, 12)
+    over = dict(image_width=hw)
+    if route == "region_random_batch":
+        disp.set(region_min_rays=1)
+        sel = np.random.default_rng(3).permutation(o.shape[0])[:6000]
+        o, d = np.ascontiguousarray(o[sel]), np.ascontiguousarray(d[sel])
+        over = {}
+    else:
+        disp.set(tile_min_rays=-1, precise_grad=1 if route == "tile_lean_precise" else 0)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=5, rng_offset=3)
+    rng = (5, 3)
+    out, ref = gh.hip_forward(grid, cfg, o, d, rng=rng, **over), vo.render_fwd(grid, cfg, o, d)
+    # the scene IS opaque: most rays through the ball end at T == 0 exactly
+    assert (ref["acc"] == 1.0).mean() > 0.08
+    np.testing.assert_allclose(out["colour"], ref["colour"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["acc"], ref["acc"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(out["depth"], ref["depth"], rtol=1e-5, atol=1e-5)
+    r = np.random.default_rng(9)
+    gc = r.standard_normal((o.shape[0], 3)).astype(np.float32)
+    gdep = (0.1 * r.standard_normal(o.shape[0])).astype(np.float32)
+    gacc = (0.1 * r.standard_normal(o.shape[0])).astype(np.float32)
+    gd, gf = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, g_acc=gacc, rng=rng, **over)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, d_acc=gacc)
+    assert rel_l2(gd, rd) < 1e-4 and rel_l2(gf, rf) < 1e-4, (rel_l2(gd, rd), rel_l2(gf, rf))
+    # nothing behind the surface receives a gradient: voxels the oracle leaves at exactly zero hold rounding-sized values only
+    # (float suffix sums next to the surface: 1.1e-9 of the largest gradient measured on the tile route)
+    untouched = (rd == 0) & (rf == 0).all(axis=-1, keepdims=True)
+    assert untouched.mean() > 0.05
+    assert np.abs(gd[untouched]).max(initial=0.0) <= 1e-8 * np.abs(rd).max()
