@@ -94,6 +94,9 @@ bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, i
 void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl, int nb, int qsplit, float fit_m, float fit_lat,
                       hipStream_t st);
 // ... and the forward built the same way (no LDS; per-segment partials into a.segbuf, then the ordinary combine pass)
+bool tile4_dep_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int cm);
+void launch_bwd_tile4_dep(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int nb, int qsplit, int ngrp, float fit_m,
+                          float fit_lat, hipStream_t st);
 bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, int cout, int ncm);
 void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st);
 // LDS-staged forward for SH-0 image-ordered renders: writes the per-segment partials into a.segbuf (the caller then runs

@@ -1218,7 +1218,10 @@ static void launch_bwd_tile_t(const DevGrid& g, const HostCfg& c, const BwdArgs&
     if (a.sample_src && a.want_f) {   // two-phase: march once for the per-sample sources, then one deposit block per group
       if (a.want_d) VOXE_TBWD(true, true, 1, 8, nb / ngrp, 0, 1);
       else VOXE_TBWD(false, true, 1, 8, nb / ngrp, 0, 1);
-      VOXE_TBWD(true, true, 2, 8, nb, 0, ngrp);
+      if (NCM == NCU && tile4_dep_supported(g, c, a, NCU, COUT * NCM + 1))   // r05: the lean kernel's deposit passes
+        launch_bwd_tile4_dep(g, c, a, NCU, nb, qsplit, ngrp, fit_m, fit_lat, st);
+      else
+        VOXE_TBWD(true, true, 2, 8, nb, 0, ngrp);
       return;
     }
     if (a.want_d && a.want_f) VOXE_TBWD(true, true, 0, 8, nb, grp_begin, ngrp);

@@ -54,6 +54,20 @@ struct Tile4Args {
   float fit_m, fit_lat;
   int want_d, want_f;
   const double* segsum;   // PREC kernels: the forward's segment-local sums in double (FwdArgs::segsum_d)
+  // deposit passes of view-dependent grids (DEP kernels): the per-sample gradient sources of the source pass, bytes of a packed
+  // texel, channel groups of the launch (group g = texel channels 4 g .. 4 g + 3), gradient channels in all
+  const float4* sample_src;
+  unsigned tex_bytes;
+  int ngrp, ng;
+};
+
+// what a deposit pass multiplies the sample's sources with (this lane's ray, this block's channel group):
+// window channel s = A * mA[s] + B * mB[s] with A / B two of (d rad_0, d rad_1, d rad_2, d v) -- a group of four consecutive
+// gradient channels spans at most two colours, or a colour and the density
+struct DepCtx {
+  float mA[4], mB[4];
+  int cA, cB;            // wave-uniform: source index of A / B
+  long long src_base;    // slot of (tile, segment, sample 0, lane) in the source buffer (render_bwd_tile_kernel's layout)
 };
 
 constexpr int kTabKeys = 64;     // layer keys tabulated per pass (re-based when the window has moved 32 layers)
@@ -151,25 +165,33 @@ __device__ __forceinline__ bool tile_lanes_down_columns(const DevGrid& g, const 
 // the saved suffix of the NEXT boundary (summed back to front by the combine pass: accurate relative to itself).  The default
 // path takes (suffix at the segment start) - (float running sum): relative error 1e-7 / (T_k / T_start), i.e. the density
 // gradients of samples behind a dense stretch of the same segment are off by 1e-5 (median, profiles/r05_band_probe.txt).
-template <int MA, int KL, bool PREC>
+// DEP (deposit pass of a view-dependent grid, r05): no gather, no activations, no ray state -- the sample's four gradient sources
+// come from the source pass's buffer (16 bytes per sample, coalesced), times this ray's basis values for the block's channel
+// group; the window, its flush and the march are the SH-0 kernel's with the texel stride of the wide grid (`a.tex_bytes`).
+template <int MA, int KL, bool PREC, bool DEP>
 __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, const Tile4Args& a, RayCtx<3, 1, 1>& rc,
                                            double* __restrict__ win, int2* __restrict__ tab, const int lane, const long long r,
                                            bool has, const int k_lo, int k_hi, const int kmin, const int kmax, const int seg,
-                                           const int ks, const Geo4 geo, const float strat_lo, const float strat_sp) {
+                                           const int ks, const Geo4 geo, const float strat_lo, const float strat_sp,
+                                           const DepCtx& dep) {
   constexpr int UA = (MA == 0) ? 1 : 0, VA = (MA == 2) ? 1 : 2;
   constexpr int COUT = 3;
   constexpr int kCtr = Lat<KL>::kCentre;
   typedef Pcb<KL> P;
+  static_assert(!(DEP && PREC), "deposit passes carry no suffix sums");
+  const unsigned TB = DEP ? a.tex_bytes : 16u;                  // bytes of a packed texel
 
   // ---- per-ray constants of the backward (render_bwd_kernel, voxe_render.hip) ----------------------------------------
-  float gc[COUT], gsum = 0.0f;
+  float gc[COUT] = {0.0f, 0.0f, 0.0f}, gsum = 0.0f;
+  if constexpr (!DEP) {
 #pragma unroll
-  for (int ch = 0; ch < COUT; ++ch) { gc[ch] = a.d_colour[r * COUT + ch]; gsum += gc[ch]; }
-  const float gdep = a.d_depth ? a.d_depth[r] : 0.0f;
-  const float gacc = a.d_acc ? a.d_acc[r] : 0.0f;
+    for (int ch = 0; ch < COUT; ++ch) { gc[ch] = a.d_colour[r * COUT + ch]; gsum += gc[ch]; }
+  }
+  const float gdep = (!DEP && a.d_depth) ? a.d_depth[r] : 0.0f;
+  const float gacc = (!DEP && a.d_acc) ? a.d_acc[r] : 0.0f;
   const bool white = c.white != 0;
-  float T = 1.0f, suffix0;
-  {
+  float T = 1.0f, suffix0 = 0.0f;
+  if constexpr (!DEP) {
     const float asum = a.acc[r];
     float total = gdep * a.depth[r] + gacc * asum;
 #pragma unroll
@@ -292,18 +314,18 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   if constexpr (KL == 8) {
     const int fa = q4 & 1, fb = q4 >> 1;                           // lateral cell (2 j + fa, fb) of this lane in group j
     fl_lds[0] = ((fa << 1) + (fb >> 1) * (P::SB / 8) + (fb & 1) + (ch4 << 3)) * 8;
-    fl_vox[0] = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
+    fl_vox[0] = (unsigned)(fa * stride_u + fb * stride_v) * TB + (unsigned)(ch4 * 4);
   } else {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int ab = j * 16 + q4, fa = ab / KL, fb = ab - fa * KL;
       const bool cell_live = ab < KL * KL;
       fl_lds[j] = cell_live ? ((fa >> 1) * P::SA + ((fa & 1) << 4) + (fb >> 1) * P::SB + ((fb & 1) << 3) + (ch4 << 6)) : -1;
-      fl_vox[j] = (unsigned)((fa * stride_u + fb * stride_v) * 16 + ch4 * 4);
+      fl_vox[j] = (unsigned)(fa * stride_u + fb * stride_v) * TB + (unsigned)(ch4 * 4);
     }
   }
   const unsigned long long gaddr = reinterpret_cast<unsigned long long>(a.gpacked);
-  const long long sm16 = (long long)stride_m * 16, su16 = (long long)stride_u * 16, sv16 = (long long)stride_v * 16;
+  const long long sm16 = (long long)stride_m * TB, su16 = (long long)stride_u * TB, sv16 = (long long)stride_v * TB;   // (bytes per step)
   // The flush of a layer is split in two: flush_issue() reads-and-clears the layer (ds_wrxchg_rtn_b64) and keeps the returned
   // values pending in registers, flush_consume() -- one iteration later, after the next sample's texels are in -- converts them
   // and issues the global atomics (vmcnt counts in order: loads behind an atomic wait for it).
@@ -317,7 +339,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
 #ifndef VOXE_T4_ZPAIR
 #define VOXE_T4_ZPAIR 1
 #endif
-  constexpr bool kPair = VOXE_T4_ZPAIR && MA == 2 && KL == 8;
+  constexpr bool kPair = VOXE_T4_ZPAIR && MA == 2 && KL == 8 && !DEP;   // (wide texels: z-neighbours are not contiguous)
   unsigned long long pend[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) pend[j] = 0ull;
@@ -328,7 +350,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   unsigned long long pendB_vb = 0ull;
   int oddA = 0, oddB = 0;
   const bool lane_hi = lane >= 32;
-  const unsigned step4 = (unsigned)(4 * stride_v * 16);
+  const unsigned step4 = (unsigned)(4 * stride_v) * TB;
   const unsigned vox_b03 = kPair ? fl_vox[0] - (lane_hi ? step4 : 0u) : 0u;   // this lane's voxel with b reduced to 0..3
   auto flush_issue = [&](int key) __attribute__((always_inline)) {      // key wave-uniform
     if (VOXE_T4_EXP & 4) return;
@@ -454,13 +476,19 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
     // gather: 8 texels as (scalar base + 32-bit offset); the z-neighbour is the immediate
-    unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
-    if (!live || (VOXE_T4_EXP & 1)) off0 = 0u;
-    float4 t[8];
+    float4 t[DEP ? 1 : 8];
+    if constexpr (DEP) {
+      // the sample's sources: lanes without a sample read slot 0 of the block's own rows (always inside the buffer)
+      const long long so = live ? dep.src_base + (long long)k * 64 : dep.src_base + (long long)ks * 64;
+      t[0] = a.sample_src[so];
+    } else {
+      unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] << 4));
+      if (!live || (VOXE_T4_EXP & 1)) off0 = 0u;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
-      t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+      for (int q = 0; q < 8; ++q) {
+        const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+        t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+      }
     }
     // layer roles of the deposit: "A" = the layer whose ring slot has parity hm (slot parity == key parity == parity of the
     // march index: the ring depth is even), "B" the other one; their table entries
@@ -469,7 +497,8 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
     const int relA = ((imA ^ smask) - smask) + nkey0, relB = ((imB ^ smask) - smask) + nkey0;   // sgn * im - key0
     const int2 eA = tab[relA & (kTabKeys - 1)], eB = tab[relB & (kTabKeys - 1)];
     float f0, f1, f2, v;
-    interp_texels4(t, cell, f0, f1, f2, v);
+    if constexpr (DEP) { f0 = t[0].x; f1 = t[0].y; f2 = t[0].z; v = t[0].w; }
+    else interp_texels4(t, cell, f0, f1, f2, v);
     asm volatile("" ::"v"(f0), "v"(f1), "v"(f2), "v"(v));   // (consumed HERE, by every lane: see phase 1)
     // ---- the layer flushed at the end of the previous iteration: its values have long arrived.  The global atomics go out
     // AFTER this sample's texels are in: vmcnt counts in order, so loads behind an atomic would wait for it, and atomics issued
@@ -480,6 +509,15 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
       const bool last = (k == Sm1);        // wave-uniform
       const float z_next = last ? z : depth_of(k + 1);
       if (fp.inside) {
+        float gch[4];
+        bool deposit;
+        if constexpr (DEP) {
+          const float sA = dep.cA == 0 ? f0 : (dep.cA == 1 ? f1 : (dep.cA == 2 ? f2 : v));
+          const float sB = dep.cB == 0 ? f0 : (dep.cB == 1 ? f1 : (dep.cB == 2 ? f2 : v));
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) gch[s4] = fmaf(sB, dep.mB[s4], sA * dep.mA[s4]);   // (one of the two products is an exact zero)
+          deposit = gch[0] != 0.0f || gch[1] != 0.0f || gch[2] != 0.0f || gch[3] != 0.0f;
+        } else {
         const float rad[COUT] = {kC0 * f0, kC0 * f1, kC0 * f2};
         float sigma, dpost;
         post_activate_vg(g.post_act, v, sigma, dpost);
@@ -515,14 +553,15 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
         }
         const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
         const float dsig = (delta * e) * fmaf(Tk, dldw, -tail);
-        float gch[4];
 #pragma unroll
         for (int ch = 0; ch < COUT; ++ch) gch[ch] = ((wk * gcf[ch]) * (col[ch] * (1.0f - col[ch]))) * kC0;
         gch[3] = (dsig * dpost) * dmask;
         if constexpr (PREC) { if (term_eps > 0.0f && Tk * om < term_eps) k_hi = k; }
         else { T = T * om; if (term_eps > 0.0f && T < term_eps) k_hi = k; }   // gradient truncation (not in the reference)
+        deposit = wk != 0.0f || gch[3] != 0.0f;
+        }
 
-        if (!(VOXE_T4_EXP & 16) && (wk != 0.0f || gch[3] != 0.0f)) {
+        if (!(VOXE_T4_EXP & 16) && deposit) {
           // ---- the cell in (march, lateral u, lateral v) order ---------------------------------------------------------
           const int pm = cell.i[MA], pu = cell.i[UA], pv = cell.i[VA];
           const float wm0 = cell.w[MA][0], wm1 = cell.w[MA][1];
@@ -583,7 +622,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
             const int brel = base + nkey0;
             const int2 e0 = tm ? eB : eA, e1 = tm ? eA : eB;                    // table entries of layers pm, pm + 1
             const int rel0 = tm ? relB : relA, rel1 = tm ? relA : relB;
-            const unsigned vo = (unsigned)((pm * stride_m + pu * stride_u + pv * stride_v) * 16);
+            const unsigned vo = (unsigned)(pm * stride_m + pu * stride_u + pv * stride_v) * TB;
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) {
               const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
@@ -600,9 +639,10 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
                   for (int ch = 0; ch < 4; ++ch)
                     __hip_atomic_fetch_add(wp + ch * 8, (double)(gch[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                  float* const gp = reinterpret_cast<float*>(gbytes + (size_t)(vo + (unsigned)((cm * stride_m + cu * stride_u + cv * stride_v) * 16)));
+                  float* const gp = reinterpret_cast<float*>(gbytes + (size_t)(vo + (unsigned)(cm * stride_m + cu * stride_u + cv * stride_v) * TB));
 #pragma unroll
-                  for (int ch = 0; ch < 4; ++ch) atomicAdd(gp + ch, gch[ch] * wgt);
+                  for (int ch = 0; ch < 4; ++ch)
+                    if (!DEP || gch[ch] != 0.0f) atomicAdd(gp + ch, gch[ch] * wgt);   // (DEP: an unused slot of the last group lies outside the texel)
                 }
               }
             }
@@ -647,22 +687,29 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   }
 }
 
-template <int KL, bool PREC>
+// NCU_DEP > 0: the deposit pass of a view-dependent grid with NCU_DEP coefficients per colour (MODE 2 of render_bwd_tile_kernel:
+// same block order -- channel group outermost --, same lanes -> pixels, same source-buffer slots as its source pass)
+template <int KL, bool PREC, int NCU_DEP = 0>
 #ifndef VOXE_TILE4_LB_PREC
 #define VOXE_TILE4_LB_PREC 2   // the precise kernels at 3 waves per SIMD spill inside the sample loop (0.64 vs 0.50 ms on the bench camera)
 #endif
-__global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE_TILE4_LB)) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a) {
+__global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE_TILE4_LB)) void render_bwd_tile4_kernel(const DevGrid g, const DevCfg c, const Tile4Args a_in) {
+  constexpr bool DEP = NCU_DEP > 0;
   __shared__ double win[WinMap<KL, 4>::kDoubles];
   __shared__ int2 tab[kTabKeys];
   const int lane = threadIdx.x;
   for (int i = lane; i < WinMap<KL, 4>::kDoubles; i += 64) win[i] = 0.0;
 
-  // ---- block -> (pixel tile, depth segment[, part]): the block order of render_bwd_tile_kernel ---------------------------
+  // ---- block -> ([channel group,] pixel tile, depth segment[, part]): the block order of render_bwd_tile_kernel ----------
   const int W = c.image_width;
   const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
   const int nseg = num_segments(c.S, c.seg_len);
-  const int ntp = gridDim.x / (nseg * a.qsplit);
-  const int part = blockIdx.x / ntp;
+  const int ntp = gridDim.x / (nseg * a_in.qsplit * (DEP ? a_in.ngrp : 1));
+  int part = blockIdx.x / ntp;
+  int grp = 0;
+  if constexpr (DEP) { grp = part / (nseg * a_in.qsplit); part -= grp * nseg * a_in.qsplit; }
+  Tile4Args a = a_in;
+  a.gpacked = a_in.gpacked + 4 * grp;             // the group's four channels of every texel
   const int quad = part / nseg, seg = part - quad * nseg;
   const int tile = logical_tile_of(c, blockIdx.x % ntp, ntp, ntx, nty);
   if (tile < 0) return;  // launch padding (wave-uniform)
@@ -677,7 +724,8 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
 #ifndef VOXE_T4_ORIENT
 #define VOXE_T4_ORIENT 1   // 0: lanes always along the pixel rows
 #endif
-  if (VOXE_T4_ORIENT) {   // lanes along the image rows or down the columns (tile_lanes_down_columns): fewer cache lines per gather
+  if (VOXE_T4_ORIENT && !DEP) {   // lanes along the image rows or down the columns (tile_lanes_down_columns): fewer cache lines per gather
+                                  // (a deposit pass gathers nothing, and its lanes must sit where the source pass's did)
     const unsigned long long am0 = __ballot(alive);
     if ((am0 & 1ull) && (am0 >> 1 & 1ull) && (am0 >> 8 & 1ull)) {
       const float d0[3] = {readlane_f32(rc.d[0], 0), readlane_f32(rc.d[1], 0), readlane_f32(rc.d[2], 0)};
@@ -732,6 +780,38 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
     const float2 st = depth_stratum(rc.dg, ks + lane);
     strat_lo = st.x; strat_sp = st.y;
   }
+  DepCtx dep;
+  dep.cA = dep.cB = 0; dep.src_base = 0;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) dep.mA[s4] = dep.mB[s4] = 0.0f;
+  if constexpr (DEP) {
+    // window channel s4 = gradient channel q = 4 grp + s4: coefficient q % NCU of colour q / NCU (factor: that basis value of
+    // this ray), the density last (factor 1), nothing beyond (render_bwd_tile_kernel's chsel / mult tables)
+    float basis[NCU_DEP];
+    {
+      const float vdir[3] = {rc.d[0] / rc.dnorm, rc.d[1] / rc.dnorm, rc.d[2] / rc.dnorm};   // (as RayCtx::init)
+      sh_basis<NCU_DEP>(vdir, basis);
+    }
+    const int q0 = 4 * grp;
+    dep.cA = q0 >= a.ng - 1 ? 3 : q0 / NCU_DEP;
+    dep.cB = dep.cA;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int q = q0 + s4;
+      if (q >= a.ng) continue;
+      const int src = q == a.ng - 1 ? 3 : q / NCU_DEP;
+      float m = 1.0f;
+      if (src != 3) {
+        const int j = q - src * NCU_DEP;
+        m = basis[0];
+#pragma unroll
+        for (int t = 1; t < NCU_DEP; ++t) m = (j == t) ? basis[t] : m;
+      }
+      if (src == dep.cA) dep.mA[s4] = m;
+      else { dep.cB = src; dep.mB[s4] = m; }
+    }
+    dep.src_base = ((long long)tile * nseg + seg) * c.seg_len * 64 + lane - (long long)ks * 64;
+  }
 
   auto run_pass = [&](const bool alive_q, const int centre_lane, const int centre_lane2) {
     const int k_lo = max(rc.k_lo, ks);
@@ -771,9 +851,9 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
       geo.Bu = DUu * inv; geo.Au = U0u - geo.Bu * U0m;
       geo.Bv = DUv * inv; geo.Av = U0v - geo.Bv * U0m;
     }
-    if (m == 0) bwd4_march<0, KL, PREC>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
-    else if (m == 1) bwd4_march<1, KL, PREC>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
-    else bwd4_march<2, KL, PREC>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp);
+    if (m == 0) bwd4_march<0, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep);
+    else if (m == 1) bwd4_march<1, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep);
+    else bwd4_march<2, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep);
   };
   auto in_part = [&](int q) {
     const int hx = (lane >> 2) & 1, hy = (lane >> 5) & 1;
@@ -1007,9 +1087,33 @@ bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, i
   return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);   // (mad24 operands)
 }
 
+// deposit passes of the two-phase backward of view-dependent grids (SH degree 1 - 3, not diffuse): the lean kernel with the
+// wide grid's texel stride; same conditions as the SH-0 kernel, the byte offsets taken with the wide texel
+bool tile4_dep_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int cm) {
+  if (c.disp.tile_lean < 0 || !(ncu == 4 || ncu == 9 || ncu == 16) || cm != 3 * ncu + 1) return false;
+  if (a.gdet || a.jitter || c.aabb_clip || c.attn || c.image_width <= 0 || !a.sample_src) return false;
+  if (c.seg_len + 1 > 64) return false;
+  const long long tb = (long long)cm * 4;
+  return (long long)g.X * g.Y * g.Z * tb < (1ll << 31);
+}
+void launch_bwd_tile4_dep(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int nb, int qsplit, int ngrp, float fit_m,
+                          float fit_lat, hipStream_t st) {
+  Tile4Args t;
+  t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
+  t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
+  t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = 1; t.want_f = 1;
+  t.segsum = nullptr;
+  t.sample_src = reinterpret_cast<const float4*>(a.sample_src);
+  t.tex_bytes = (unsigned)(3 * ncu + 1) * 4u; t.ngrp = ngrp; t.ng = 3 * ncu + 1;
+  if (ncu == 4) render_bwd_tile4_kernel<8, false, 4><<<nb, 64, 0, st>>>(g, c, t);
+  else if (ncu == 9) render_bwd_tile4_kernel<8, false, 9><<<nb, 64, 0, st>>>(g, c, t);
+  else render_bwd_tile4_kernel<8, false, 16><<<nb, 64, 0, st>>>(g, c, t);
+}
+
 void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl, int nb, int qsplit, float fit_m, float fit_lat,
                       hipStream_t st) {
   Tile4Args t;
+  t.sample_src = nullptr; t.tex_bytes = 16u; t.ngrp = 1; t.ng = 4;
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
   t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = a.want_d ? 1 : 0; t.want_f = a.want_f ? 1 : 0;
