@@ -73,3 +73,31 @@ def test_opaque_scene_matches_the_oracle(route, post_act, disp):
     untouched = (rd == 0) & (rf == 0).all(axis=-1, keepdims=True)
     assert untouched.mean() > 0.05
     assert np.abs(gd[untouched]).max(initial=0.0) <= 1e-8 * np.abs(rd).max()
+
+
+@pytest.mark.parametrize("deg,dims", [(1, (21, 19, 23)), (2, (24, 20, 16)), (3, (21, 19, 23))])
+def test_lean_deposit_passes_of_view_dependent_grids_vs_oracle_and_the_general_kernel(deg, dims, disp):
+    """r05: the deposit passes of the two-phase image-ordered backward run in the lean tile kernel and flush into a group-planar
+    staging gradient that one pass adds into the packed gradient (voxel counts with and without a tail behind the 64-voxel
+    chunks); against the oracle, against the general kernel's deposit passes (VoxeDispatch::tile_lean = -1), twice on one
+    workspace (the staging planes are cleared per call).  Math: spherical_harmonics.py:87-116, accumulate.py:63-84."""
+    rng = np.random.default_rng(deg)
+    F = 3 * (deg + 1) ** 2
+    dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
+    feat = rng.uniform(-1, 1, (*dims, F)).astype(np.float32)
+    grid = vo.Grid(dens, feat, AABB, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    hw = 40
+    o, d = _rays(hw, 17)
+    cfg = make_render_cfg(96, NEAR, FAR, white_bkgd=True, sh_degree=deg, perturb=True, seed=8, rng_offset=2)
+    gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+    gdep = (0.1 * rng.standard_normal(o.shape[0])).astype(np.float32)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep)
+    disp.set(tile_min_rays=-1)
+    lean = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, rng=(8, 2), image_width=hw)
+    again = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, rng=(8, 2), image_width=hw)
+    disp.set(tile_lean=-1)
+    general = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, rng=(8, 2), image_width=hw)
+    for got in (lean, again, general):
+        assert rel_l2(got[0], rd) < 1e-4 and rel_l2(got[1], rf) < 1e-4, (rel_l2(got[0], rd), rel_l2(got[1], rf))
+    assert rel_l2(lean[1], general[1]) < 2e-6 and rel_l2(lean[0], general[0]) < 2e-6
+    assert rel_l2(lean[1], again[1]) < 2e-6

@@ -112,7 +112,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // workspace = [ packed grid | packed gradient | per-ray depth-segment states ]
 struct WsLayout {
-  size_t packed_off, grad_off, state_off, seg_off, prec_off, src_off, fwdval_off, det_off, region_off, fwd_total, total, total_with_src;
+  size_t packed_off, grad_off, state_off, seg_off, prec_off, src_off, fwdval_off, planar_off, det_off, region_off, fwd_total, total, total_with_src;
   bool region;   // the space-binned backward applies to (grid, cfg, R): its scratch is part of the workspace
 };
 WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
@@ -145,7 +145,10 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
   // ... and, behind the sources, the forward's per-sample (rad, v) in the same layout (r04: the source pass reads them instead of
   // gathering the wide texels again)
   l.fwdval_off = l.total + srcb;
-  l.total_with_src = l.total + 2 * srcb;
+  // ... and the group-planar staging gradient of the lean deposit passes (r05: [group][voxel][4], 16 bytes per voxel and group)
+  l.planar_off = l.total + 2 * srcb;
+  const size_t planarb = srcb ? align_up(tile_planar_bytes((long long)nvox, g->F + 1), 256) : 0;
+  l.total_with_src = l.total + 2 * srcb + planarb;
   // deterministic mode: the fixed-point gradient and its scales behind everything else
   l.det_off = l.total_with_src;
   if (c && c->deterministic) l.total_with_src += det_bytes((long long)nvox, g->F + 1);
@@ -360,6 +363,7 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
       // the forward of these rays (voxe_render_fwd with this workspace, or the re-march below) wrote its per-sample values when it
       // ran the depth-segmented kernel: launch_fwd_t's condition
       if (num_segments(cfg->num_samples, dc.seg_len) > 1) a.sample_fwd = (const float*)((char*)workspace + l.fwdval_off);
+      a.grad_planar = (float*)((char*)workspace + l.planar_off);
     }
     if (cfg->deterministic) {
       if (!det_bwd_supported(dc, cfg->sh_degree, cfg->render_diffuse)) return VOXE_ERR_UNSUPPORTED;

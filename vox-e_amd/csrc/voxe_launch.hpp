@@ -29,6 +29,7 @@ struct BwdArgs {
   const float* ray_state;  // states written by the forward for the same rays (tile backward only)
   float* sample_src = nullptr;   // scratch of the two-phase tile backward of view-dependent grids (tile_src_bytes())
   const float* sample_fwd = nullptr;   // the forward's per-sample (rad, v) for the SAME rays (FwdArgs::sample_fwd), or null
+  float* grad_planar = nullptr;        // group-planar staging gradient of the lean deposit passes (tile_planar_bytes()), or null
   // deterministic mode (VoxeRenderCfg::deterministic): 64-bit fixed-point gradient [voxels * C] + 4 floats
   // (max |contribution| of features / density as float bits, then their power-of-two scales); see det_bytes()
   unsigned long long* gdet = nullptr;
@@ -94,6 +95,7 @@ bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, i
 void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl, int nb, int qsplit, float fit_m, float fit_lat,
                       hipStream_t st);
 // ... and the forward built the same way (no LDS; per-segment partials into a.segbuf, then the ordinary combine pass)
+size_t tile_planar_bytes(long long nvox, int cm);
 bool tile4_dep_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int cm);
 void launch_bwd_tile4_dep(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int nb, int qsplit, int ngrp, float fit_m,
                           float fit_lat, hipStream_t st);

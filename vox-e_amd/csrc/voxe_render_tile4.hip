@@ -54,11 +54,14 @@ struct Tile4Args {
   float fit_m, fit_lat;
   int want_d, want_f;
   const double* segsum;   // PREC kernels: the forward's segment-local sums in double (FwdArgs::segsum_d)
-  // deposit passes of view-dependent grids (DEP kernels): the per-sample gradient sources of the source pass, bytes of a packed
-  // texel, channel groups of the launch (group g = texel channels 4 g .. 4 g + 3), gradient channels in all
+  // deposit passes of view-dependent grids (DEP kernels): the per-sample gradient sources of the source pass, channel groups of
+  // the launch (group g = texel channels 4 g .. 4 g + 3), gradient channels in all, voxels of the grid.  `gpacked` is then the
+  // GROUP-PLANAR staging gradient [group][voxel][4]: a group's flush is as line-dense as the SH-0 kernel's (a z-run of 8 voxels =
+  // one 128-byte line; flushed straight into 112-byte texels the same run is 7 lines = 7 atomic requests, and the memory side
+  // retires requests -- 0.45 instead of 0.31 ms per pass); planar_to_packed_kernel adds the planes into the packed gradient.
   const float4* sample_src;
-  unsigned tex_bytes;
   int ngrp, ng;
+  long long nvox;
 };
 
 // what a deposit pass multiplies the sample's sources with (this lane's ray, this block's channel group):
@@ -179,7 +182,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   constexpr int kCtr = Lat<KL>::kCentre;
   typedef Pcb<KL> P;
   static_assert(!(DEP && PREC), "deposit passes carry no suffix sums");
-  const unsigned TB = DEP ? a.tex_bytes : 16u;                  // bytes of a packed texel
+  constexpr unsigned TB = 16u;   // bytes of a texel of the gradient the window is flushed into (DEP: the group's plane, see DepCtx)
 
   // ---- per-ray constants of the backward (render_bwd_kernel, voxe_render.hip) ----------------------------------------
   float gc[COUT] = {0.0f, 0.0f, 0.0f}, gsum = 0.0f;
@@ -339,7 +342,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
 #ifndef VOXE_T4_ZPAIR
 #define VOXE_T4_ZPAIR 1
 #endif
-  constexpr bool kPair = VOXE_T4_ZPAIR && MA == 2 && KL == 8 && !DEP;   // (wide texels: z-neighbours are not contiguous)
+  constexpr bool kPair = VOXE_T4_ZPAIR && MA == 2 && KL == 8;
   unsigned long long pend[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) pend[j] = 0ull;
@@ -642,7 +645,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
                   float* const gp = reinterpret_cast<float*>(gbytes + (size_t)(vo + (unsigned)(cm * stride_m + cu * stride_u + cv * stride_v) * TB));
 #pragma unroll
                   for (int ch = 0; ch < 4; ++ch)
-                    if (!DEP || gch[ch] != 0.0f) atomicAdd(gp + ch, gch[ch] * wgt);   // (DEP: an unused slot of the last group lies outside the texel)
+                    atomicAdd(gp + ch, gch[ch] * wgt);
                 }
               }
             }
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
   int grp = 0;
   if constexpr (DEP) { grp = part / (nseg * a_in.qsplit); part -= grp * nseg * a_in.qsplit; }
   Tile4Args a = a_in;
-  a.gpacked = a_in.gpacked + 4 * grp;             // the group's four channels of every texel
+  if constexpr (DEP) a.gpacked = a_in.gpacked + (long long)grp * a_in.nvox * 4;   // the group's plane of the staging gradient
   const int quad = part / nseg, seg = part - quad * nseg;
   const int tile = logical_tile_of(c, blockIdx.x % ntp, ntp, ntx, nty);
   if (tile < 0) return;  // launch padding (wave-uniform)
@@ -1087,33 +1090,75 @@ bool tile4_bwd_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, i
   return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);   // (mad24 operands)
 }
 
-// deposit passes of the two-phase backward of view-dependent grids (SH degree 1 - 3, not diffuse): the lean kernel with the
-// wide grid's texel stride; same conditions as the SH-0 kernel, the byte offsets taken with the wide texel
+// ---- group-planar staging gradient -> packed gradient (accumulating) -------------------------------------------------------------
+// chunks of 64 voxels through LDS: 16-byte reads of every group's plane, 16-byte read-modify-writes of 64 whole texels
+__global__ __launch_bounds__(256) void planar_to_packed_kernel(const float4* __restrict__ planar, float* __restrict__ gpacked,
+                                                               const long long nvox, const int cm, const int ngrp) {
+  constexpr int V = 64;
+  extern __shared__ float4 p2p_buf4[];
+  float* const buf = reinterpret_cast<float*>(p2p_buf4);
+  const int tid = threadIdx.x;
+  const long long nchunks = nvox / V;
+  for (long long ck = blockIdx.x; ck < nchunks; ck += gridDim.x) {
+    for (int q = tid; q < V * ngrp; q += 256) {
+      const int gi = q / V, i = q - gi * V;
+      const float4 t = planar[(long long)gi * nvox + ck * V + i];
+      const float e[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (4 * gi + u < cm) buf[i * cm + 4 * gi + u] = e[u];
+    }
+    __syncthreads();
+    float4* __restrict__ g4 = reinterpret_cast<float4*>(gpacked + ck * V * cm);
+    for (int q = tid; q < V * cm / 4; q += 256) {
+      const float4 o = g4[q], t = p2p_buf4[q];
+      g4[q] = make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w);
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {   // the voxels behind the last whole chunk
+    const float* const pl = reinterpret_cast<const float*>(planar);
+    for (long long e = nchunks * V * cm + tid; e < nvox * cm; e += 256) {
+      const long long vox = e / cm;
+      const int ch = (int)(e - vox * cm);
+      gpacked[e] += pl[((long long)(ch >> 2) * nvox + vox) * 4 + (ch & 3)];
+    }
+  }
+}
+
+// deposit passes of the two-phase backward of view-dependent grids (SH degree 1 - 3, not diffuse): the lean kernel, flushing
+// into the group-planar staging gradient (BwdArgs::grad_planar); same conditions as the SH-0 kernel
 bool tile4_dep_supported(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int cm) {
   if (c.disp.tile_lean < 0 || !(ncu == 4 || ncu == 9 || ncu == 16) || cm != 3 * ncu + 1) return false;
-  if (a.gdet || a.jitter || c.aabb_clip || c.attn || c.image_width <= 0 || !a.sample_src) return false;
+  if (a.gdet || a.jitter || c.aabb_clip || c.attn || c.image_width <= 0 || !a.sample_src || !a.grad_planar) return false;
   if (c.seg_len + 1 > 64) return false;
-  const long long tb = (long long)cm * 4;
-  return (long long)g.X * g.Y * g.Z * tb < (1ll << 31);
+  const long long bytes = (long long)g.X * g.Y * g.Z * 16;
+  return bytes < (1ll << 31) && (long long)g.Y * g.Z * 16 < (1 << 24) && g.X < (1 << 24);
 }
+size_t tile_planar_bytes(long long nvox, int cm) { return (size_t)nvox * 16 * (size_t)((cm + 3) / 4); }
 void launch_bwd_tile4_dep(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int ncu, int nb, int qsplit, int ngrp, float fit_m,
                           float fit_lat, hipStream_t st) {
   Tile4Args t;
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
-  t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
+  t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.grad_planar;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = 1; t.want_f = 1;
   t.segsum = nullptr;
   t.sample_src = reinterpret_cast<const float4*>(a.sample_src);
-  t.tex_bytes = (unsigned)(3 * ncu + 1) * 4u; t.ngrp = ngrp; t.ng = 3 * ncu + 1;
+  const int cm = 3 * ncu + 1;
+  t.ngrp = ngrp; t.ng = cm; t.nvox = (long long)g.X * g.Y * g.Z;
+  (void)hipMemsetAsync(a.grad_planar, 0, tile_planar_bytes(t.nvox, cm), st);
   if (ncu == 4) render_bwd_tile4_kernel<8, false, 4><<<nb, 64, 0, st>>>(g, c, t);
   else if (ncu == 9) render_bwd_tile4_kernel<8, false, 9><<<nb, 64, 0, st>>>(g, c, t);
   else render_bwd_tile4_kernel<8, false, 16><<<nb, 64, 0, st>>>(g, c, t);
+  const long long nchunks = t.nvox / 64;
+  planar_to_packed_kernel<<<(int)(nchunks < 8192 ? (nchunks > 0 ? nchunks : 1) : 8192), 256, (size_t)64 * cm * sizeof(float), st>>>(
+      reinterpret_cast<const float4*>(a.grad_planar), a.gpacked, t.nvox, cm, ngrp);
 }
 
 void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int kl, int nb, int qsplit, float fit_m, float fit_lat,
                       hipStream_t st) {
   Tile4Args t;
-  t.sample_src = nullptr; t.tex_bytes = 16u; t.ngrp = 1; t.ng = 4;
+  t.sample_src = nullptr; t.ngrp = 1; t.ng = 4; t.nvox = 0;
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
   t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = a.want_d ? 1 : 0; t.want_f = a.want_f ? 1 : 0;
