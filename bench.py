@@ -310,14 +310,18 @@ def main():
     # the forward kernel of this launch: image-ordered SH-0 renders march through the LDS texel window (r03) unless switched off
     from voxe_hip import dispatch as _dispatch
 
-    fwd_kernel = ("voxe::render_fwd_tile_kernel" if args.ray_order == "image" and _dispatch.current().fwd_window >= 0
+    # (r05: the lean tile-ordered kernels of voxe_render_tile4.hip wherever they apply -- the headline configuration included)
+    lean = args.ray_order == "image" and _dispatch.current().tile_lean >= 0 and not args.no_jitter
+    fwd_kernel = ("voxe::render_fwd_tile4_kernel<3, false>" if lean else
+                  "voxe::render_fwd_tile_kernel" if args.ray_order == "image" and _dispatch.current().fwd_window >= 0
                   else "voxe::render_fwd_seg_kernel<3, 1, 1>")
     # algorithmic bytes: per in-AABB sample 8 corners x 4 ch x 4 B = 128 B read (fwd),
     # 128 B re-read + 128 B gradient scatter (bwd); per ray 24 B rays + outputs/upstream I/O
     bytes_fwd = s_in_total * 128 + R * (24 + 12 + 12)
     bytes_bwd = s_in_total * 256 + R * (24 + 12 + 20)
     if ms_bwd >= ms_fwd:
-        bwd_name = "render_bwd_tile_kernel<3,1,1,true,true,0,8,false>" if args.ray_order == "image" else "region_bwd_kernel<3,1>"
+        bwd_name = (("render_bwd_tile4_kernel<8,false,0>" if lean else "render_bwd_tile_kernel<3,1,1,true,true,0,8,false>")
+                    if args.ray_order == "image" else "region_bwd_kernel<3,1>")
         kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
         kname, kbytes, kms = fwd_kernel.replace("voxe::", "").replace(", ", ","), bytes_fwd, ms_fwd
@@ -382,7 +386,8 @@ def main():
         targs = [a.strip() for a in name[name.index("<") + 1: name.rindex(">")].split(",")]
         return len(targs) >= 7 and targs[6] == "8" and (len(targs) < 8 or targs[7] == "false")
 
-    phys_bwd = physical_of("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0,", _is_headline_bwd, ms_bwd)
+    phys_bwd = (physical_of("voxe::render_bwd_tile4_kernel<8, false, 0>", lambda k: True, ms_bwd) if lean else
+                physical_of("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0,", _is_headline_bwd, ms_bwd))
     phys_fwd = physical_of(fwd_kernel, lambda k: True, ms_fwd)
     physical = phys_bwd if ms_bwd >= ms_fwd else phys_fwd
     traffic = physical.get("traffic_bytes") if physical and not physical.get("stale") else None

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp
 run() { # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gpu-baseline > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-gpu-baseline --no-secondary > $OUT/$name.log 2>&1
   echo "== $name rc=$? =="; ls $OUT/$name | head
 }
 run fetch FETCH_SIZE
