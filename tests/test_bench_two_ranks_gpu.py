@@ -122,7 +122,7 @@ def test_default_bench_line_has_the_contract_fields():
     else:
         assert roof["traffic"] > 0 and roof["bound"] == roof["physical"]["binding"]
         assert roof["physical"]["binding"] in ("lds_issue", "valu_issue", "hbm") and 0 < roof["physical"]["binding_frac"] <= 1
-        assert roof["physical_other"]["kernel"].startswith("voxe::render_fwd_tile_kernel")
+        assert roof["physical_other"]["kernel"].startswith("voxe::render_fwd_tile")   # tile4 (lean, r05) or tile (general)
     assert out["ms_per_step_min"] <= out["ms_per_step_median"] <= out["ms_per_step_max"] and out["config"]["untimed_warmup_ms"] >= 5
     assert out["cpu_baseline"]["reps"] == 3 and out["gpu_baseline"]["reps"] == 3
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0

@@ -452,5 +452,7 @@ def test_newest_pmc_summary_belongs_to_these_kernel_sources():
 
         warnings.warn(f"{newest} was collected on other kernel sources ({summary['source_hash']} != {h}): "
                       f"re-run tools/gpu_pmc.sh + tools/pmc_to_json.py before quoting roofline.physical")
-    key = [k for k in summary["kernels"] if k.startswith("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0, 8")]
+    # the headline backward: the lean kernel since r05, the general LDS-window kernel in older summaries
+    key = [k for k in summary["kernels"] if k.startswith(("voxe::render_bwd_tile4_kernel<8, false, 0>",
+                                                            "voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0, 8"))]
     assert key and {"FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE"} <= set(summary["kernels"][key[0]])

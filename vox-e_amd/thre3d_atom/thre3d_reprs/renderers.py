@@ -82,7 +82,10 @@ def _render_params(voxel_grid: VoxelGrid, rays: Optional[Rays], cfg: SHVoxGridRe
     if cfg.radiance_hdr_tone_map is not torch.sigmoid:
         raise VoxeError("only torch.sigmoid tone mapping has a HIP path")
     if cfg.stochastic_density_noise_std != 0.0:
-        raise VoxeError("stochastic_density_noise_std != 0 is not supported by the HIP renderer")
+        # accumulate.py:57-63 adds the noise to every sample, the last one (delta 1e10) included: the reference itself renders
+        # NaN for half of all rays of a voxel grid at any std (tools/ref_density_noise_demo.py) and never sets it
+        raise VoxeError("stochastic_density_noise_std != 0 is not supported by the HIP renderer (the reference renders NaN "
+                        "for every ray whose last sample draws negative noise: profiles/r05_density_noise_reference.txt)")
     num_rays = rays.origins.shape[0] if rays is not None else 0     # (rays None: parameters of an unordered batch)
     # image-ordered rays: one image (R == H * W) or a multi-view batch of K images of that shape, one after the other
     # (collate_rays of flattened cameras that all carry the same image_shape): ONE launch, 2-D pixel tiles per camera
