@@ -155,8 +155,12 @@ typedef struct VoxeRenderCfg {
                                  0: the backward first re-marches the rays to rebuild them.
                                  voxe_render_fwd reads it too: -1 = no backward of these rays will follow
                                  (inference): the forward skips what only that backward would read (the per-sample
-                                 values of view-dependent image-ordered renders, r04); a backward after such a
-                                 forward must pass 0.                                             */
+                                 values of view-dependent image-ordered renders, r04), and
+                                 voxe_workspace_bytes() leaves out the backward's scratch.  The 1 is a CLAIM the
+                                 library checks (r05): every forward records, per workspace address, what it
+                                 rendered there (grid, rays, jitter, cfg, dispatch, whether the per-sample values
+                                 were kept); a backward whose claim does not match the record -- after a forward
+                                 with -1, or a forward of other rays in between -- re-marches as if given 0.      */
   const VoxeDispatch* dispatch; /* HOST pointer, NULL = the shipped dispatch; read during the call only (ABI v7)      */
 } VoxeRenderCfg;
 

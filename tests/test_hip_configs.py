@@ -628,3 +628,57 @@ def test_sh_source_pass_reads_the_forwards_sample_values_or_regathers(order):
         assert rel_l2(got[-1][0], rd) < GRAD_TOL and rel_l2(got[-1][1], rf) < GRAD_TOL, (mode, rel_l2(got[-1][0], rd), rel_l2(got[-1][1], rf))
     for a, b in zip(got[0], got[1]):
         assert rel_l2(a, b) < 2e-6
+
+
+@pytest.mark.parametrize("order", ["image", "random"])
+def test_a_false_ray_state_valid_claim_is_served_by_a_re_march(order):
+    """`ray_state_valid = 1` is a claim of the C caller.  An inference forward (ray_state_valid = -1: per-sample values of
+    a view-dependent grid NOT kept) followed by a backward that claims 1 used to read stale per-sample values; the library now
+    checks the claim against its record of what the last forward left in that workspace and re-marches.  Same for a forward of
+    OTHER rays in between.  The gradients equal those of an honest forward + backward."""
+    from voxe_hip import ops
+    from voxe_hip.dispatch import TILE_ALWAYS, Dispatch
+    from voxe_hip.runtime import lib
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    dims = (36, 40, 32)
+    dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
+    feat = rng.uniform(-1, 1, (*dims, 12)).astype(np.float32)
+    grid = vo.Grid(dens, feat, [(-1.5, 1.5)] * 3, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    hw = 48
+    o, d = _rays(hw, 31)
+    cfg = make_render_cfg(96, NEAR, FAR, white_bkgd=True, sh_degree=1, perturb=True, seed=4, rng_offset=6)
+    gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+    if order == "random":
+        perm = rng.permutation(o.shape[0])
+        o, d, gc = np.ascontiguousarray(o[perm]), np.ascontiguousarray(d[perm]), np.ascontiguousarray(gc[perm])
+        spec, params = gh.spec_of(grid), gh.params_of(cfg, dispatch=Dispatch(region_min_rays=1))
+    else:
+        spec, params = gh.spec_of(grid), gh.params_of(cfg, image_width=hw, dispatch=TILE_ALWAYS)
+    rd, rf = vo.render_bwd(grid, cfg, o, d, gc)
+    td, tf, to, tdir, tg = gh.t(dens), gh.t(feat), gh.t(o), gh.t(d), gh.t(gc)
+    to2, tdir2 = to.flip(0).contiguous(), tdir.flip(0).contiguous()
+    outs = [torch.empty((o.shape[0], n), device="cuda") for n in (3, 1, 1, 1)]
+    junk = [torch.empty((o.shape[0], n), device="cuda") for n in (3, 1, 1, 1)]
+    # the size a training caller allocates (a C caller's one workspace for inference and training alike)
+    g_, c_ = ops._descs(spec, params, td, tf, 4, 6, False)
+    nbytes = lib().voxe_workspace_bytes(C.byref(g_), C.byref(c_), o.shape[0])
+    c_.ray_state_valid = -1
+    assert lib().voxe_workspace_bytes(C.byref(g_), C.byref(c_), o.shape[0]) < nbytes     # inference needs none of the backward's scratch
+    got = {}
+    for mode in ("honest", "inference_forward", "other_rays_in_between"):
+        ws = ops.Workspace()
+        ws.ensure(nbytes, td.device).fill_(0xFF)        # (NaN bit patterns wherever a kernel reads what nobody wrote)
+        ops.render_fwd_into(spec, params, td, tf, to, tdir, None, *outs, ws, (4, 6), keep_for_backward=(mode != "inference_forward"))
+        claim = ops._state_key(ops._pack_key(spec, td, tf), params, to, tdir, None, (4, 6), ops._route(g_, c_, o.shape[0]))
+        if mode == "other_rays_in_between":
+            ops.render_fwd_into(spec, params, td, tf, to2, tdir2, None, *junk, ws, (4, 6))
+        ws.state_key = claim                            # what a careless C caller passes: ray_state_valid = 1
+        d_d, d_f = torch.zeros_like(td), torch.zeros_like(tf)
+        ops.render_bwd_into(spec, params, td, tf, to, tdir, None, outs[0], outs[1], outs[2], tg, None, None, d_d, d_f, ws, (4, 6))
+        got[mode] = (gh.n(d_d), gh.n(d_f))
+        assert np.isfinite(got[mode][0]).all() and np.isfinite(got[mode][1]).all(), mode
+        assert rel_l2(got[mode][0], rd) < GRAD_TOL and rel_l2(got[mode][1], rf) < GRAD_TOL, (mode, rel_l2(got[mode][0], rd), rel_l2(got[mode][1], rf))
+    for mode in ("inference_forward", "other_rays_in_between"):
+        for a, b in zip(got["honest"], got[mode]):
+            assert rel_l2(a, b) < 2e-6, mode

@@ -4,6 +4,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "../../include/voxe.h"
 #include "voxe_launch.hpp"
 #include "voxe_render_common.hpp"
@@ -172,6 +175,66 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
 
 int finish() { return hipGetLastError() == hipSuccess ? VOXE_OK : VOXE_ERR_LAUNCH; }
 
+// ---- what the last forward left in a workspace --------------------------------------------------------------------
+// VoxeRenderCfg::ray_state_valid = 1 is a CLAIM by the caller ("this workspace still holds what voxe_render_fwd wrote for exactly
+// these rays / cfg / jitter").  The library checks the claim instead of trusting it: every forward leaves a host-side record of
+// what it rendered into the workspace it was given (keyed by the workspace address; calls on one workspace are ordered by the
+// caller's stream, the record by the order of the calls), and a backward whose claim does not match the record re-marches the rays
+// exactly as if it had been called with 0.  In particular a forward with ray_state_valid = -1 (inference: per-sample values not
+// kept) followed by a backward with 1 is served by a re-march, not by stale per-sample values.  The record is a cache of facts
+// about buffers, not dispatch state: losing it (more than kMaxStamps workspaces) only costs a re-march.
+struct FwdStamp {
+  const void *densities, *features, *rays_o, *rays_d, *jitter;
+  int64_t R, pair_rays;
+  uint64_t seed, rng_offset, pair_offset, wsbytes;
+  int32_t X, Y, Z, F, feature_kind, pre_act, post_act, S, perturb, lindisp, clip, white, deg, diffuse, width, height, det, kept;
+  float near_, far_, density_scale;
+  // the dispatch fields (VoxeDispatch, field by field: the struct's padding is the caller's)
+  int64_t d_tile_min_rays, d_region_min_rays;
+  int32_t d_bwd_mode, d_tile_map, d_two_phase, d_qsplit, d_kl, d_fwd_window, d_fwd_spt, d_lean, d_precise, d_lds_ranks;
+  float d_fit_m, d_fit_lat, d_ffit_lat, d_ffit_m, d_zdom, d_max_adv, d_image_ratio;
+};
+FwdStamp make_stamp(const VoxeGridDesc* g, const VoxeRenderCfg* c, const float* rays_o, const float* rays_d, int64_t R,
+                    const float* jitter, size_t wsbytes) {
+  FwdStamp k;
+  memset(&k, 0, sizeof(k));   // (padding included: stamps are compared with memcmp)
+  const int64_t pair_rays = tl_pair ? tl_pair->rays : 0;
+  const uint64_t pair_offset = tl_pair ? tl_pair->rng_offset : 0;
+  k.densities = g->densities; k.features = g->features; k.rays_o = rays_o; k.rays_d = rays_d; k.jitter = jitter;
+  k.R = R; k.pair_rays = pair_rays; k.seed = c->seed; k.rng_offset = c->rng_offset; k.pair_offset = pair_offset; k.wsbytes = wsbytes;
+  k.X = g->X; k.Y = g->Y; k.Z = g->Z; k.F = g->F; k.feature_kind = g->feature_kind; k.pre_act = g->density_pre_act;
+  k.post_act = g->density_post_act; k.S = c->num_samples; k.perturb = c->perturb; k.lindisp = c->linear_disparity;
+  k.clip = c->aabb_clip; k.white = c->white_bkgd; k.deg = c->sh_degree; k.diffuse = c->render_diffuse; k.width = c->image_width;
+  k.height = c->image_height; k.det = c->deterministic;
+  k.near_ = c->near; k.far_ = c->far; k.density_scale = g->density_scale;
+  const VoxeDispatch& d = disp_of(c);
+  k.d_tile_min_rays = d.tile_min_rays; k.d_region_min_rays = d.region_min_rays; k.d_bwd_mode = d.bwd_mode; k.d_tile_map = d.tile_map;
+  k.d_two_phase = d.tile_two_phase; k.d_qsplit = d.tile_qsplit; k.d_kl = d.tile_kl; k.d_fwd_window = d.fwd_window;
+  k.d_fwd_spt = d.fwd_segments_per_thread; k.d_lean = d.tile_lean; k.d_precise = d.precise_grad; k.d_lds_ranks = d.region_lds_ranks;
+  k.d_fit_m = d.tile_fit_m; k.d_fit_lat = d.tile_fit_lat; k.d_ffit_lat = d.fwd_fit_lat; k.d_ffit_m = d.fwd_fit_m; k.d_zdom = d.fwd_zdom;
+  k.d_max_adv = d.fwd_max_adv; k.d_image_ratio = d.region_image_ratio;
+  return k;
+}
+constexpr size_t kMaxStamps = 256;
+std::mutex g_stamp_mu;
+std::unordered_map<const void*, FwdStamp> g_stamps;
+void record_stamp(const void* workspace, const FwdStamp& k) {
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  if (g_stamps.size() >= kMaxStamps && g_stamps.find(workspace) == g_stamps.end()) g_stamps.clear();
+  g_stamps[workspace] = k;
+}
+void forget_stamp(const void* workspace) {
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  g_stamps.erase(workspace);
+}
+// does `workspace` hold the forward of exactly this render, per-sample values included?
+bool stamp_matches(const void* workspace, FwdStamp k) {
+  k.kept = 1;
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  const auto it = g_stamps.find(workspace);
+  return it != g_stamps.end() && memcmp(&it->second, &k, sizeof(k)) == 0;
+}
+
 // ---- per-phase timing (voxe_profile_*) ----------------------------------------------------------
 enum Phase { PH_PACK = 0, PH_FWD, PH_MEMSET, PH_BWD, PH_UNPACK, PH_COUNT };
 struct Profiler {
@@ -287,7 +350,11 @@ int voxe_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_off
 
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R) {
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || grid->F <= 0) return 0;
-  return ws_layout(grid, cfg, R).total_with_src;
+  const WsLayout l = ws_layout(grid, cfg, R);
+  // ray_state_valid = -1 (inference: no backward of these rays follows): the packed grid and the segmented forward's states /
+  // partials -- none of the backward's per-sample sources, staging gradient or binning scratch (gigabytes at large R)
+  if (cfg && cfg->ray_state_valid < 0) return l.total;
+  return l.total_with_src;
 }
 
 int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const float* rays_o,
@@ -304,6 +371,12 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   float* packed = (float*)((char*)workspace + l.packed_off);
   if (!cfg->reuse_packed_grid) { PhaseTimer t(PH_PACK, s); launch_pack_any(grid, packed, s); }
   if (R == 0) return finish();
+  {
+    // what this workspace holds from now on (a backward's ray_state_valid = 1 is checked against it)
+    FwdStamp k = make_stamp(grid, cfg, rays_o, rays_d, R, jitter, workspace_bytes);
+    k.kept = cfg->ray_state_valid >= 0 ? 1 : 0;
+    record_stamp(workspace, k);
+  }
   DevGrid dg; HostCfg dc;
   make_dev(grid, cfg, R, v, &dg, &dc);
   // depth-segment states for the segmented backward, when that backward applies and the workspace holds them
@@ -374,12 +447,21 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     }
     const bool det = cfg->deterministic != 0;
     const bool region = l.region && !det && workspace_bytes >= l.total_with_src;
-    if (region && cfg->ray_state_valid <= 0) {
+    // the caller's claim that the workspace holds this render's forward is only believed when the forward's record says so
+    const FwdStamp stamp = make_stamp(grid, cfg, rays_o, rays_d, R, jitter, workspace_bytes);
+    const bool states_valid = cfg->ray_state_valid > 0 && stamp_matches(workspace, stamp);
+    if (!states_valid) {
+      // (the re-march below writes everything a backward reads: from here on the workspace holds THIS render)
+      FwdStamp k = stamp;
+      k.kept = 1;
+      record_stamp(workspace, k);
+    }
+    if (region && !states_valid) {
       // the caller's workspace does not hold this call's segment tables / states: rebuild them (no outputs)
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       launch_fwd_region(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, (char*)workspace + l.region_off, s);
-    } else if ((tiled || packed_bwd || det) && cfg->ray_state_valid <= 0) {
+    } else if ((tiled || packed_bwd || det) && !states_valid) {
       // the caller's workspace does not hold this call's forward states: re-march to rebuild them
       PhaseTimer t(PH_FWD, s);
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,

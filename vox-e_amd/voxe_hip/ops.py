@@ -171,9 +171,9 @@ def render_fwd_into(spec: GridSpec, params: RenderParams, densities, features, r
     key = _pack_key(spec, densities, features)
     g, c = _descs(spec, params, densities, features, rng[0], rng[1], workspace.key == key)
     with torch.cuda.device(device):
+        c.ray_state_valid = 0 if keep_for_backward else -1     # (-1: the size query leaves out everything only a backward reads)
         ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
         c.reuse_packed_grid = int(workspace.key == key)
-        c.ray_state_valid = 0 if keep_for_backward else -1
         check(L.voxe_render_fwd(C.byref(g), C.byref(c), ptr(rays_o), ptr(rays_d), R, ptr(jitter), ptr(colour),
                                 ptr(depth), ptr(acc), ptr(disparity), ptr(ws), ws.numel(),
                                 stream_ptr(device)), "voxe_render_fwd")
