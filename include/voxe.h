@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 9
+#define VOXE_ABI_VERSION 10
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -431,6 +431,35 @@ size_t voxe_recon_scratch_bytes(int64_t batch);
 int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* step,
                     void* workspace, size_t workspace_bytes, void* workspace2, size_t workspace2_bytes,
                     void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One attention grid's share of an iteration of the refinement loop in ONE call (ABI v10)
+ *   modules/attn_grid_trainer.py:335-378 -- per grid (edit / object): render_rays_attn -> calc_loss_on_attn_grid
+ *   (modules/refinement_functions.py:42-77) + attn_tv_weight * _tv_loss_on_grid (:659-663) -> backward -> Adam step of the
+ *   attention tensor.  The cross-attention map of the UNet (`attn_map`, the boundary to the networks) is an INPUT: the
+ *   reference computes it before the attention renders, so everything behind it is grid work and runs here back to back on
+ *   `stream`: voxe_render_fwd -> masked L1 + its gradient (one block) -> voxe_render_bwd_acc (attention channel only: the
+ *   densities are frozen) -> voxe_tv_fwd_bwd -> voxe_grid_adam_step.  Arithmetic identical to the composition of those calls.
+ *   grid     : VOXE_FEAT_ATTN; grid->features is the attention tensor [X,Y,Z,1], updated in place;
+ *   rays     : [R,3] device, image order when cfg->image_width > 0 (R = H * W); jitter stream (cfg->seed, cfg->rng_offset);
+ *   losses   : [2] device floats (or NULL): masked L1, TV (unweighted);
+ *   scratch  : voxe_attn_refine_scratch_bytes(grid, R) bytes of device memory (outputs, upstream gradient, TV gradient).
+ *   Afterwards `workspace` holds the updated grid packed and a cleared gradient region, like voxe_grid_adam_step.        */
+typedef struct {
+  const float* attn_map;        /* [R] device, row-major like the rays                                          */
+  float tv_weight;              /* attn_tv_weight; 0: no TV gradient (and no TV pass unless tv_loss_always)      */
+  int32_t tv_loss_always;       /* != 0: losses[1] is evaluated even when tv_weight == 0                         */
+  float lr, beta1, beta2, eps;
+  int64_t step;                 /* 1-based Adam step of the attention tensor                                    */
+  float *exp_avg, *exp_avg_sq;  /* [X,Y,Z,1] Adam state of the attention tensor                                 */
+  float* losses;                /* [2] device or NULL                                                           */
+  float* attn_render;           /* [R] device or NULL: receives the rendered attention image (logging)          */
+  int32_t zero_gradient_first;  /* != 0: clear the gradient region of `workspace` first                         */
+} VoxeAttnRefineStep;
+size_t voxe_attn_refine_scratch_bytes(const VoxeGridDesc* grid, int64_t R);
+int voxe_attn_refine_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeAttnRefineStep* step,
+                          const float* rays_o, const float* rays_d, int64_t R, void* workspace, size_t workspace_bytes,
+                          void* scratch, size_t scratch_bytes, void* stream);
 
 /* Measurement aids (bench.py, tests): not part of the reference's interface.
  * voxe_clock_probe        sustained shader clock in Hz: a chip-filling VALU + LDS kernel on `stream` reads the shader-clock

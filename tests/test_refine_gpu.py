@@ -142,6 +142,30 @@ def test_refinement_loop_cuts_out_the_hat(tmp_path):
     assert torch.equal(loaded.thre3d_repr.attn.detach()[..., 0], keep)
 
 
+def test_fused_refinement_step_follows_the_autograd_loop(tmp_path):
+    """the loop with one library call per attention grid and iteration (fused_grid_step, voxe_attn_refine_step) against the same
+    loop written like the reference (render_rays_attn -> calc_loss_on_attn_grid + TV -> backward -> Adam): same poses, same
+    jitter streams, same maps -- the attention grids agree up to float summation order"""
+    grids = {}
+    for fused in (True, False):
+        torch.manual_seed(3)
+        np.random.seed(3)
+        edited, reference, hat, body = _scene_models(side=32)
+        vm_edit, vm_obj, vm_out = copy.deepcopy(edited), copy.deepcopy(edited), copy.deepcopy(edited)
+        refine_edited_relu_field(
+            vm_edit, vm_obj, vm_out, reference, train_dataset=None, hf_auth_token="", output_dir=tmp_path / str(fused),
+            prompt="a ball wearing a hat", edit_idx=[2], timestamp=200, image_dims=None, num_iterations=8,
+            learning_rate=0.3, feedback_freq=100, save_freq=100, summary_freq=4, attn_tv_weight=0.01,
+            edit_mask_thresh=0.97, num_obj_voxels_thresh=400, min_num_edit_voxels=10, top_k_edit_thresh=30,
+            top_k_obj_thresh=30, attn_guidance=_BlobAttention(), camera_intrinsics=CameraIntrinsics(40, 40, 55.0),
+            camera_bounds=CameraBounds(1.8, 6.6), fused_grid_step=fused)
+        grids[fused] = [vm.thre3d_repr.attn.detach().clone() for vm in (vm_edit, vm_obj)]
+    for a, b in zip(grids[True], grids[False]):
+        moved = torch.linalg.norm(b + 20.0)
+        assert float(moved) > 1.0
+        assert float(torch.linalg.norm(a - b) / moved) < 2e-2
+
+
 def test_get_edit_region_downsampled_and_mismatch_guard():
     torch.manual_seed(1)
     edited, reference, hat, body = _scene_models(side=32)

@@ -712,6 +712,65 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
                              rs->beta2, rs->eps, rs->step_densities, rs->step_features, nullptr, workspace, workspace_bytes, stream);
 }
 
+namespace {
+struct RefineLayout { size_t out, d_render, tv_grad, tv_scratch, l1_scratch, total; };
+RefineLayout refine_layout(const VoxeGridDesc* g, int64_t R) {
+  RefineLayout l;
+  size_t off = 0;
+  const size_t r = (size_t)(R > 0 ? R : 0);
+  l.out = off; off += up256b(r * 4 * sizeof(float));          // attn [R] | depth [R] | acc [R] | (spare)
+  l.d_render = off; off += up256b(r * sizeof(float));
+  l.tv_grad = off; off += up256b((size_t)g->X * g->Y * g->Z * sizeof(float));
+  l.tv_scratch = off; off += up256b(tv_scratch_bytes(g->X, g->Y, g->Z, 1));
+  l.l1_scratch = off; off += up256b(attn_l1_scratch_bytes());
+  l.total = off;
+  return l;
+}
+}  // namespace
+
+size_t voxe_attn_refine_scratch_bytes(const VoxeGridDesc* grid, int64_t R) {
+  if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || R <= 0) return 0;
+  return refine_layout(grid, R).total;
+}
+
+int voxe_attn_refine_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeAttnRefineStep* rs, const float* rays_o,
+                          const float* rays_d, int64_t R, void* workspace, size_t workspace_bytes, void* scratch,
+                          size_t scratch_bytes, void* stream) {
+  if (!grid || !cfg || !rs || !rays_o || !rays_d || !rs->attn_map || !rs->exp_avg || !rs->exp_avg_sq) return VOXE_ERR_NULL_POINTER;
+  if (grid->feature_kind != VOXE_FEAT_ATTN) return VOXE_ERR_UNSUPPORTED;
+  if (R <= 0) return VOXE_ERR_BAD_SHAPE;
+  if (cfg->deterministic) return VOXE_ERR_UNSUPPORTED;
+  const RefineLayout l = refine_layout(grid, R);
+  if (!scratch || scratch_bytes < l.total) return VOXE_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  char* sc = (char*)scratch;
+  float* attn = rs->attn_render ? rs->attn_render : (float*)(sc + l.out);
+  float *depth = (float*)(sc + l.out) + R, *acc = depth + R;
+  float* d_render = (float*)(sc + l.d_render);
+  float* tv_grad = (float*)(sc + l.tv_grad);
+  VoxeRenderCfg rc = *cfg;
+  rc.ray_state_valid = 0;
+  int st = voxe_render_fwd(grid, &rc, rays_o, rays_d, R, nullptr, attn, depth, acc, nullptr, workspace, workspace_bytes, stream);
+  if (st) return st;
+  launch_attn_masked_l1(attn, rs->attn_map, R, d_render, rs->losses, sc + l.l1_scratch, s);
+  rc.ray_state_valid = 1;
+  rc.reuse_packed_grid = 1;
+  int32_t layout = VOXE_GRAD_ANY;
+  st = voxe_render_bwd_acc_into(grid, &rc, rays_o, rays_d, R, nullptr, attn, depth, acc, d_render, nullptr, nullptr,
+                                /*want_densities=*/0, /*want_features=*/1, rs->zero_gradient_first ? 1 : 0, &layout, workspace,
+                                workspace_bytes, nullptr, 0, stream);
+  if (st) return st;
+  // the TV stencil reads the parameters BEFORE the step overwrites them: its gradient goes through the step's extra-gradient input
+  const float* extra = nullptr;
+  if (rs->tv_weight != 0.0f || (rs->losses && rs->tv_loss_always)) {
+    launch_tv(grid->features, grid->X, grid->Y, grid->Z, 1, rs->tv_weight, rs->losses ? rs->losses + 1 : nullptr,
+              rs->tv_weight != 0.0f ? tv_grad : nullptr, 0, sc + l.tv_scratch, s);
+    if (rs->tv_weight != 0.0f) extra = tv_grad;
+  }
+  return voxe_grid_adam_step(grid, layout, 0, grid->X, nullptr, extra, nullptr, nullptr, rs->exp_avg, rs->exp_avg_sq, rs->lr,
+                             rs->beta1, rs->beta2, rs->eps, rs->step, rs->step, nullptr, workspace, workspace_bytes, stream);
+}
+
 int voxe_clock_probe(int32_t spin, double* shader_hz, void* stream) {
   if (!shader_hz) return VOXE_ERR_NULL_POINTER;
   *shader_hz = run_clock_probe(spin, (hipStream_t)stream);

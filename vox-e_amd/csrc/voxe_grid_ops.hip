@@ -577,6 +577,60 @@ void launch_l1_loss_grad_n(const float* a, const float* b, long long n, int rend
 }
 
 // ------------------------------------------------------------------------------------------------
+// calc_loss_on_attn_grid -- modules/refinement_functions.py:42-77 (+ autograd):
+//   mask = render > 0;  loss = sum(|render - map| * mask) / sum(mask)
+//   d loss / d render = ((1 / sum(mask)) * mask) * sign(render - map)      (div, sum, mul, abs backward in that order; sign(0) = 0)
+// Two launches: per-block (count, sum) partials in a fixed order, then every block of the gradient pass folds the (few) partials
+// itself -- no finalize launch in between.  sum(mask) is an exact integer; the loss sum is carried in double and rounded once.
+// (A single block doing both passes measured 69 us at 266x266: 70 dependent round trips per thread.)
+// ------------------------------------------------------------------------------------------------
+constexpr int kAttnL1Blocks = 128;
+__global__ __launch_bounds__(256) void attn_masked_l1_partial_kernel(const float* __restrict__ render, const float* __restrict__ map,
+                                                                      long long n, double* __restrict__ partial) {
+  double s[2] = {0.0, 0.0};     // sum |render - map| over the mask, count of the mask
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float r = render[i];
+    if (r > 0.0f) { s[0] += (double)fabsf(r - map[i]); s[1] += 1.0; }
+  }
+  block_sum<2>(s, partial + (long long)blockIdx.x * 2);
+}
+__global__ __launch_bounds__(256) void attn_masked_l1_grad_kernel(const float* __restrict__ render, const float* __restrict__ map,
+                                                                   long long n, const double* __restrict__ partial, int nblocks,
+                                                                   float* __restrict__ d_render, float* __restrict__ loss_out) {
+  __shared__ float sm_inv;
+  if (threadIdx.x < 64) {       // one wave folds the partials (nblocks <= 128), the same order in every block
+    double ts = 0.0, tc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 64) { ts += partial[2 * i]; tc += partial[2 * i + 1]; }
+    ts = wave_sum(ts);
+    tc = wave_sum(tc);
+    if (threadIdx.x == 0) {
+      const float msum = (float)tc;                                        // mask.sum(): float32, exact below 2^24 pixels
+      if (loss_out && blockIdx.x == 0) *loss_out = (float)ts / msum;        // diff_masked.sum() / mask.sum()  (0 / 0 = NaN, like the reference)
+      sm_inv = 1.0f / msum;
+    }
+  }
+  __syncthreads();
+  const float inv = sm_inv;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float r = render[i];
+    const float m = r > 0.0f ? 1.0f : 0.0f;
+    d_render[i] = (inv * m) * sgnf(r - map[i]);
+  }
+}
+size_t attn_l1_scratch_bytes() { return sizeof(double) * 2 * kAttnL1Blocks; }
+void launch_attn_masked_l1(const float* render, const float* map, long long n, float* d_render, float* loss_out, void* scratch,
+                           hipStream_t st) {
+  if (n <= 0) return;
+  const int nb = (int)((n + 255) / 256 < kAttnL1Blocks ? (n + 255) / 256 : kAttnL1Blocks);
+  double* partial = (double*)scratch;
+  attn_masked_l1_partial_kernel<<<nb, 256, 0, st>>>(render, map, n, partial);
+  const int ng = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  attn_masked_l1_grad_kernel<<<ng, 256, 0, st>>>(render, map, n, partial, nb, d_render, loss_out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sustained shader clock (measurement aid of bench.py: the issue-rate ceilings of the render kernels are quoted in shader
 // clocks, so the clock has to be MEASURED under load, not assumed).  s_memtime counts shader clocks, s_memrealtime a
 // constant reference clock (hipDeviceAttributeWallClockRate, 100 MHz); every block of a chip-filling launch that keeps

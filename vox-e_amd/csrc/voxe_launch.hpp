@@ -147,6 +147,9 @@ void launch_gather_pixels(const float* images, const long long* image_rows, cons
                           int num_images, float* out, hipStream_t st);
 size_t l1_scratch_bytes();
 void launch_l1_loss_grad(const float* a, const float* b, long long n, float* d_a, float* out2, void* scratch, hipStream_t st);
+size_t attn_l1_scratch_bytes();
+void launch_attn_masked_l1(const float* render, const float* map, long long n, float* d_render, float* loss_out, void* scratch,
+                           hipStream_t st);
 void launch_l1_loss_grad_n(const float* a, const float* b, long long n, int renders, float* d_a, float* out2, void* scratch,
                            hipStream_t st);   // (scratch: l1_scratch_bytes() covers two renders)
 void launch_recon_batch(long long B, unsigned long long seed, unsigned long long rng_offset, int H, int W, float focal, int K,

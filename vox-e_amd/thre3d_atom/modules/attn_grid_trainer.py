@@ -21,7 +21,7 @@ from thre3d_atom.modules.optim import FusedGridAdam, VoxeAdam
 from thre3d_atom.modules.refinement_functions import calc_loss_on_attn_grid, get_edit_region
 from thre3d_atom.modules.volumetric_model import VolumetricModel
 from thre3d_atom.rendering.volumetric.utils.misc import cast_rays, flatten_rays
-from thre3d_atom.thre3d_reprs.renderers import render_sh_voxel_grid_attn
+from thre3d_atom.thre3d_reprs.renderers import attn_render_params, render_sh_voxel_grid_attn
 from thre3d_atom.thre3d_reprs.voxels import VoxelGrid
 from thre3d_atom.utils.constants import CAMERA_BOUNDS, CAMERA_INTRINSICS, HEMISPHERICAL_RADIUS
 from thre3d_atom.utils.imaging_utils import CameraBounds, CameraIntrinsics, CameraPose, get_random_pose, to8b
@@ -181,6 +181,7 @@ def refine_edited_relu_field(
     trained_time, last = 0.0, time.perf_counter()
     data_cursor = 0
     pose = None
+    step_losses = step_renders = None      # device buffers of the fused step (masked L1 / TV per grid, rendered attention images)
     try:
         for global_step in range(1, num_iterations + 1):
             if data_pose_mode:
@@ -201,19 +202,34 @@ def refine_edited_relu_field(
                                                  indices_to_fetch=list(range(1, num_tokens + 1)))
             edit_attn_map, object_attn_map = split_attention_maps(maps, edit_idx, object_idx)
 
-            edit_render = vol_mod_edit.render_rays_attn(rays_batch).attn
-            object_render = vol_mod_object.render_rays_attn(rays_batch).attn
-            edit_attn_loss = calc_loss_on_attn_grid(edit_render, edit_attn_map, token="edit", global_step=global_step)
-            object_attn_loss = calc_loss_on_attn_grid(object_render, object_attn_map, token="object", global_step=global_step)
-            total_loss_edit = edit_attn_loss + _tv_loss_on_grid(edit_grid.attn) * attn_tv_weight
-            total_loss_object = object_attn_loss + _tv_loss_on_grid(object_grid.attn) * attn_tv_weight
+            if fused_grid_step:
+                # everything behind the UNet's maps is grid work: per attention grid ONE library call (voxe_attn_refine_step:
+                # attention render -> masked L1 + TV -> backward -> Adam), the reference's lines :335-378 with the same arithmetic
+                num_rays = rays_batch.origins.shape[0]
+                if step_losses is None:
+                    step_losses = torch.zeros((2, 2), dtype=torch.float32, device=device)
+                    step_renders = torch.empty((2, num_rays), dtype=torch.float32, device=device)
+                for i, (vm, opt, amap) in enumerate(((vol_mod_edit, optimizer_edit, edit_attn_map),
+                                                     (vol_mod_object, optimizer_object, object_attn_map))):
+                    params = attn_render_params(vm.thre3d_repr, rays_batch, vm.render_config)
+                    opt.attention_refinement_step(params, rays_batch.origins, rays_batch.directions, amap.reshape(-1),
+                                                  attn_tv_weight, step_losses[i], rng=_ops._next_rng(), attn_render=step_renders[i])
+                edit_attn_loss, object_attn_loss = step_losses[0, 0], step_losses[1, 0]
+                edit_render, object_render = step_renders[0], step_renders[1]
+            else:
+                edit_render = vol_mod_edit.render_rays_attn(rays_batch).attn
+                object_render = vol_mod_object.render_rays_attn(rays_batch).attn
+                edit_attn_loss = calc_loss_on_attn_grid(edit_render, edit_attn_map, token="edit", global_step=global_step)
+                object_attn_loss = calc_loss_on_attn_grid(object_render, object_attn_map, token="object", global_step=global_step)
+                total_loss_edit = edit_attn_loss + _tv_loss_on_grid(edit_grid.attn) * attn_tv_weight
+                total_loss_object = object_attn_loss + _tv_loss_on_grid(object_grid.attn) * attn_tv_weight
 
-            total_loss_edit.backward()
-            optimizer_edit.step()
-            optimizer_edit.zero_grad()
-            total_loss_object.backward()
-            optimizer_object.step()
-            optimizer_object.zero_grad()
+                total_loss_edit.backward()
+                optimizer_edit.step()
+                optimizer_edit.zero_grad()
+                total_loss_object.backward()
+                optimizer_object.step()
+                optimizer_object.zero_grad()
             trained_time += time.perf_counter() - last
 
             if global_step % summary_freq == 0 or global_step in (1, num_iterations):

@@ -199,6 +199,40 @@ class FusedGridAdam(torch.optim.Optimizer):
         d.dirty, d.layout = False, _ops.abi.GRAD_ANY
 
     @torch.no_grad()
+    def attention_refinement_step(self, render_params, rays_o, rays_d, attn_map, tv_weight: float, losses=None, rng=(0, 0),
+                                  attn_render=None) -> None:
+        """One attention grid's share of a refinement iteration (modules/attn_grid_trainer.py:335-378) in ONE library call
+        (voxe_attn_refine_step): attention render of the rays -> masked L1 against the UNet's cross-attention map `attn_map`
+        [H, W] + `tv_weight` x TV of the attention grid -> backward -> this optimiser's Adam step.  State, step counter and
+        the current learning rate are this optimiser's; `losses` [2] (device) receives masked L1 and TV (unweighted),
+        `attn_render` [R] the rendered attention image."""
+        if self.kind != "attn":
+            raise RuntimeError("attention_refinement_step optimises the attention tensor of an attention grid")
+        d = self.workspace.deferred
+        if d is None:
+            raise RuntimeError("attention_refinement_step after detach()")
+        if d.dirty:
+            raise RuntimeError("attention_refinement_step: an accumulated render gradient is waiting for step()")
+        group = self.param_groups[0]
+        beta1, beta2 = group["betas"]
+        st = self._state_of(self._feat)
+        ws = self.workspace
+        fresh = ws.buf is None or d.clean_ptr != ws.buf.data_ptr()
+        try:
+            _ops.attn_refine_step_(self.spec, render_params, self._dens.detach(), self._feat.detach(), rays_o, rays_d,
+                                   attn_map.detach().to(torch.float32).contiguous(), ws, st["step"] + 1, group["lr"],
+                                   (st["exp_avg"], st["exp_avg_sq"]), tv_weight, losses, rng, beta1=beta1, beta2=beta2,
+                                   eps=group["eps"], attn_render=attn_render, zero_gradient_first=fresh)
+        except Exception:
+            d.clean_ptr = 0
+            ws.invalidate()
+            raise
+        self._opt_called = True      # (not through Optimizer.step(): see reconstruction_step)
+        st["step"] += 1          # (the binding bumped the tensor versions: the detached views share their counters)
+        d.clean_ptr = ws.buf.data_ptr()
+        d.dirty, d.layout = False, _ops.abi.GRAD_ANY
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:

@@ -112,6 +112,13 @@ def _render_params(voxel_grid: VoxelGrid, rays: Optional[Rays], cfg: SHVoxGridRe
     )
 
 
+def attn_render_params(voxel_grid: VoxelGrid, rays: Rays, render_config: SHVoxGridRenderConfig) -> _ops.RenderParams:
+    """the kernel parameters `render_sh_voxel_grid_attn` renders (voxel_grid, rays, render_config) with -- for callers that hand a
+    whole refinement iteration to the library (FusedGridAdam.attention_refinement_step)"""
+    _check_flat(rays)
+    return _render_params(voxel_grid, rays, render_config, attn=True)
+
+
 def _check_flat(rays: Rays) -> None:
     if rays.origins.dim() != 2 or rays.directions.dim() != 2:
         raise AssertionError("Please note that the RENDER interface only works with FLAT RAYS!")

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # VoxeStatus
 OK = 0
@@ -128,6 +128,15 @@ class VoxeReconStep(C.Structure):
     ]
 
 
+class VoxeAttnRefineStep(C.Structure):
+    _fields_ = [
+        ("attn_map", C.c_void_p), ("tv_weight", C.c_float), ("tv_loss_always", C.c_int32),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+        ("step", C.c_int64), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("losses", C.c_void_p), ("attn_render", C.c_void_p), ("zero_gradient_first", C.c_int32),
+    ]
+
+
 _P = C.c_void_p
 _GD = C.POINTER(VoxeGridDesc)
 _RC = C.POINTER(VoxeRenderCfg)
@@ -185,6 +194,8 @@ HIP_ONLY = {
     "region_debug_layout": (C.c_int, [_GD, _RC, C.c_int64, C.POINTER(C.c_int64)]),
     "recon_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "recon_step": (C.c_int, [_GD, _RC, C.POINTER(VoxeReconStep), _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "attn_refine_scratch_bytes": (C.c_size_t, [_GD, C.c_int64]),
+    "attn_refine_step": (C.c_int, [_GD, _RC, C.POINTER(VoxeAttnRefineStep), _P, _P, C.c_int64, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "tv_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "graphcut_scratch_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -645,10 +645,61 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
                                         float(eps), int(step), int(step if step_features is None else step_features),
                                         None if reg is None else C.byref(reg), ptr(ws), ws.numel(), stream_ptr(device)),
               "voxe_grid_adam_step")
-    for t in (densities, features, m_d, v_d, m_f, v_f):
+    # (a frozen tensor -- no Adam state -- was not written: its version stays, so other workspaces that hold it packed, e.g. the
+    #  two attention grids of the refinement stage over ONE density tensor, keep their packed copies)
+    for t in (densities if m_d is not None else None, features if m_f is not None else None, m_d, v_d, m_f, v_f):
         if t is not None:
             torch.autograd.graph.increment_version(t)
     workspace.key = _pack_key(spec, densities, features)   # the workspace holds the updated grid packed
+    workspace.state_key = None
+
+
+@torch.no_grad()
+def attn_refine_step_(spec: GridSpec, params: RenderParams, densities, attn, rays_o, rays_d, attn_map, workspace: Workspace,
+                      step: int, lr: float, state, tv_weight: float, losses: Optional[torch.Tensor] = None, rng=(0, 0),
+                      beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, attn_render: Optional[torch.Tensor] = None,
+                      zero_gradient_first: bool = False, tv_loss_always: bool = True) -> None:
+    """voxe_attn_refine_step: one attention grid's share of a refinement iteration (modules/attn_grid_trainer.py:335-378) in ONE
+    library call -- attention render -> masked L1 against `attn_map` + `tv_weight` x TV -> backward -> Adam step of `attn` in place
+    (`state` = (exp_avg, exp_avg_sq); the densities are frozen).  `losses` [2] (device) receives masked L1 and TV (unweighted),
+    `attn_render` [R] the rendered attention image."""
+    device = densities.device
+    ensure_gfx950(device)
+    if spec.feature_kind != abi.FEAT_ATTN:
+        raise VoxeError("attn_refine_step_ needs an attention grid spec (feature_kind = FEAT_ATTN)")
+    R = int(rays_o.shape[0])
+    for nm, t, n in (("densities", densities, densities.numel()), ("attn", attn, densities.numel()),
+                     ("exp_avg", state[0], densities.numel()), ("exp_avg_sq", state[1], densities.numel()),
+                     ("rays_o", rays_o, 3 * R), ("rays_d", rays_d, 3 * R), ("attn_map", attn_map, R)):
+        require_device(t, f"attn_refine_step_ ({nm})")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+            raise VoxeError(f"attn_refine_step_: {nm} must be contiguous float32 with {n} elements")
+    for nm, t, n in (("losses", losses, 2), ("attn_render", attn_render, R)):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n):
+            raise VoxeError(f"attn_refine_step_: {nm} must be contiguous float32 with {n} elements on the device")
+    L = lib()
+    key = _pack_key(spec, densities, attn)
+    g, c = _descs(spec, params, densities, attn, rng[0], rng[1], workspace.key == key)
+    rs = abi.VoxeAttnRefineStep()
+    rs.attn_map, rs.tv_weight, rs.tv_loss_always = ptr(attn_map), float(tv_weight), int(bool(tv_loss_always))
+    rs.lr, rs.beta1, rs.beta2, rs.eps, rs.step = float(lr), float(beta1), float(beta2), float(eps), int(step)
+    rs.exp_avg, rs.exp_avg_sq = ptr(state[0]), ptr(state[1])
+    rs.losses, rs.attn_render = ptr(losses), ptr(attn_render)
+    with torch.cuda.device(device):
+        had = workspace.buf
+        ws = workspace.ensure(L.voxe_workspace_bytes(C.byref(g), C.byref(c), R), device)
+        # (a buffer this call allocated holds whatever torch.empty returned in its gradient region)
+        rs.zero_gradient_first = int(bool(zero_gradient_first) or ws is not had)
+        c.reuse_packed_grid = int(workspace.key == key)
+        need = L.voxe_attn_refine_scratch_bytes(C.byref(g), R)
+        sc = workspace.recon_scratch.get("refine")
+        if sc is None or sc.numel() < need or sc.device != ws.device:
+            sc = workspace.recon_scratch["refine"] = torch.empty(need, dtype=torch.uint8, device=device)
+        check(L.voxe_attn_refine_step(C.byref(g), C.byref(c), C.byref(rs), ptr(rays_o), ptr(rays_d), R, ptr(ws), ws.numel(),
+                                      ptr(sc), sc.numel(), stream_ptr(device)), "voxe_attn_refine_step")
+    for t in (attn, state[0], state[1]):
+        torch.autograd.graph.increment_version(t)
+    workspace.key = _pack_key(spec, densities, attn)       # the workspace holds the updated grid packed
     workspace.state_key = None
 
 
