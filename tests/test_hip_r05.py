@@ -101,3 +101,37 @@ def test_lean_deposit_passes_of_view_dependent_grids_vs_oracle_and_the_general_k
         assert rel_l2(got[0], rd) < 1e-4 and rel_l2(got[1], rf) < 1e-4, (rel_l2(got[0], rd), rel_l2(got[1], rf))
     assert rel_l2(lean[1], general[1]) < 2e-6 and rel_l2(lean[0], general[0]) < 2e-6
     assert rel_l2(lean[1], again[1]) < 2e-6
+
+
+@pytest.mark.parametrize("hw,cam,kl,side", [(96, 3, 8, 64), (96, 0, 8, 64), (90, 12, 10, 64), (100, 26, 0, 48), (70, 40, 8, 40)])
+def test_attention_backward_with_frozen_densities(hw, cam, kl, side, disp):
+    """attention grids whose densities are frozen (the refinement loop: modules/attn_grid_trainer.py:243-247; what
+    voxe_attn_refine_step runs): the LDS-window backward with want_densities = 0 against the oracle -- x / y / z-march cameras,
+    both window widths, image sides that are not multiples of 8, a depth gradient upstream as well -- under both values of
+    VoxeDispatch::tile_lean (a lean one-channel variant of the kernel was built on this test, measured and not shipped:
+    profiles/r05_attn_lean_null.txt)"""
+    from voxe_hip import ops
+    rng = np.random.default_rng(side + cam)
+    dens = rng.uniform(-1.0, 1.0, (side,) * 3 + (1,)).astype(np.float32)
+    attn = (rng.standard_normal((side,) * 3 + (1,)) - 0.5).astype(np.float32)
+    grid = vo.Grid(dens, attn, AABB, 20.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_ATTN)
+    o, d = _rays(hw, cam)
+    cfg = make_render_cfg(96, NEAR, FAR, perturb=True, white_bkgd=True, seed=2, rng_offset=5)
+    ga = rng.standard_normal((o.shape[0], 1)).astype(np.float32)
+    gdep = (0.1 * rng.standard_normal(o.shape[0])).astype(np.float32)
+    _, rf = vo.render_bwd(grid, cfg, o, d, ga, d_depth=gdep, want_densities=False)
+    spec = gh.spec_of(grid)
+    td, tf, to, tdir = gh.t(dens), gh.t(attn), gh.t(o), gh.t(d)
+    got = {}
+    for lean in (0, -1):
+        disp.set(tile_min_rays=-1, tile_kl=kl, tile_lean=lean)
+        params = gh.params_of(cfg, image_width=hw)
+        outs = [torch.empty((o.shape[0], n), device="cuda") for n in (1, 1, 1, 1)]
+        ws = ops.Workspace()
+        ops.render_fwd_into(spec, params, td, tf, to, tdir, None, *outs, ws, (2, 5))
+        d_f = torch.zeros_like(tf)
+        ops.render_bwd_into(spec, params, td, tf, to, tdir, None, outs[0], outs[1], outs[2], gh.t(ga), gh.t(gdep), None, None, d_f,
+                            ws, (2, 5))
+        got[lean] = gh.n(d_f)
+        assert rel_l2(got[lean], rf) < 1e-4, (lean, rel_l2(got[lean], rf))
+    assert rel_l2(got[0], got[-1]) < 2e-6, rel_l2(got[0], got[-1])
