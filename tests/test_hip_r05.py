@@ -135,3 +135,42 @@ def test_attention_backward_with_frozen_densities(hw, cam, kl, side, disp):
         got[lean] = gh.n(d_f)
         assert rel_l2(got[lean], rf) < 1e-4, (lean, rel_l2(got[lean], rf))
     assert rel_l2(got[0], got[-1]) < 2e-6, rel_l2(got[0], got[-1])
+
+
+@pytest.mark.parametrize("dims,C", [((37, 20, 24), 1), ((38, 12, 16), 3), ((5, 8, 4), 1), ((3, 4, 8), 3), ((17, 9, 7), 3)])
+def test_tv_pass_odd_shapes_vs_oracle(dims, C):
+    """the TV pass (tv_kernel_v4: 4 elements per vector; rows that do not vectorise -> tv_kernel) on x extents that are not
+    multiples of 4, grids smaller than one block and exact ties (sign(0) = 0): loss and gradient against the oracle
+    (modules/sds_trainer.py:563-567), accumulate on top of an existing gradient too.  (A variant with 4 consecutive x-planes per
+    thread was built on this test and measured slower: profiles/r05_grid_passes.txt)"""
+    import ctypes as C_
+    from voxe_hip.runtime import check, lib, ptr, stream_ptr
+    rng = np.random.default_rng(sum(dims) + C)
+    grid = rng.standard_normal((*dims, C)).astype(np.float32)
+    grid[1:3, 2:5] = grid[0:1, 2:5]                      # exact ties: sign(0) = 0
+    ref_loss, ref_grad = vo.tv_fwd_bwd(grid, 0.7)
+    tg = gh.t(grid)
+    L = lib()
+    sc = torch.empty(L.voxe_tv_scratch_bytes(*dims, C), dtype=torch.uint8, device="cuda")
+    loss = torch.zeros((), device="cuda")
+    base = rng.standard_normal(grid.shape).astype(np.float32)
+    for accumulate in (0, 1):
+        d_g = gh.t(base.copy())
+        check(L.voxe_tv_fwd_bwd(ptr(tg), *dims, C, 0.7, ptr(loss), ptr(d_g), accumulate, ptr(sc), sc.numel(), stream_ptr(tg.device)), "tv")
+        want = ref_grad + base if accumulate else ref_grad
+        assert rel_l2(gh.n(d_g), want) < 1e-6
+        assert abs(float(loss) - ref_loss) < 2e-6 * max(1.0, abs(ref_loss))
+
+
+@pytest.mark.parametrize("src_dims,dst_dims,C", [((20, 24, 28), (40, 48, 56), 1), ((20, 24, 28), (40, 48, 56), 3),
+                                                   ((16, 16, 16), (23, 23, 24), 3), ((10, 12, 9), (21, 17, 13), 1), ((8, 8, 8), (16, 16, 16), 2)])
+def test_upsample_shapes_vs_oracle(src_dims, dst_dims, C):
+    """up-sampling by factors other than 2, odd extents and 1 / 2 / 3 channels, bit for bit against the oracle's restatement of
+    voxels.py:409-447.  (A variant with four outputs per thread and 16-byte stores was built on this test and measured equal:
+    profiles/r05_grid_passes.txt)"""
+    from voxe_hip import ops
+    rng = np.random.default_rng(sum(src_dims) + C)
+    src = rng.standard_normal((*src_dims, C)).astype(np.float32)
+    ref = vo.upsample_trilinear(src, dst_dims)
+    up = ops.upsample_trilinear(gh.t(src), dst_dims)
+    np.testing.assert_array_equal(gh.n(up), ref)
