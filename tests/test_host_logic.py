@@ -69,6 +69,9 @@ def test_struct_layout_matches_header():
     #include <stddef.h>
     #include "voxe.h"
     int main(void) {
+      printf("%zu %zu %zu %zu %zu %zu %zu ", sizeof(VoxeAttnRefineStep), offsetof(VoxeAttnRefineStep, tv_loss_always),
+             offsetof(VoxeAttnRefineStep, step), offsetof(VoxeAttnRefineStep, exp_avg_sq), offsetof(VoxeAttnRefineStep, zero_gradient_first),
+             sizeof(VoxeReconStep), offsetof(VoxeReconStep, losses));
       printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(VoxeGridDesc), offsetof(VoxeGridDesc, aabb_lo),
              offsetof(VoxeGridDesc, density_scale), sizeof(VoxeRenderCfg), offsetof(VoxeRenderCfg, seed),
              offsetof(VoxeRenderCfg, reuse_packed_grid), offsetof(VoxeRenderCfg, image_width),
@@ -82,6 +85,10 @@ def test_struct_layout_matches_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), p, "-o", exe])
         vals = [int(v) for v in subprocess.check_output([exe]).split()]
     G, R, D = abi.VoxeGridDesc, abi.VoxeRenderCfg, abi.VoxeDispatch
+    A, RS = abi.VoxeAttnRefineStep, abi.VoxeReconStep          # (ABI v10 / v7: the per-iteration library calls)
+    assert vals[:7] == [ctypes.sizeof(A), A.tv_loss_always.offset, A.step.offset, A.exp_avg_sq.offset, A.zero_gradient_first.offset,
+                        ctypes.sizeof(RS), RS.losses.offset]
+    vals = vals[7:]
     assert vals == [ctypes.sizeof(G), G.aabb_lo.offset, G.density_scale.offset, ctypes.sizeof(R), R.seed.offset,
                     R.reuse_packed_grid.offset, R.image_width.offset, R.ray_state_valid.offset, R.dispatch.offset,
                     ctypes.sizeof(D), D.tile_min_rays.offset, D.fwd_window.offset, D.region_image_ratio.offset]
