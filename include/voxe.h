@@ -445,6 +445,13 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
  *   losses   : [2] device floats (or NULL): masked L1, TV (unweighted);
  *   scratch  : voxe_attn_refine_scratch_bytes(grid, R) bytes of device memory (outputs, upstream gradient, TV gradient).
  *   Afterwards `workspace` holds the updated grid packed and a cleared gradient region, like voxe_grid_adam_step.        */
+/* calc_loss_on_attn_grid  modules/refinement_functions.py:42-77 (+ autograd), on its own:
+ *   mask = render > 0;  *loss_out = sum(|render - map| * mask) / sum(mask);  d_render = ((1 / sum(mask)) * mask) * sign(render - map)
+ *   render, map, d_render: [n] device floats; loss_out: device float or NULL; scratch: voxe_attn_masked_l1_scratch_bytes() bytes. */
+size_t voxe_attn_masked_l1_scratch_bytes(void);
+int voxe_attn_masked_l1(const float* render, const float* attn_map, int64_t n, float* d_render, float* loss_out,
+                        void* scratch, size_t scratch_bytes, void* stream);
+
 typedef struct {
   const float* attn_map;        /* [R] device, row-major like the rays                                          */
   float tv_weight;              /* attn_tv_weight; 0: no TV gradient (and no TV pass unless tv_loss_always)      */

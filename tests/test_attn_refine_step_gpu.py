@@ -129,3 +129,29 @@ def test_refine_step_rejects_what_it_cannot_run():
     with pytest.raises(VoxeError):
         ops.attn_refine_step_(spec, params, dens, attn0.clone(), ro, rd, amap.reshape(-1)[:-1].contiguous(), ops.Workspace(), 1, 0.01,
                               state, 0.0)
+
+
+def test_masked_l1_kernel_vs_the_reference_golden(golden):
+    """voxe_attn_masked_l1 against calc_loss_on_attn_grid of the REFERENCE (modules/refinement_functions.py:42-77; loss and autograd
+    gradient recorded by tools/gen_golden.py in refine_graph.npz), against this package's Python restatement, and on a large image
+    (several blocks, every element exercised: gradient bit for bit against the torch expression)"""
+    g = golden("refine_graph.npz")
+    for tag in ("a", "b"):
+        render, amap = torch.from_numpy(g[f"loss_{tag}_render"]).to(DEV), torch.from_numpy(g[f"loss_{tag}_map"]).to(DEV)
+        loss, grad = ops.attn_masked_l1(render, amap)
+        assert abs(float(loss) - float(g[f"loss_{tag}_value"])) < 1e-6
+        np.testing.assert_allclose(grad.cpu().numpy(), g[f"loss_{tag}_grad"], rtol=1e-6, atol=0)
+    gen = torch.Generator().manual_seed(3)
+    render = (torch.rand((400 * 400, 1), generator=gen) * 1.5 - 0.5).to(DEV)
+    render[::7] = 0.0                                      # exactly on the mask's edge (render > 0 is false)
+    amap = torch.rand((400, 400), generator=gen).to(DEV)
+    render[5::11, 0] = amap.reshape(-1)[5::11]             # exact ties: sign(0) = 0
+    r = render.clone().requires_grad_(True)
+    ref = calc_loss_on_attn_grid(r, amap)
+    ref.backward()
+    loss, grad = ops.attn_masked_l1(render, amap)
+    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert torch.equal(grad, r.grad)
+    # nothing above zero: 0 / 0 like the reference
+    loss0, grad0 = ops.attn_masked_l1(-torch.ones((50, 1), device=DEV), torch.rand((5, 10), device=DEV))
+    assert torch.isnan(loss0) and torch.isnan(grad0).all()

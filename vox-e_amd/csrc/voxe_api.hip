@@ -728,6 +728,18 @@ RefineLayout refine_layout(const VoxeGridDesc* g, int64_t R) {
 }
 }  // namespace
 
+size_t voxe_attn_masked_l1_scratch_bytes(void) { return attn_l1_scratch_bytes(); }
+
+int voxe_attn_masked_l1(const float* render, const float* attn_map, int64_t n, float* d_render, float* loss_out, void* scratch,
+                        size_t scratch_bytes, void* stream) {
+  if (n < 0) return VOXE_ERR_BAD_SHAPE;
+  if (n == 0) return VOXE_OK;
+  if (!render || !attn_map || !d_render) return VOXE_ERR_NULL_POINTER;
+  if (!scratch || scratch_bytes < attn_l1_scratch_bytes()) return VOXE_ERR_WORKSPACE;
+  launch_attn_masked_l1(render, attn_map, n, d_render, loss_out, scratch, (hipStream_t)stream);
+  return finish();
+}
+
 size_t voxe_attn_refine_scratch_bytes(const VoxeGridDesc* grid, int64_t R) {
   if (!grid || grid->X <= 0 || grid->Y <= 0 || grid->Z <= 0 || R <= 0) return 0;
   return refine_layout(grid, R).total;

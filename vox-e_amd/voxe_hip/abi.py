@@ -194,6 +194,8 @@ HIP_ONLY = {
     "region_debug_layout": (C.c_int, [_GD, _RC, C.c_int64, C.POINTER(C.c_int64)]),
     "recon_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "recon_step": (C.c_int, [_GD, _RC, C.POINTER(VoxeReconStep), _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "attn_masked_l1_scratch_bytes": (C.c_size_t, []),
+    "attn_masked_l1": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "attn_refine_scratch_bytes": (C.c_size_t, [_GD, C.c_int64]),
     "attn_refine_step": (C.c_int, [_GD, _RC, C.POINTER(VoxeAttnRefineStep), _P, _P, C.c_int64, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "dcl_scratch_bytes": (C.c_size_t, [C.c_int64]),

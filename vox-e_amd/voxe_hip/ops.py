@@ -655,6 +655,27 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
 
 
 @torch.no_grad()
+def attn_masked_l1(render: torch.Tensor, attn_map: torch.Tensor):
+    """voxe_attn_masked_l1: calc_loss_on_attn_grid (modules/refinement_functions.py:42-77) and its gradient w.r.t. the render.
+    Returns (loss [scalar tensor], d_render like `render`)."""
+    require_device(render, "attn_masked_l1 (render)")
+    require_device(attn_map, "attn_masked_l1 (attn_map)")
+    r, m = f32c(render.detach()).reshape(-1), f32c(attn_map.detach()).reshape(-1)
+    if r.numel() != m.numel():
+        raise VoxeError(f"attn_masked_l1: render ({r.numel()}) and map ({m.numel()}) differ in size")
+    device = r.device
+    ensure_gfx950(device)
+    L = lib()
+    d_r = torch.empty_like(r)
+    loss = torch.zeros((), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        sc = _scratch_for(device, L.voxe_attn_masked_l1_scratch_bytes())
+        check(L.voxe_attn_masked_l1(ptr(r), ptr(m), r.numel(), ptr(d_r), ptr(loss), ptr(sc), sc.numel(), stream_ptr(device)),
+              "voxe_attn_masked_l1")
+    return loss, d_r.reshape(render.shape)
+
+
+@torch.no_grad()
 def attn_refine_step_(spec: GridSpec, params: RenderParams, densities, attn, rays_o, rays_d, attn_map, workspace: Workspace,
                       step: int, lr: float, state, tv_weight: float, losses: Optional[torch.Tensor] = None, rng=(0, 0),
                       beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, attn_render: Optional[torch.Tensor] = None,
