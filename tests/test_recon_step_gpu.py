@@ -90,6 +90,60 @@ def test_recon_step_equals_the_composed_iteration(batch, diffuse):
     assert float(((d_a.detach() - dens0).abs() > 0).float().mean()) > 0.05
 
 
+@pytest.mark.parametrize("batch", [20000, 3000])
+def test_recon_step_first_iteration_against_the_oracle(batch):
+    """the test above is HIP against HIP.  Here the first iteration of voxe_recon_step against the CPU oracle composed
+    by hand the way modules/trainers.py:288-351 reads: random subset of the K * H * W pixels -> rays + target pixels -> specular
+    and diffuse render (jitter streams offset + 1 / + 2) -> L1 losses and their gradients -> both backward passes summed -> Adam.
+    Compared where Adam's normalisation has not yet amplified rounding: the losses, exp_avg = (1 - beta1) * gradient, and the
+    parameters of every voxel whose gradient is far above the noise of the float atomics."""
+    import dataclasses
+
+    from oracle import voxe_oracle as vo
+    from voxe_hip.desc import make_render_cfg
+
+    side, hw, K = 40, 72, 5
+    dens0, feat0, poses, images, spec, params = _setup(side, hw, K)
+    rows = torch.tensor([3, 0, 4, 1, 2], device=DEV)
+    lr, seed, off = 2e-2, 13, 4000
+    # ---- oracle
+    subset = vo.random_subset(K * hw * hw, batch, seed, off)
+    o, d = vo.cast_rays_indexed(hw, hw, focal_for(hw), poses.cpu().numpy(), subset)
+    cam, rem = subset // (hw * hw), subset % (hw * hw)
+    target = images.cpu().numpy()[rows.cpu().numpy()[cam], :, rem // hw, rem % hw].astype(np.float32)
+    grid = vo.Grid(dens0.cpu().numpy(), feat0.cpu().numpy(), [(-1.5, 1.5)] * 3, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    gd_sum, gf_sum, ref_l1 = np.zeros_like(grid.densities), np.zeros_like(grid.features), []
+    for i, diffuse in enumerate((False, True)):
+        cfg = make_render_cfg(params.num_samples, NEAR, FAR, perturb=True, white_bkgd=True, seed=seed, rng_offset=off + 1 + i,
+                              render_diffuse=diffuse)
+        col = vo.render_fwd(grid, cfg, o, d)["colour"]
+        diff = col - target
+        ref_l1.append(float(np.abs(diff).astype(np.float64).mean()))
+        g_col = (np.sign(diff) * np.float32(1.0 / diff.size)).astype(np.float32)
+        gd, gf = vo.render_bwd(grid, cfg, o, d, g_col)
+        gd_sum += gd
+        gf_sum += gf
+    pd, pf = grid.densities.reshape(-1).copy(), grid.features.reshape(-1).copy()
+    for p_, g_ in ((pd, gd_sum.reshape(-1)), (pf, gf_sum.reshape(-1))):
+        vo.adam_step(p_, np.ascontiguousarray(g_), np.zeros_like(p_), np.zeros_like(p_), lr, 0.9, 0.999, 1e-8, 1)
+    # ---- the one call
+    d_b, f_b = dens0.clone(), feat0.clone()
+    st_d = (torch.zeros_like(d_b), torch.zeros_like(d_b))
+    st_f = (torch.zeros_like(f_b), torch.zeros_like(f_b))
+    losses = torch.zeros(4, device=DEV)
+    ops.recon_step_(spec, params, d_b, f_b, ops.Workspace(), ops.Workspace(), hw, hw, focal_for(hw), poses, rows, images, batch, True,
+                    st_d, st_f, 1, 1, lr, losses, (seed, off), zero_gradient_first=True)
+    got = losses.tolist()
+    assert abs(got[0] - ref_l1[0]) < 2e-6 and abs(got[2] - ref_l1[1]) < 2e-6, (got, ref_l1)
+    for m1, g_ref, p_lib, p_ref in ((st_d[0], gd_sum, d_b, pd), (st_f[0], gf_sum, f_b, pf)):
+        g_lib = m1.cpu().numpy().reshape(-1) / np.float32(0.1)
+        g_ref = g_ref.reshape(-1)
+        assert np.linalg.norm(g_lib - g_ref) / np.linalg.norm(g_ref) < 1e-4
+        big = np.abs(g_ref) > 1e-3 * np.abs(g_ref).max()
+        assert big.sum() > 100
+        assert np.abs(p_lib.cpu().numpy().reshape(-1) - p_ref)[big].max() < 1e-3 * lr
+
+
 def test_fused_grid_adam_reconstruction_step_drives_the_trainer_state():
     """the optimiser-level wrapper: step counters, learning rate and Adam state are the optimiser's"""
     from thre3d_atom.modules.optim import FusedGridAdam
