@@ -374,3 +374,60 @@ def test_wide_texel_grid_step_chunks_tail_and_slabs(case):
         packed = ops.workspace_packed_view(spec, dens, feat, ws).view(*dims, C)[sl]
         assert torch.equal(packed[..., :F], feat[sl]) and torch.equal(packed[..., F:], (dens[sl] * 3.0).abs())
         assert float(ops.workspace_grad_view(spec, dens, feat, ws)[x0 * 36 * C: x1 * 36 * C].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", ["sh0_tile", "sh0_scatter_bricked_odd", "sh0_preact_abs_relu", "attn_frozen_density", "sh1_linear"])
+def test_fused_step_first_step_against_the_oracle(case):
+    """the equivalence test above compares product paths with each other.  Here ONE fused step (voxe_render_fwd ->
+    voxe_render_bwd_acc -> voxe_grid_adam_step from the zero Adam state) against the CPU oracle: its render gradient w.r.t. the
+    API tensors (chain rule of the density pre-activation included) and its restatement of torch.optim.Adam -- exp_avg =
+    (1 - beta1) * gradient in the rel-L2 sense, parameters on every voxel whose gradient is far above the float atomics' noise"""
+    import numpy as np
+
+    from oracle import voxe_oracle as vo
+    from voxe_hip.desc import make_render_cfg
+
+    side, nfeat, hw, ordered, dims, kind, pre, post, freeze = {
+        "sh0_tile": (40, 3, 96, True, None, "sh", "identity", "softplus", False),
+        "sh0_scatter_bricked_odd": (40, 3, 64, False, (37, 40, 33), "sh", "identity", "softplus", False),
+        "sh0_preact_abs_relu": (40, 3, 96, True, None, "sh", "abs", "relu", False),
+        "attn_frozen_density": (40, 1, 96, True, None, "attn", "identity", "relu", True),
+        "sh1_linear": (24, 12, 48, True, None, "sh1", "identity", "softplus", False),
+    }[case]
+    dens, feat, ro, rd = _scene(side, nfeat, hw, ordered, dims)
+    acts = {"identity": abi.ACT_IDENTITY, "abs": abi.ACT_ABS, "relu": abi.ACT_RELU, "softplus": abi.ACT_SOFTPLUS}
+    scale = 100.0 / 3.0 if post == "softplus" else 1.0
+    fk = abi.FEAT_ATTN if kind == "attn" else abi.FEAT_SH
+    deg = 1 if kind == "sh1" else 0
+    spec = ops.GridSpec(aabb=AABB, density_scale=scale, density_pre_act=acts[pre], density_post_act=acts[post], feature_kind=fk)
+    params = ops.RenderParams(num_samples=96, near=NEAR, far=FAR, perturb=True, white_bkgd=kind != "attn", sh_degree=deg,
+                              image_width=hw if ordered else 0, dispatch=dispatch.TILE_ALWAYS if ordered else None)
+    cout = 1 if kind == "attn" else 3
+    R = ro.shape[0]
+    g_col = torch.randn((R, cout), generator=torch.Generator().manual_seed(9)).to(dens.device)
+    # ---- oracle: gradient of sum(colour * g_col) w.r.t. the API tensors, then Adam
+    grid = vo.Grid(dens.cpu().numpy(), feat.cpu().numpy(), [(-1.5, 1.5)] * 3, scale, acts[pre], acts[post], fk)
+    cfg = make_render_cfg(96, NEAR, FAR, perturb=True, white_bkgd=kind != "attn", sh_degree=deg, seed=21, rng_offset=5)
+    gd, gf = vo.render_bwd(grid, cfg, ro.cpu().numpy(), rd.cpu().numpy(), g_col.cpu().numpy())
+    # ---- one fused step
+    d, f = dens.clone(), feat.clone()
+    st_d = None if freeze else (torch.zeros_like(d), torch.zeros_like(d))
+    st_f = (torch.zeros_like(f), torch.zeros_like(f))
+    outs = [torch.empty((R, n), device=d.device) for n in (cout, 1, 1, 1)]
+    ws = ops.Workspace()
+    ops.render_fwd_into(spec, params, d, f, ro, rd, None, *outs, ws, (21, 5))
+    layout = ops.render_bwd_acc(spec, params, d, f, ro, rd, None, outs[0], outs[1], outs[2], g_col, None, None, ws, (21, 5),
+                                zero_first=True, want_densities=not freeze)
+    ops.grid_adam_step_(spec, d, f, layout, ws, 1, LR, state_densities=st_d, state_features=st_f)
+    checks = [(st_f[0], gf, f, feat)] + ([] if freeze else [(st_d[0], gd, d, dens)])
+    for m1, g_ref, p_new, p_old in checks:
+        g_ref = np.asarray(g_ref, dtype=np.float32).reshape(-1)
+        g_lib = m1.cpu().numpy().reshape(-1) / np.float32(0.1)
+        assert np.linalg.norm(g_lib - g_ref) / np.linalg.norm(g_ref) < 1e-4
+        p_ref = p_old.cpu().numpy().reshape(-1).copy()
+        vo.adam_step(p_ref, g_ref, np.zeros_like(p_ref), np.zeros_like(p_ref), LR, 0.9, 0.999, 1e-8, 1)
+        big = np.abs(g_ref) > 1e-3 * np.abs(g_ref).max()
+        assert big.sum() > 100
+        assert np.abs(p_new.cpu().numpy().reshape(-1) - p_ref)[big].max() < 1e-3 * LR
+    if freeze:
+        assert torch.equal(d, dens)
