@@ -218,6 +218,24 @@ def test_reference_checkpoint_loads_and_product_refuses_cpu():
             vm.render_rays(rays)
 
 
+def test_per_iteration_entry_points_refuse_cpu_tensors():
+    """the r05 entry points (voxe_attn_refine_step, voxe_attn_masked_l1) have no CPU path either: CPU tensors raise VoxeError
+    before anything is launched -- on a box without a GPU as well as on one with"""
+    from voxe_hip import ops
+    from voxe_hip.runtime import VoxeError
+
+    spec = ops.GridSpec(aabb=((-1.5, 1.5),) * 3, density_scale=3.0, feature_kind=abi.FEAT_ATTN)
+    params = ops.RenderParams(num_samples=8, near=1.8, far=6.6, image_width=4)
+    dens, attn = torch.zeros(4, 4, 4, 1), torch.zeros(4, 4, 4, 1)
+    rays = torch.zeros(16, 3)
+    state = (torch.zeros_like(attn), torch.zeros_like(attn))
+    with pytest.raises(VoxeError):
+        ops.attn_refine_step_(spec, params, dens, attn, rays, rays + 1.0, torch.zeros(16), ops.Workspace(), 1, 0.01, state, 0.0)
+    with pytest.raises(VoxeError):
+        ops.attn_masked_l1(torch.zeros(16, 1), torch.zeros(4, 4))
+    assert attn.abs().sum() == 0 and state[0].abs().sum() == 0
+
+
 def test_datasets_on_disk_format_and_downsampling(tmp_path):
     """`*_camera_params.json` + image folder (reference data/datasets.py, data/constants.py) round trip."""
     import json

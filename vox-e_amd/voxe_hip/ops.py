@@ -685,7 +685,6 @@ def attn_refine_step_(spec: GridSpec, params: RenderParams, densities, attn, ray
     (`state` = (exp_avg, exp_avg_sq); the densities are frozen).  `losses` [2] (device) receives masked L1 and TV (unweighted),
     `attn_render` [R] the rendered attention image."""
     device = densities.device
-    ensure_gfx950(device)
     if spec.feature_kind != abi.FEAT_ATTN:
         raise VoxeError("attn_refine_step_ needs an attention grid spec (feature_kind = FEAT_ATTN)")
     R = int(rays_o.shape[0])
@@ -698,6 +697,7 @@ def attn_refine_step_(spec: GridSpec, params: RenderParams, densities, attn, ray
     for nm, t, n in (("losses", losses, 2), ("attn_render", attn_render, R)):
         if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n):
             raise VoxeError(f"attn_refine_step_: {nm} must be contiguous float32 with {n} elements on the device")
+    ensure_gfx950(device)      # (behind the tensor checks: CPU tensors are refused with a VoxeError, GPU or not)
     L = lib()
     key = _pack_key(spec, densities, attn)
     g, c = _descs(spec, params, densities, attn, rng[0], rng[1], workspace.key == key)
