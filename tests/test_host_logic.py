@@ -234,6 +234,11 @@ def test_per_iteration_entry_points_refuse_cpu_tensors():
     with pytest.raises(VoxeError):
         ops.attn_masked_l1(torch.zeros(16, 1), torch.zeros(4, 4))
     assert attn.abs().sum() == 0 and state[0].abs().sum() == 0
+    # ... and every entry point that asks for the device first says the same (not a bare RuntimeError from torch.cuda)
+    with pytest.raises(VoxeError):
+        ops.grid_adam_step_(spec, dens, attn, abi.GRAD_LINEAR, ops.Workspace(), 1, 0.01, state_features=state)
+    with pytest.raises(VoxeError):
+        ops.render_fwd_into(spec, params, dens, attn, rays, rays + 1.0, None, *[torch.zeros(16, 1) for _ in range(4)], ops.Workspace())
 
 
 def test_datasets_on_disk_format_and_downsampling(tmp_path):

@@ -83,6 +83,9 @@ _device_checked = set()
 
 
 def ensure_gfx950(device) -> None:
+    if torch.device(device).type != "cuda":
+        raise VoxeError(f"the voxe HIP path only runs on a ROCm GPU, not on {torch.device(device)} (there is no CPU fallback in "
+                        f"the product path)")
     idx = torch.device(device).index
     if idx is None:
         idx = torch.cuda.current_device()
