@@ -160,7 +160,8 @@ typedef struct VoxeRenderCfg {
                                  library checks (r05): every forward records, per workspace address, what it
                                  rendered there (grid, rays, jitter, cfg, dispatch, whether the per-sample values
                                  were kept); a backward whose claim does not match the record -- after a forward
-                                 with -1, or a forward of other rays in between -- re-marches as if given 0.      */
+                                 with -1, a forward of other rays in between, or a voxe_grid_adam_step on this
+                                 workspace (the parameters moved) -- re-marches as if given 0.                    */
   const VoxeDispatch* dispatch; /* HOST pointer, NULL = the shipped dispatch; read during the call only (ABI v7)      */
 } VoxeRenderCfg;
 

@@ -682,3 +682,40 @@ def test_a_false_ray_state_valid_claim_is_served_by_a_re_march(order):
     for mode in ("inference_forward", "other_rays_in_between"):
         for a, b in zip(got["honest"], got[mode]):
             assert rel_l2(a, b) < 2e-6, mode
+
+
+def test_a_grid_step_between_forward_and_backward_invalidates_the_claim(tile_always):
+    """ray_state_valid = 1 after voxe_grid_adam_step moved the parameters: the states in the workspace describe the OLD grid; the
+    library forgets its record of the forward with the step, so the backward re-marches on the NEW grid and equals a fresh
+    forward + backward there"""
+    from voxe_hip import ops
+    rng = np.random.default_rng(8)
+    dims = (32, 32, 32)
+    dens = rng.uniform(-1, 1, (*dims, 1)).astype(np.float32)
+    feat = rng.uniform(-1, 1, (*dims, 3)).astype(np.float32)
+    grid = vo.Grid(dens, feat, [(-1.5, 1.5)] * 3, 3.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS, abi.FEAT_SH)
+    hw = 64
+    o, d = _rays(hw, 5)
+    cfg = make_render_cfg(64, NEAR, FAR, white_bkgd=True, perturb=True, seed=2, rng_offset=3)
+    spec, params = gh.spec_of(grid), gh.params_of(cfg, image_width=hw)
+    td, tf, to, tdir = gh.t(dens), gh.t(feat), gh.t(o), gh.t(d)
+    gc = gh.t(rng.standard_normal((o.shape[0], 3)).astype(np.float32))
+    outs = [torch.empty((o.shape[0], n), device="cuda") for n in (3, 1, 1, 1)]
+    ws = ops.Workspace()
+    ops.render_fwd_into(spec, params, td, tf, to, tdir, None, *outs, ws, (2, 3))
+    claim = ws.state_key
+    layout = ops.render_bwd_acc(spec, params, td, tf, to, tdir, None, outs[0], outs[1], outs[2], gc, None, None, ws, (2, 3), zero_first=True)
+    st_d, st_f = (torch.zeros_like(td), torch.zeros_like(td)), (torch.zeros_like(tf), torch.zeros_like(tf))
+    ops.grid_adam_step_(spec, td, tf, layout, ws, 1, 0.05, state_densities=st_d, state_features=st_f)      # the grid moves by ~lr
+    # a careless caller: backward of the OLD forward's outputs with the claim that the workspace still holds its states
+    fresh = [torch.empty_like(t_) for t_ in outs]
+    ws2 = ops.Workspace()
+    ops.render_fwd_into(spec, params, td, tf, to, tdir, None, *fresh, ws2, (2, 3))
+    want_d, want_f = torch.zeros_like(td), torch.zeros_like(tf)
+    ops.render_bwd_into(spec, params, td, tf, to, tdir, None, fresh[0], fresh[1], fresh[2], gc, None, None, want_d, want_f, ws2, (2, 3))
+    assert claim is not None and ws.state_key is None                # (the binding itself drops its claim with the step)
+    g_, c_ = ops._descs(spec, params, td, tf, 2, 3, False)
+    ws.state_key = ops._state_key(ops._pack_key(spec, td, tf), params, to, tdir, None, (2, 3), ops._route(g_, c_, o.shape[0]))
+    got_d, got_f = torch.zeros_like(td), torch.zeros_like(tf)
+    ops.render_bwd_into(spec, params, td, tf, to, tdir, None, fresh[0], fresh[1], fresh[2], gc, None, None, got_d, got_f, ws, (2, 3))
+    assert rel_l2(gh.n(got_d), gh.n(want_d)) < 2e-6 and rel_l2(gh.n(got_f), gh.n(want_f)) < 2e-6

@@ -841,6 +841,9 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
                                    (hipStream_t)stream);
   }
   if (x_begin == x_end) return VOXE_OK;
+  // the parameters move: the per-ray states a forward left in this workspace no longer describe the grid -- a backward that still
+  // claims ray_state_valid = 1 afterwards is served by a re-march
+  forget_stamp(workspace);
   if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, x_begin, x_end, (float*)((char*)workspace + l.grad_off),
                         extra_d_densities, extra_d_features, exp_avg_d, exp_avg_sq_d, exp_avg_f, exp_avg_sq_f, lr, beta1,
                         beta2, eps, step, step_features > 0 ? step_features : step,
