@@ -111,7 +111,10 @@ template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE, int KL
 #ifndef VOXE_TILE_WIDE_FROM
 #define VOXE_TILE_WIDE_FROM 9     // windows at least this wide get the relaxed register budget (2 waves per SIMD)
 #endif
-__global__ __launch_bounds__(64, ((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE_FROM) ? 2 : VOXE_TILE_LB) void render_bwd_tile_kernel(
+// (attention grids with frozen densities -- the refinement loop -- hold a 2-channel window of 6 - 10 KB and need 126 - 130
+//  registers: asked to fit 128, they run 4 waves per SIMD; r05)
+__global__ __launch_bounds__(64, (COUT == 1 && NCU == 1 && !WANT_D && !DET) ? 4
+                                 : (((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE_FROM) ? 2 : VOXE_TILE_LB)) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
