@@ -582,7 +582,9 @@ __device__ __forceinline__ RegionBlock region_block(const DevGrid& g, unsigned r
 
 // ---- pass 3: forward, one block per region -----------------------------------------------------------------------------------
 template <int COUT, int NCM, int NCU>
-__global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_fwd_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
+// (r05: 4-channel texels need 91 registers = 5 waves per SIMD; asked to fit 80 they run 6 -- 133 -> 123 us on the reconstruction batch;
+//  7 is equal, 8 spills: 160 us.  View-dependent instantiations keep their budget.)
+__global__ __launch_bounds__(VOXE_REGION_BLOCK, NCU == 1 ? 6 : 1) void region_fwd_kernel(DevGrid g, DevCfg c, const float* __restrict__ packed,
                                                                        const float* __restrict__ rays_o,
                                                                        const float* __restrict__ rays_d,
                                                                        const float* __restrict__ jitter, BinScratch bs,
