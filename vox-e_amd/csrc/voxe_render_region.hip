@@ -103,7 +103,16 @@ constexpr int kSlotsPerLane = VOXE_REGION_SLOTS;  // segment slots of one (ray, 
                                    // passes instead of 4 / 7: fewer footprint re-computations), 13 -> 1.22 / 3.27 (77 KB: 2 blocks per CU)
 #endif
 #ifndef VOXE_REGION_BWD_TEX
-#define VOXE_REGION_BWD_TEX 1      // backward: stage the region's texels in LDS too (0: gather them from L1 / L2)
+#define VOXE_REGION_BWD_TEX 2      // backward: stage the region's texels in LDS too: 1 always | 0 never (gather them from L1 / L2) |
+                                   // 2 (r05) by launch: the channel-strided texels of wide grids (NCM > 1) always, packed 16- / 8-byte
+                                   // texels only from VOXE_REGION_TEX_MIN_RAYS rays on.  Below, they come from L1 / L2: without the
+                                   // 11.7 KB the banked kernel holds 36 KB of LDS and, asked to fit 128 registers, runs 4 blocks per CU
+                                   // instead of 3 (backward, staged -> from L2: 32 761 rays 0.218 -> 0.212 ms, 65 536 0.278 -> 0.263,
+                                   // the reconstruction batch 0.323 -> 0.296; 160 000 rays 0.485 -> 0.513: regions that full re-use a
+                                   // staged texel often enough to pay for the residency)
+#endif
+#ifndef VOXE_REGION_TEX_MIN_RAYS
+#define VOXE_REGION_TEX_MIN_RAYS 110000
 #endif
 constexpr unsigned kNoRegion = 0xFFFFFFFFu;
 // Segments of a region are grouped by LENGTH class (longest first): the lanes of a wave then run similar trip counts
@@ -783,15 +792,15 @@ __global__ __launch_bounds__(256) void region_fold_kernel(DevCfg c, BinScratch b
 }
 
 // ---- pass 5: backward, one block per region ------------------------------------------------------------------------------------
-template <int COUT, int NCM, bool BANKED>
-__global__ __launch_bounds__(VOXE_REGION_BLOCK) void region_bwd_kernel(
+template <int COUT, int NCM, bool BANKED, bool TEXLDS>
+__global__ __launch_bounds__(VOXE_REGION_BLOCK, TEXLDS ? 1 : 4) void region_bwd_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
     const float* __restrict__ jitter, const float* __restrict__ colour, const float* __restrict__ depth,
     const float* __restrict__ acc, const float* __restrict__ d_colour, const float* __restrict__ d_depth,
     const float* __restrict__ d_acc, float* __restrict__ gpacked, const int want_d, const int want_f, BinScratch bs,
     const int nreg) {
   constexpr int C = COUT + 1, CM = COUT * NCM + 1;
-  constexpr bool kTexLds = VOXE_REGION_BWD_TEX != 0;
+  constexpr bool kTexLds = TEXLDS;
   constexpr bool kPcb = BANKED && C == 4;
   constexpr int kWinDoubles = kPcb ? kPcbDoubles : C * kRPlane;
   __shared__ float tex[kTexLds ? kRWin * C : 1];
@@ -1329,15 +1338,22 @@ static void launch_bwd_region_t(const DevGrid& g, const DevCfg& c, const BwdArgs
     // pays when the regions are FULL: 160 000 unordered rays 0.79 -> 0.51 ms, 80 000 (8 cameras of 100x100) 0.373 -> 0.357,
     // but 32 768 (a reconstruction batch: ~110 segments per region, under two waves) 0.246 -> 0.287 per render
     // (profiles/r04_ab_lds_layout.txt).  VOXE_REGION_PCB = 0 builds without it.
-    if (VOXE_REGION_PCB && COUT == 3 && c.R >= kBankedMinRays) {
-      region_bwd_kernel<COUT, NCM, true><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
-          g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
-          a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+    // texels staged in LDS or gathered from L1 / L2 (VOXE_REGION_BWD_TEX)
+    const bool stage = VOXE_REGION_BWD_TEX == 1 || (VOXE_REGION_BWD_TEX == 2 && (NCM > 1 || c.R >= (long long)VOXE_REGION_TEX_MIN_RAYS));
+    const bool banked = VOXE_REGION_PCB && COUT == 3 && c.R >= kBankedMinRays;
+#define VOXE_RBWD(B, T)                                                                                                          \
+    region_bwd_kernel<COUT, NCM, B, T><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(                                   \
+        g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,       \
+        a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg)
+    if constexpr (NCM > 1) {      // (wide grids: always staged -- the un-staged instantiations are not built)
+      if (banked) VOXE_RBWD(true, true); else VOXE_RBWD(false, true);
     } else {
-      region_bwd_kernel<COUT, NCM, false><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, 0, st>>>(
-          g, c, a.packed, a.rays_o, a.rays_d, a.jitter, a.colour, a.depth, a.acc, a.d_colour, a.d_depth, a.d_acc, a.gpacked,
-          a.want_d ? 1 : 0, a.want_f ? 1 : 0, bs, l.nreg);
+      if (banked && stage) VOXE_RBWD(true, true);
+      else if (banked) VOXE_RBWD(true, false);
+      else if (stage) VOXE_RBWD(false, true);
+      else VOXE_RBWD(false, false);
     }
+#undef VOXE_RBWD
   } else {
     float4* src = (float4*)((char*)scratch + l.src);
     // the forward that filled these tables (voxe_render_fwd on this workspace, or the backward's own re-march) kept its samples
