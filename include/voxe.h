@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 10
+#define VOXE_ABI_VERSION 11
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -161,7 +161,12 @@ typedef struct VoxeRenderCfg {
                                  rendered there (grid, rays, jitter, cfg, dispatch, whether the per-sample values
                                  were kept); a backward whose claim does not match the record -- after a forward
                                  with -1, a forward of other rays in between, or a voxe_grid_adam_step on this
-                                 workspace (the parameters moved) -- re-marches as if given 0.                    */
+                                 workspace (the parameters moved) -- re-marches as if given 0.  voxe_grid_adam_step
+                                 and voxe_adam_step also drop the record of EVERY workspace whose forward read the
+                                 tensors they rewrite (r06).  What the record compares is identity -- pointers,
+                                 shapes, AABB, cfg, dispatch -- never CONTENTS: a caller that rewrites the grid, the
+                                 rays or the jitter in place by other means (its own kernels, a copy into the same
+                                 buffer) must pass 0.                                                            */
   const VoxeDispatch* dispatch; /* HOST pointer, NULL = the shipped dispatch; read during the call only (ABI v7)      */
 } VoxeRenderCfg;
 
@@ -297,6 +302,25 @@ int voxe_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale
                      float* loss_out, float* d_a, int32_t accumulate,
                      void* scratch, size_t scratch_bytes, void* stream);
 
+/* density_correlation_loss_fn's l2_mode / l1_mode  modules/sds_trainer.py:494-503 (+ autograd)
+ *   VOXE_DREG_L2: loss = mean((a - b)^2)  (torch mse_loss),  d_a = grad_scale * 2 (a - b) / n
+ *   VOXE_DREG_L1: loss = mean(|a - b|)    (torch l1_loss),   d_a = grad_scale * sign(a - b) / n   (sign(0) = 0)
+ *   a = sds densities (differentiated), b = regular densities (constant); loss_out: 1 float or NULL; d_a: n floats or NULL
+ *   (accumulate as above); scratch: >= voxe_dcl_scratch_bytes(n) bytes (only read when loss_out != NULL).
+ *   VOXE_DREG_CORRELATION names the default (_density_correlation_loss, voxe_dcl_fwd_bwd) in VoxeGridRegularisers.      */
+enum { VOXE_DREG_CORRELATION = 0, VOXE_DREG_L2 = 1, VOXE_DREG_L1 = 2 };
+int voxe_density_diff_fwd_bwd(const float* a, const float* b, int64_t n, int32_t kind, float grad_scale,
+                              float* loss_out, float* d_a, int32_t accumulate,
+                              void* scratch, size_t scratch_bytes, void* stream);
+
+/* _feature_correlation_loss  modules/sds_trainer.py:526-534 (+ autograd): f = sds features [nvox, F] (differentiated),
+ *   r = regular features (constant):  D_v = sum_c (sigmoid(f_vc) - sigmoid(r_vc));  loss = sum_v D_v^2;
+ *   d_f[v, c] = grad_scale * 2 D_v sigmoid(f_vc) (1 - sigmoid(f_vc)).  loss_out: 1 float or NULL; d_f: nvox * F floats or NULL
+ *   (accumulate as above); scratch: >= voxe_dcl_scratch_bytes(nvox) bytes.  1 <= F <= 64.                                */
+int voxe_feature_correlation_fwd_bwd(const float* f, const float* r, int64_t nvox, int32_t F, float grad_scale,
+                                     float* loss_out, float* d_f, int32_t accumulate,
+                                     void* scratch, size_t scratch_bytes, void* stream);
+
 /* _tv_loss_on_grid  modules/sds_trainer.py:563-567 : grid [X,Y,Z,C]
  *   loss = (mean|diff_x| + mean|diff_y| + mean|diff_z|)/3 ; d_grid accumulates grad_scale * dloss/dgrid */
 size_t voxe_tv_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t C);
@@ -362,6 +386,18 @@ typedef struct VoxeGridRegularisers {
   float* dcl_loss;              /* device float[1] or NULL: receives 1 - corr (unweighted, what the trainer logs)         */
   void* scratch;                /* >= voxe_dcl_scratch_bytes(X * Y * Z) bytes of device memory                            */
   size_t scratch_bytes;
+  /* ABI v11: every regulariser the edit's CLI can switch on is a term of the fused step (no torch op, no gradient tensor)   */
+  int32_t density_kind;         /* VOXE_DREG_*: what (dcl_reference, dcl_weight, dcl_loss) mean.  L2 / L1 are per-voxel
+                                   terms with NO reduction (a reduction runs only when dcl_loss != NULL) and, unlike the
+                                   correlation, also work on a slab (x_begin, x_end) -- the loss value then is the slab's
+                                   share: sum over the slab / (X Y Z)                                                      */
+  const float* feat_reference;  /* [X,Y,Z,F] features of the pretrained field (constant), device; NULL = no term:
+                                   _feature_correlation_loss (sds_trainer.py:526-534) evaluated per voxel inside the step
+                                   on the parameters the step starts from.  SH-0 / attention grids (F <= 3);
+                                   VOXE_ERR_UNSUPPORTED for wider texels (use voxe_feature_correlation_fwd_bwd +
+                                   extra_d_features there)                                                                */
+  float feat_weight;            /* feature_correlation_weight (x any 1 / world factor)                                    */
+  float* feat_loss;             /* device float[1] or NULL: the unweighted loss value (a reduction of its own)            */
 } VoxeGridRegularisers;
 int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x_begin, int32_t x_end,
                         const float* extra_d_densities, const float* extra_d_features,
@@ -567,6 +603,10 @@ int voxe_cpu_sample_probe(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
                           int32_t* idx, uint8_t* inside, float* zvals, float* sigma, float* rad);
 int voxe_cpu_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale,
                          float* loss_out, float* d_a, int32_t accumulate);
+int voxe_cpu_density_diff_fwd_bwd(const float* a, const float* b, int64_t n, int32_t kind, float grad_scale,
+                                  float* loss_out, float* d_a, int32_t accumulate);
+int voxe_cpu_feature_correlation_fwd_bwd(const float* f, const float* r, int64_t nvox, int32_t F, float grad_scale,
+                                         float* loss_out, float* d_f, int32_t accumulate);
 int voxe_cpu_tv_fwd_bwd(const float* grid, int32_t X, int32_t Y, int32_t Z, int32_t C,
                         float grad_scale, float* loss_out, float* d_grid, int32_t accumulate);
 int voxe_cpu_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -228,6 +228,27 @@ def dcl_fwd_bwd(a, b, grad_scale: float = 1.0):
     return float(loss[0]), d_a
 
 
+def density_diff_fwd_bwd(a, b, kind: int, grad_scale: float = 1.0):
+    """l2_mode (kind = abi.DREG_L2) / l1_mode (abi.DREG_L1) of density_correlation_loss_fn: (loss, gradient w.r.t. a)"""
+    a, b = _f32(a), _f32(b)
+    loss = np.empty((1,), np.float32)
+    d_a = np.empty_like(a)
+    _check(lib().voxe_cpu_density_diff_fwd_bwd(a.ctypes.data, b.ctypes.data, a.size, int(kind), float(grad_scale),
+                                               loss.ctypes.data, d_a.ctypes.data, 0), "density_diff")
+    return float(loss[0]), d_a
+
+
+def feature_correlation_fwd_bwd(f, r, grad_scale: float = 1.0):
+    """_feature_correlation_loss: (loss, gradient w.r.t. f); f, r [..., F]"""
+    f, r = _f32(f), _f32(r)
+    loss = np.empty((1,), np.float32)
+    d_f = np.empty_like(f)
+    F = f.shape[-1]
+    _check(lib().voxe_cpu_feature_correlation_fwd_bwd(f.ctypes.data, r.ctypes.data, f.size // F, F, float(grad_scale),
+                                                      loss.ctypes.data, d_f.ctypes.data, 0), "feature_correlation")
+    return float(loss[0]), d_f
+
+
 def tv_fwd_bwd(grid, grad_scale: float = 1.0):
     grid = _f32(grid)
     X, Y, Z, Cn = grid.shape

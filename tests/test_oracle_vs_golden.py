@@ -171,6 +171,27 @@ def test_render_sh_degrees(deg, mode):
     assert rel_l2(gf, g[tag + "grad_features"]) < GRAD_REL_L2
 
 
+def test_regulariser_modes():
+    """l2_mode / l1_mode of density_correlation_loss_fn and _feature_correlation_loss (sds_trainer.py:494-505, 526-534) against
+    the reference's own functions (tests/golden/reg_modes.npz, tools/gen_golden.py g17): values <= 2e-6 relative, gradients
+    <= 1e-5 rel-L2, exact zeros of the l1 gradient at ties"""
+    from voxe_hip import abi
+
+    g = load_golden("reg_modes.npz")
+    for t in ("a", "b"):
+        sds, reg = g[f"dens_{t}_sds"], g[f"dens_{t}_reg"]
+        for mode, kind in (("l2", abi.DREG_L2), ("l1", abi.DREG_L1)):
+            loss, grad = vo.density_diff_fwd_bwd(sds, reg, kind)
+            assert abs(loss - float(g[f"dens_{t}_{mode}_loss"])) < 2e-6 * max(1.0, abs(loss))
+            assert rel_l2(grad, g[f"dens_{t}_{mode}_grad"]) < 1e-5
+            assert np.array_equal(grad == 0, g[f"dens_{t}_{mode}_grad"] == 0)
+        assert float(g[f"dens_{t}_both_loss"]) == float(g[f"dens_{t}_l2_loss"])     # (l2 wins when both flags are set)
+    for t in ("a", "b", "sh1", "attn"):
+        loss, grad = vo.feature_correlation_fwd_bwd(g[f"feat_{t}_sds"], g[f"feat_{t}_reg"])
+        assert abs(loss - float(g[f"feat_{t}_loss"])) < 2e-6 * max(1.0, abs(loss))
+        assert rel_l2(grad, g[f"feat_{t}_grad"]) < 1e-5
+
+
 def test_grid_ops():
     g = load_golden("grid_ops.npz")
     for t in ("a", "b"):

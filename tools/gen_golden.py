@@ -634,8 +634,60 @@ def g16_sds_boundary():
     save("sds_boundary.npz", **out)
 
 
+def _reference_functions(path, names):
+    """compile the named top-level functions of a reference module from ITS OWN source text (read here, in the build container,
+    never stored) into a namespace holding the torch names the module imports for them -- for modules whose import chain
+    needs packages this image lacks (diffusers, wandb, lpips, tensorboard ...) but whose functions are pure torch"""
+    import ast
+
+    from torch import Tensor
+    from torch.nn.functional import l1_loss, mse_loss
+
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {n.name for n in body} == set(names), [n.name for n in body]
+    ns = {"torch": torch, "Tensor": Tensor, "mse_loss": mse_loss, "l1_loss": l1_loss, "np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def g17_regulariser_modes():
+    """density_correlation_loss_fn with l2_mode / l1_mode (modules/sds_trainer.py:494-505) and _feature_correlation_loss
+    (:526-534): the reference's own functions (compiled from its source file, see _reference_functions), values and autograd
+    gradients.  Includes exact ties (sds == regular at some voxels: sign(0) = 0 in l1_loss's gradient)."""
+    dcl_fn, _, fcl_fn = _reference_functions(os.path.join(REF, "thre3d_atom", "modules", "sds_trainer.py"),
+                                             ["density_correlation_loss_fn", "_density_correlation_loss", "_feature_correlation_loss"])
+    out = {}
+    g = torch.Generator().manual_seed(17)
+    for tag, shape in {"a": (8, 8, 8, 1), "b": (6, 7, 5, 1)}.items():
+        reg = torch.empty(shape).uniform_(-1, 1, generator=g)
+        sds = reg + 0.3 * torch.randn(shape, generator=g)
+        sds.view(-1)[::7] = reg.view(-1)[::7]            # ties
+        sds.requires_grad_(True)
+        out[f"dens_{tag}_sds"], out[f"dens_{tag}_reg"] = np_(sds), np_(reg)
+        for mode in ("l2", "l1"):
+            loss, aux = dcl_fn(sds_density=sds, regular_density=reg, l2_mode=mode == "l2", l1_mode=mode == "l1")
+            assert aux is None
+            (gr,) = torch.autograd.grad(loss, sds)
+            out[f"dens_{tag}_{mode}_loss"], out[f"dens_{tag}_{mode}_grad"] = np_(loss), np_(gr)
+        loss, _ = dcl_fn(sds_density=sds, regular_density=reg, l2_mode=True, l1_mode=True)   # (both flags: l2 wins, :498-500)
+        out[f"dens_{tag}_both_loss"] = np_(loss)
+    for tag, shape in {"a": (8, 8, 8, 3), "b": (5, 6, 7, 3), "sh1": (4, 5, 3, 12), "attn": (6, 5, 4, 1)}.items():
+        reg = torch.empty(shape).uniform_(-2, 2, generator=g)
+        sds = (reg + 0.5 * torch.randn(shape, generator=g)).requires_grad_(True)
+        loss = fcl_fn(sds_features=sds, regular_features=reg, density_cov_grid=None)
+        (gr,) = torch.autograd.grad(loss, sds)
+        out[f"feat_{tag}_sds"], out[f"feat_{tag}_reg"] = np_(sds), np_(reg)
+        out[f"feat_{tag}_loss"], out[f"feat_{tag}_grad"] = np_(loss), np_(gr)
+    save("reg_modes.npz", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1:      # python tools/gen_golden.py g17_regulariser_modes  -> only that fixture
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     torch.set_num_threads(8)
     g1_cast_rays()
     g2_g3_sampling()
@@ -651,3 +703,4 @@ if __name__ == "__main__":
     g14_edit_trajectory()
     g15_attention_maps()
     g16_sds_boundary()
+    g17_regulariser_modes()

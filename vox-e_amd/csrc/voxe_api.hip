@@ -175,6 +175,19 @@ WsLayout ws_layout(const VoxeGridDesc* g, const VoxeRenderCfg* c, int64_t R) {
 
 int finish() { return hipGetLastError() == hipSuccess ? VOXE_OK : VOXE_ERR_LAUNCH; }
 
+// VoxeDispatch::precise_grad: the double segment sums exist only when the forward of these rays is
+// render_fwd_tile4_kernel<3, true> -- launch_fwd_t's condition, restated ONCE here for the forward, the re-march and the backward:
+// a depth-segmented march (nseg > 1), one segment per task, the lean forward's own conditions.  Everywhere else (S <= one segment,
+// fwd_segments_per_thread > 1, caller jitter, AABB clip, ...) the backward runs its default suffix arithmetic.
+bool precise_sums_apply(const WsLayout& l, const DevGrid& dg, const HostCfg& dc, const VoxeRenderCfg* cfg, const float* jitter) {
+  if (!(l.total > l.prec_off) || cfg->sh_degree != 0 || dc.attn) return false;
+  if (num_segments(cfg->num_samples, dc.seg_len) <= 1 || dc.disp.fwd_segments_per_thread > 1) return false;
+  FwdArgs probe{};
+  probe.jitter = jitter;
+  probe.segbuf = reinterpret_cast<float*>(1);   // (the segment partials live in the same workspace tier as the sums)
+  return fwd_tile4_supported(dg, dc, probe, 3, 1);
+}
+
 // ---- what the last forward left in a workspace --------------------------------------------------------------------
 // VoxeRenderCfg::ray_state_valid = 1 is a CLAIM by the caller ("this workspace still holds what voxe_render_fwd wrote for exactly
 // these rays / cfg / jitter").  The library checks the claim instead of trusting it: every forward leaves a host-side record of
@@ -188,7 +201,7 @@ struct FwdStamp {
   int64_t R, pair_rays;
   uint64_t seed, rng_offset, pair_offset, wsbytes;
   int32_t X, Y, Z, F, feature_kind, pre_act, post_act, S, perturb, lindisp, clip, white, deg, diffuse, width, height, det, kept;
-  float near_, far_, density_scale;
+  float near_, far_, density_scale, lo[3], hi[3];
   // the dispatch fields (VoxeDispatch, field by field: the struct's padding is the caller's)
   int64_t d_tile_min_rays, d_region_min_rays;
   int32_t d_bwd_mode, d_tile_map, d_two_phase, d_qsplit, d_kl, d_fwd_window, d_fwd_spt, d_lean, d_precise, d_lds_ranks;
@@ -207,6 +220,7 @@ FwdStamp make_stamp(const VoxeGridDesc* g, const VoxeRenderCfg* c, const float* 
   k.clip = c->aabb_clip; k.white = c->white_bkgd; k.deg = c->sh_degree; k.diffuse = c->render_diffuse; k.width = c->image_width;
   k.height = c->image_height; k.det = c->deterministic;
   k.near_ = c->near; k.far_ = c->far; k.density_scale = g->density_scale;
+  for (int a = 0; a < 3; ++a) { k.lo[a] = g->aabb_lo[a]; k.hi[a] = g->aabb_hi[a]; }
   const VoxeDispatch& d = disp_of(c);
   k.d_tile_min_rays = d.tile_min_rays; k.d_region_min_rays = d.region_min_rays; k.d_bwd_mode = d.bwd_mode; k.d_tile_map = d.tile_map;
   k.d_two_phase = d.tile_two_phase; k.d_qsplit = d.tile_qsplit; k.d_kl = d.tile_kl; k.d_fwd_window = d.fwd_window;
@@ -226,6 +240,13 @@ void record_stamp(const void* workspace, const FwdStamp& k) {
 void forget_stamp(const void* workspace) {
   std::lock_guard<std::mutex> lock(g_stamp_mu);
   g_stamps.erase(workspace);
+}
+// the tensor at `param` is about to be rewritten in place: no workspace's record of a forward over it describes the grid any more
+void forget_stamps_of(const void* param) {
+  if (!param) return;
+  std::lock_guard<std::mutex> lock(g_stamp_mu);
+  for (auto it = g_stamps.begin(); it != g_stamps.end();)
+    it = (it->second.densities == param || it->second.features == param) ? g_stamps.erase(it) : std::next(it);
 }
 // does `workspace` hold the forward of exactly this render, per-sample values included?
 bool stamp_matches(const void* workspace, FwdStamp k) {
@@ -387,7 +408,7 @@ int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const fl
   float* segbuf = workspace_bytes >= l.total ? (float*)((char*)workspace + l.seg_off) : nullptr;
   FwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, disparity, state, segbuf};
   a.keep_samples = cfg->ray_state_valid >= 0;
-  if (segbuf && l.total > l.prec_off && cfg->ray_state_valid >= 0) a.segsum_d = (double*)((char*)workspace + l.prec_off);
+  if (segbuf && cfg->ray_state_valid >= 0 && precise_sums_apply(l, dg, dc, cfg, jitter)) a.segsum_d = (double*)((char*)workspace + l.prec_off);
   if (cfg->ray_state_valid >= 0 && tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp))
     a.sample_fwd = (float*)((char*)workspace + l.fwdval_off);   // (what render_bwd_common's two-phase backward will read)
   if (l.region && workspace_bytes >= l.total_with_src) {
@@ -429,7 +450,8 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
     const bool packed_bwd = !tiled && packed_scatter_supported(cfg->sh_degree) && !force_scatter_bwd(dc.disp);
     BwdArgs a{packed, rays_o, rays_d, jitter, colour, depth, acc, d_colour, d_depth, d_acc, gpacked,
               want_d, want_f, (tiled || packed_bwd) ? state : nullptr};
-    if (l.total > l.prec_off) a.segsum_d = (const double*)((char*)workspace + l.prec_off);
+    const bool precise = precise_sums_apply(l, dg, dc, cfg, jitter);
+    if (precise) a.segsum_d = (const double*)((char*)workspace + l.prec_off);
     const bool two_phase = tiled && l.fwdval_off > l.src_off && workspace_bytes >= l.total_with_src && !two_phase_disabled(dc.disp);
     if (two_phase) {
       a.sample_src = (float*)((char*)workspace + l.src_off);
@@ -467,7 +489,7 @@ int render_bwd_common(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const 
       FwdArgs f{packed, rays_o, rays_d, jitter, nullptr, nullptr, nullptr, nullptr, state,
                 (float*)((char*)workspace + l.seg_off)};
       if (two_phase) f.sample_fwd = (float*)((char*)workspace + l.fwdval_off);
-      if (l.total > l.prec_off) f.segsum_d = (double*)((char*)workspace + l.prec_off);
+      if (precise) f.segsum_d = (double*)((char*)workspace + l.prec_off);
       launch_fwd(dg, dc, cfg->sh_degree, cfg->render_diffuse, f, s);
     }
     PhaseTimer t(PH_BWD, s);
@@ -831,19 +853,53 @@ int voxe_grid_adam_step(const VoxeGridDesc* grid, int32_t grad_layout, int32_t x
   const WsLayout l = ws_layout(grid, nullptr, 0);
   if (!workspace || workspace_bytes < l.state_off) return VOXE_ERR_WORKSPACE;
   DclTerm dcl;
-  if (reg && reg->dcl_reference) {
+  const long long nvox_all = (long long)grid->X * grid->Y * grid->Z;
+  if (reg && reg->dcl_reference && reg->density_kind == VOXE_DREG_CORRELATION) {
     // moments over the WHOLE grid of the current parameters; the gradient is evaluated inside the step
-    const long long n = (long long)grid->X * grid->Y * grid->Z;
+    const long long n = nvox_all;
     if (x_begin != 0 || x_end != grid->X || !exp_avg_d) return VOXE_ERR_UNSUPPORTED;
     if (!reg->scratch || reg->scratch_bytes < dcl_scratch_bytes(n)) return VOXE_ERR_WORKSPACE;
     dcl.b = reg->dcl_reference;
     dcl.stats = launch_dcl_moments(grid->densities, reg->dcl_reference, n, reg->dcl_weight, reg->dcl_loss, reg->scratch,
                                    (hipStream_t)stream);
+  } else if (reg && reg->dcl_reference) {
+    // l2_mode / l1_mode (sds_trainer.py:494-503): per-voxel terms, no statistics; a reduction only for the logged value
+    if (reg->density_kind != VOXE_DREG_L2 && reg->density_kind != VOXE_DREG_L1) return VOXE_ERR_UNSUPPORTED;
+    if (!exp_avg_d) return VOXE_ERR_UNSUPPORTED;
+    const long long plane = (long long)grid->Y * grid->Z;
+    if (reg->dcl_loss) {
+      if (!reg->scratch || reg->scratch_bytes < dcl_scratch_bytes(nvox_all)) return VOXE_ERR_WORKSPACE;
+      if (x_begin == x_end && hipMemsetAsync(reg->dcl_loss, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return VOXE_ERR_LAUNCH;
+      if (x_begin < x_end)
+        launch_density_diff(grid->densities + x_begin * plane, reg->dcl_reference + x_begin * plane, (x_end - x_begin) * plane,
+                            reg->density_kind, 0.0f, reg->dcl_loss, (float)(1.0 / (double)nvox_all), nullptr, 0, reg->scratch,
+                            (hipStream_t)stream);
+    }
+    dcl.b = reg->dcl_reference;
+    dcl.kind = reg->density_kind;
+    dcl.k = (float)((reg->density_kind == VOXE_DREG_L2 ? 2.0 : 1.0) * (double)reg->dcl_weight / (double)nvox_all);
+  }
+  if (reg && reg->feat_reference) {
+    // _feature_correlation_loss (sds_trainer.py:526-534): per voxel inside the step (texels of up to 4 channels)
+    if (grid->F > 3 || !exp_avg_f) return VOXE_ERR_UNSUPPORTED;
+    const long long plane = (long long)grid->Y * grid->Z;
+    if (reg->feat_loss) {
+      if (!reg->scratch || reg->scratch_bytes < dcl_scratch_bytes(nvox_all)) return VOXE_ERR_WORKSPACE;
+      if (x_begin == x_end && hipMemsetAsync(reg->feat_loss, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return VOXE_ERR_LAUNCH;
+      if (x_begin < x_end)
+        launch_feature_correlation(grid->features + x_begin * plane * grid->F, reg->feat_reference + x_begin * plane * grid->F,
+                                   (x_end - x_begin) * plane, grid->F, 0.0f, reg->feat_loss, nullptr, 0, reg->scratch,
+                                   (hipStream_t)stream);
+    }
+    dcl.fref = reg->feat_reference;
+    dcl.fk = 2.0f * reg->feat_weight;
   }
   if (x_begin == x_end) return VOXE_OK;
   // the parameters move: the per-ray states a forward left in this workspace no longer describe the grid -- a backward that still
   // claims ray_state_valid = 1 afterwards is served by a re-march
   forget_stamp(workspace);
+  forget_stamps_of(grid->densities);   // (sibling workspaces / a grad_workspace's owner rendered the same tensors)
+  forget_stamps_of(grid->features);
   if (!launch_grid_adam(grid, grad_layout == VOXE_GRAD_BRICKED, x_begin, x_end, (float*)((char*)workspace + l.grad_off),
                         extra_d_densities, extra_d_features, exp_avg_d, exp_avg_sq_d, exp_avg_f, exp_avg_sq_f, lr, beta1,
                         beta2, eps, step, step_features > 0 ? step_features : step,
@@ -953,6 +1009,27 @@ int voxe_dcl_fwd_bwd(const float* a, const float* b, int64_t n, float grad_scale
   return finish();
 }
 
+int voxe_density_diff_fwd_bwd(const float* a, const float* b, int64_t n, int32_t kind, float grad_scale, float* loss_out,
+                              float* d_a, int32_t accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!a || !b) return VOXE_ERR_NULL_POINTER;
+  if (n <= 0) return VOXE_ERR_BAD_SHAPE;
+  if (kind != VOXE_DREG_L2 && kind != VOXE_DREG_L1) return VOXE_ERR_UNSUPPORTED;
+  if (loss_out && (!scratch || scratch_bytes < dcl_scratch_bytes(n))) return VOXE_ERR_WORKSPACE;
+  if (!loss_out && !d_a) return VOXE_OK;
+  launch_density_diff(a, b, n, kind, grad_scale, loss_out, (float)(1.0 / (double)n), d_a, accumulate, scratch, (hipStream_t)stream);
+  return finish();
+}
+
+int voxe_feature_correlation_fwd_bwd(const float* f, const float* r, int64_t nvox, int32_t F, float grad_scale, float* loss_out,
+                                     float* d_f, int32_t accumulate, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!f || !r) return VOXE_ERR_NULL_POINTER;
+  if (nvox <= 0 || F < 1 || F > 64) return VOXE_ERR_BAD_SHAPE;
+  if (loss_out && (!scratch || scratch_bytes < dcl_scratch_bytes(nvox))) return VOXE_ERR_WORKSPACE;
+  if (!loss_out && !d_f) return VOXE_OK;
+  launch_feature_correlation(f, r, nvox, F, grad_scale, loss_out, d_f, accumulate, scratch, (hipStream_t)stream);
+  return finish();
+}
+
 size_t voxe_tv_scratch_bytes(int32_t X, int32_t Y, int32_t Z, int32_t C) {
   return tv_scratch_bytes(X, Y, Z, C);
 }
@@ -972,6 +1049,7 @@ int voxe_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq) return VOXE_ERR_NULL_POINTER;
   if (n < 0 || step < 1) return VOXE_ERR_BAD_SHAPE;
+  forget_stamps_of(param);   // (a later ray_state_valid = 1 over this tensor re-marches)
   launch_adam(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
   return finish();
 }

@@ -203,6 +203,79 @@ void launch_dcl(const float* a, const float* b, long long n, float grad_scale, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// density_correlation_loss_fn, l2_mode / l1_mode -- modules/sds_trainer.py:494-503 (+ autograd): torch mse_loss / l1_loss of
+// the two density grids (mean reduction).  The gradient needs no reduction: (a - b) * (2 w / n)  /  sign(a - b) * (w / n).
+// _feature_correlation_loss -- modules/sds_trainer.py:526-534 (+ autograd): per voxel D = sum_c (sigmoid(f_c) - sigmoid(r_c)),
+// loss = sum_v D^2, d f_c = 2 w D sigmoid(f_c) (1 - sigmoid(f_c)).  Values: per-block double partials, fixed-order final sum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }   // (torch.sigmoid; not the render's fast path)
+
+__global__ __launch_bounds__(256) void density_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                           int kind, float k, double* __restrict__ partial,
+                                                           float* __restrict__ d_a, int accumulate) {
+  double s[1] = {0.0};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = a[i] - b[i];
+    if (partial) s[0] += kind == VOXE_DREG_L2 ? (double)d * (double)d : (double)fabsf(d);
+    if (d_a) {
+      const float gv = kind == VOXE_DREG_L2 ? d * k : (d > 0.0f ? k : (d < 0.0f ? -k : 0.0f));
+      d_a[i] = accumulate ? d_a[i] + gv : gv;
+    }
+  }
+  if (partial) block_sum<1>(s, partial + blockIdx.x);
+}
+
+// loss = (sum of the partials) * norm
+__global__ __launch_bounds__(256) void sum_finalize_kernel(const double* __restrict__ partial, int nblocks, double norm,
+                                                           float* __restrict__ loss_out) {
+  double s[1] = {0.0};
+  for (int i = threadIdx.x; i < nblocks; i += blockDim.x) s[0] += partial[i];
+  __shared__ double tot[1];
+  block_sum<1>(s, tot);
+  __syncthreads();
+  if (threadIdx.x == 0) *loss_out = (float)(tot[0] * norm);
+}
+
+// loss_norm: 1 / (elements of the mean) -- the whole grid's count even when [a, a + n) is a slab of it
+void launch_density_diff(const float* a, const float* b, long long n, int kind, float grad_scale, float* loss_out, float loss_norm,
+                         float* d_a, int accumulate, void* scratch, hipStream_t st) {
+  double* partial = loss_out ? (double*)scratch : nullptr;
+  const int nb = (int)((n + 255) / 256 < kRedBlocks ? (n + 255) / 256 : kRedBlocks);
+  const float k = (float)((kind == VOXE_DREG_L2 ? 2.0 : 1.0) * (double)grad_scale * (double)loss_norm);
+  density_diff_kernel<<<nb, 256, 0, st>>>(a, b, n, kind, k, partial, d_a, accumulate);
+  if (loss_out) sum_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, (double)loss_norm, loss_out);
+}
+
+__global__ __launch_bounds__(256) void feature_correlation_kernel(const float* __restrict__ f, const float* __restrict__ r,
+                                                                  long long nvox, int F, float k2, double* __restrict__ partial,
+                                                                  float* __restrict__ d_f, int accumulate) {
+  double s[1] = {0.0};
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += stride) {
+    float D = 0.0f;
+    for (int c = 0; c < F; ++c) D += sigmoid_ref(f[v * F + c]) - sigmoid_ref(r[v * F + c]);
+    if (partial) s[0] += (double)D * (double)D;
+    if (d_f) {
+      for (int c = 0; c < F; ++c) {
+        const float sc = sigmoid_ref(f[v * F + c]);
+        const float gv = (k2 * D) * ((1.0f - sc) * sc);
+        d_f[v * F + c] = accumulate ? d_f[v * F + c] + gv : gv;
+      }
+    }
+  }
+  if (partial) block_sum<1>(s, partial + blockIdx.x);
+}
+
+void launch_feature_correlation(const float* f, const float* r, long long nvox, int F, float grad_scale, float* loss_out, float* d_f,
+                                int accumulate, void* scratch, hipStream_t st) {
+  double* partial = loss_out ? (double*)scratch : nullptr;
+  const int nb = (int)((nvox + 255) / 256 < kRedBlocks ? (nvox + 255) / 256 : kRedBlocks);
+  feature_correlation_kernel<<<nb, 256, 0, st>>>(f, r, nvox, F, 2.0f * grad_scale, partial, d_f, accumulate);
+  if (loss_out) sum_finalize_kernel<<<1, 256, 0, st>>>(partial, nb, 1.0, loss_out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // _tv_loss_on_grid -- modules/sds_trainer.py:563-567 (+ autograd), gather form (no atomics):
 // every element reads its 6 axis neighbours once.
 // ------------------------------------------------------------------------------------------------

@@ -62,9 +62,16 @@ void launch_unpack_any(const VoxeGridDesc* gd, const float* gpacked, float* d_de
 // fused un-pack + Adam + re-pack (false: channel count without a kernel)
 // density-correlation term evaluated inside the grid step: reference densities b, the finalized moment statistics of
 // launch_dcl_moments (mean a, mean b, k1, k2 with the weight folded in), see dcl_grad_kernel
+// r06: the other regulariser kinds of the edit (sds_trainer.py:494-505: l2_mode / l1_mode; :526-534: feature correlation) are
+// per-voxel terms of the same pass: `kind` (VOXE_DREG_*) says what `b` is compared with and how, `fref` / `fk` carry the
+// feature term (reference features [N, F], 2 x weight)
 struct DclTerm {
   const float* b = nullptr;
   const double* stats = nullptr;
+  int kind = 0;
+  float k = 0.0f;          // VOXE_DREG_L2: 2 weight / n;  VOXE_DREG_L1: weight / n
+  const float* fref = nullptr;
+  float fk = 0.0f;
 };
 bool launch_grid_adam(const VoxeGridDesc* gd, bool bricked, int x_begin, int x_end, float* gpacked, const float* extra_d, const float* extra_f,
                       float* m_d, float* v_d, float* m_f, float* v_f, float lr, float beta1, float beta2, float eps,
@@ -132,6 +139,11 @@ void launch_cast_rays_indexed(int H, int W, float focal, const float* poses, int
 void launch_random_subset(long long n, long long count, unsigned long long seed, unsigned long long rng_offset,
                           long long* out, hipStream_t st);
 size_t dcl_scratch_bytes(long long n);
+// l2 / l1 density regulariser and the feature-correlation regulariser on their own (value + gradient; see voxe.h)
+void launch_density_diff(const float* a, const float* b, long long n, int kind, float grad_scale, float* loss_out, float loss_norm,
+                         float* d_a, int accumulate, void* scratch, hipStream_t st);
+void launch_feature_correlation(const float* f, const float* r, long long nvox, int F, float grad_scale, float* loss_out, float* d_f,
+                                int accumulate, void* scratch, hipStream_t st);
 void launch_dcl(const float* a, const float* b, long long n, float grad_scale, float* loss_out,
                 float* d_a, int accumulate, void* scratch, hipStream_t st);
 size_t tv_scratch_bytes(int X, int Y, int Z, int C);

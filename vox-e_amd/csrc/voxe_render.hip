@@ -224,8 +224,24 @@ __device__ __forceinline__ float adam_update(float p, float gi, float& m, float&
   return p - h.step_size * (mi / denom);
 }
 
+// feature-correlation gradient of one voxel (feature_correlation_kernel's expressions, voxe_grid_ops.hip; sds_trainer.py:526-534):
+// p / r = the voxel's features / reference features, fk = 2 x weight
+template <int F>
+__device__ __forceinline__ void featcorr_term(const float (&p)[F], const float (&r)[F], float fk, float (&out)[F]) {
+  float sg[F], D = 0.0f;
+#pragma unroll
+  for (int f = 0; f < F; ++f) { sg[f] = 1.0f / (1.0f + expf(-p[f])); D += sg[f] - 1.0f / (1.0f + expf(-r[f])); }
+#pragma unroll
+  for (int f = 0; f < F; ++f) out[f] = (fk * D) * ((1.0f - sg[f]) * sg[f]);
+}
+
 // density-correlation gradient of one voxel (dcl_grad_kernel's expression; stats = mean a, mean b, k1, k2 with the weight folded in)
+// r06: VOXE_DREG_L2 / L1 (sds_trainer.py:494-503): (a - b) (2 w / n)  /  sign(a - b) (w / n), no statistics
 __device__ __forceinline__ float dcl_term(const DclTerm& t, float a, long long i) {
+  if (t.kind != VOXE_DREG_CORRELATION) {
+    const float d = a - t.b[i];
+    return t.kind == VOXE_DREG_L2 ? d * t.k : (d > 0.0f ? t.k : (d < 0.0f ? -t.k : 0.0f));
+  }
   const float ma = (float)t.stats[0], mb = (float)t.stats[1], k1 = (float)t.stats[2], k2 = (float)t.stats[3];
   const float A = a - ma, B = t.b[i] - mb;
   return A * k2 - B * k1;
@@ -262,12 +278,22 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
       for (int f = 0; f < C; ++f) { g[f] = gpacked[si * C + f]; gpacked[si * C + f] = 0.0f; }
     }
     float out[C];
+    float fg[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) fg[f] = 0.0f;
+    if (dcl.fref && m_f) {   // (the term is evaluated on the parameters the step starts from, like every gradient)
+      float pf[F], rf[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) { pf[f] = feat[i * F + f]; rf[f] = dcl.fref[i * F + f]; }
+      featcorr_term<F>(pf, rf, dcl.fk, fg);
+    }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       const long long j = i * F + f;
       float p = feat[j];
       if (m_f) {
-        const float gi = extra_f ? g[f] + extra_f[j] : g[f];
+        float gi = extra_f ? g[f] + extra_f[j] : g[f];
+        if (dcl.fref) gi += fg[f];
         float m = m_f[j], v = v_f[j];
         p = adam_update(p, gi, m, v, h_f);
         feat[j] = p; m_f[j] = m; v_f[j] = v;
@@ -357,6 +383,22 @@ __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ 
         if (m_f) { m[k * 3 + f] = b1[i]; v[k * 3 + f] = b2[i]; }
       }
     wave_lds_order();
+    float fg[12];
+    if (m_f && dcl.fref) {   // feature-correlation term (r06; weight 0 by default): the reference features through buffer 0
+      const float4* __restrict__ fr4 = reinterpret_cast<const float4*>(dcl.fref);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) buf[0][k * 64 + lane] = fr4[f4 + k * 64 + lane];
+      wave_lds_order();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float pk[3] = {p[k * 3], p[k * 3 + 1], p[k * 3 + 2]};
+        const float rk[3] = {b0[(k * 64 + lane) * 3], b0[(k * 64 + lane) * 3 + 1], b0[(k * 64 + lane) * 3 + 2]};
+        float o[3];
+        featcorr_term<3>(pk, rk, dcl.fk, o);
+        fg[k * 3] = o[0]; fg[k * 3 + 1] = o[1]; fg[k * 3 + 2] = o[2];
+      }
+      wave_lds_order();
+    }
     if (m_f) {
       if (extra_f) {   // regulariser gradient of the features (rare path): through buffer 0
 #pragma unroll
@@ -368,7 +410,8 @@ __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ 
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
           const float gj = f == 0 ? g[k].x : (f == 1 ? g[k].y : g[k].z);
-          const float gi = extra_f ? gj + b0[(k * 64 + lane) * 3 + f] : gj;
+          float gi = extra_f ? gj + b0[(k * 64 + lane) * 3 + f] : gj;
+          if (dcl.fref) gi += fg[k * 3 + f];
           p[k * 3 + f] = adam_update(p[k * 3 + f], gi, m[k * 3 + f], v[k * 3 + f], h_f);
         }
       wave_lds_order();
@@ -565,7 +608,7 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const long long vb = x_begin * plane, ve = x_end * plane;
     if (!bricked && vb % 4 == 0 && al16(gpacked) && al16(gd->densities) && al16(gd->features) && al16(extra_d) &&
-        al16(extra_f) && al16(m_d) && al16(v_d) && al16(m_f) && al16(v_f) && al16(packed_out)) {
+        al16(extra_f) && al16(m_d) && al16(v_d) && al16(m_f) && al16(v_f) && al16(packed_out) && al16(dcl.fref)) {
       if ((ve - vb) >= 256) {
         const long long nchunks = (ve - vb) / 256, tail = vb + nchunks * 256;
         const int nb5 = (int)((nchunks + 3) / 4 < VOXE_GA_BLOCKS ? (nchunks + 3) / 4 : VOXE_GA_BLOCKS);

@@ -89,18 +89,21 @@ class FusedGridAdam(torch.optim.Optimizer):
         self._train = (train_d, train_f)
         # dropped without detach() (an exception unwound the training loop, the caller forgot): leave the mode anyway
         self._finalizer = weakref.finalize(self, FusedGridAdam._release, self.workspace, mine)
-        self._dcl = None          # (reference densities, weight): density-correlation regulariser evaluated inside step()
+        self._dcl = None          # (reference densities, weight, kind): density regulariser evaluated inside step()
         self.dcl_loss = None      # device scalar: its unweighted value at the last step()
+        self._featcorr = None     # (reference features, weight): feature-correlation regulariser evaluated inside step()
+        self.featcorr_loss = None
 
     @property
     def trains_densities(self) -> bool:
         """the density tensor of the attached grid receives gradients (set_density_correlation needs it)"""
         return bool(self._train[0])
 
-    def set_density_correlation(self, regular_density, weight: float) -> None:
-        """evaluate the SDS edit's density-correlation regulariser (modules/sds_trainer.py:507-524: 1 - corr(densities,
-        `regular_density`), times `weight`) INSIDE step(): no autograd node, no [X,Y,Z,1] gradient tensor, no separate gradient
-        kernel; `self.dcl_loss` holds its value (unweighted) after every step().  `regular_density` None switches it off."""
+    def set_density_correlation(self, regular_density, weight: float, l2_mode: bool = False, l1_mode: bool = False) -> None:
+        """evaluate the SDS edit's density regulariser (modules/sds_trainer.py:494-524: 1 - corr(densities, `regular_density`)
+        by default, their mse_loss / l1_loss with `l2_mode` / `l1_mode`; times `weight`) INSIDE step(): no autograd node, no
+        [X,Y,Z,1] gradient tensor, no separate gradient kernel; `self.dcl_loss` holds its value (unweighted) after every step().
+        `regular_density` None switches it off."""
         if regular_density is None:
             self._dcl, self.dcl_loss = None, None
             return
@@ -109,8 +112,28 @@ class FusedGridAdam(torch.optim.Optimizer):
         ref = regular_density.detach().to(self._dens.device, torch.float32).contiguous()
         if ref.numel() != self._dens.numel():
             raise ValueError("regular_density must have the shape of the grid's densities")
-        self._dcl = (ref, float(weight))
+        kind = _ops.abi.DREG_L2 if l2_mode else (_ops.abi.DREG_L1 if l1_mode else _ops.abi.DREG_CORRELATION)   # (l2 wins: :498-503)
+        self._dcl = (ref, float(weight), kind)
         self.dcl_loss = torch.zeros((), dtype=torch.float32, device=self._dens.device)
+
+    @property
+    def trains_features(self) -> bool:
+        return bool(self._train[1])
+
+    def set_feature_correlation(self, regular_features, weight: float) -> None:
+        """evaluate _feature_correlation_loss (modules/sds_trainer.py:526-534) against `regular_features`, times `weight`, INSIDE
+        step() (SH-0 grids: 4-channel texels); `self.featcorr_loss` holds its value (unweighted) after every step().  None
+        switches it off."""
+        if regular_features is None:
+            self._featcorr, self.featcorr_loss = None, None
+            return
+        if self.kind != "sh" or not self._train[1] or self._feat.shape[-1] > 3:
+            raise RuntimeError("set_feature_correlation needs trainable features of an SH degree-0 grid")
+        ref = regular_features.detach().to(self._feat.device, torch.float32).contiguous()
+        if ref.numel() != self._feat.numel():
+            raise ValueError("regular_features must have the shape of the grid's features")
+        self._featcorr = (ref, float(weight))
+        self.featcorr_loss = torch.zeros((), dtype=torch.float32, device=self._feat.device)
 
     @staticmethod
     def _release(workspace, mine) -> None:
@@ -247,9 +270,17 @@ class FusedGridAdam(torch.optim.Optimizer):
             # no render gradient in the workspace this iteration (e.g. a regulariser-only step): per-tensor Adam
             if self._dcl is not None:     # (the in-step regulariser lives in the fused pass: here it goes through autograd)
                 with torch.enable_grad():
-                    dcl = _ops.density_correlation_loss(self._dens, self._dcl[0])
+                    if self._dcl[2] == _ops.abi.DREG_CORRELATION:
+                        dcl = _ops.density_correlation_loss(self._dens, self._dcl[0])
+                    else:
+                        dcl = _ops.density_diff_loss(self._dens, self._dcl[0], self._dcl[2] == _ops.abi.DREG_L2)
                     (dcl * self._dcl[1]).backward()
                 self.dcl_loss.copy_(dcl.detach())
+            if self._featcorr is not None:
+                with torch.enable_grad():
+                    fcl = _ops.feature_correlation_loss(self._feat, self._featcorr[0])
+                    (fcl * self._featcorr[1]).backward()
+                self.featcorr_loss.copy_(fcl.detach())
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -273,7 +304,10 @@ class FusedGridAdam(torch.optim.Optimizer):
                              state_features=None if st_f is None else (st_f["exp_avg"], st_f["exp_avg_sq"]),
                              extra_d_densities=extra_d, extra_d_features=extra_f, beta1=beta1, beta2=beta2,
                              eps=group["eps"], dcl_reference=None if self._dcl is None else self._dcl[0],
-                             dcl_weight=0.0 if self._dcl is None else self._dcl[1], dcl_loss=self.dcl_loss)
+                             dcl_weight=0.0 if self._dcl is None else self._dcl[1], dcl_loss=self.dcl_loss,
+                             density_kind=0 if self._dcl is None else self._dcl[2],
+                             feat_reference=None if self._featcorr is None else self._featcorr[0],
+                             feat_weight=0.0 if self._featcorr is None else self._featcorr[1], feat_loss=self.featcorr_loss)
         for st in (st_d, st_f):
             if st is not None:
                 st["step"] += 1

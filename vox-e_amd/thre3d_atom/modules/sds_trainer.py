@@ -39,10 +39,10 @@ def _density_correlation_loss(sds_density: Tensor, regular_density: Tensor):
 
 
 def density_correlation_loss_fn(sds_density: Tensor, regular_density: Tensor, l2_mode: bool = False, l1_mode: bool = False):
-    if l2_mode:
-        return torch.nn.functional.mse_loss(sds_density, regular_density), None
-    if l1_mode:
-        return torch.nn.functional.l1_loss(sds_density, regular_density), None
+    """sds_trainer.py:494-505 of the reference: mse_loss / l1_loss of the two grids with l2_mode / l1_mode (l2 first), else the
+    correlation -- all three as HIP passes (value + gradient), differentiable w.r.t. `sds_density`"""
+    if l2_mode or l1_mode:
+        return _ops.density_diff_loss(sds_density, regular_density, l2_mode=bool(l2_mode)), None
     return _density_correlation_loss(sds_density, regular_density)
 
 
@@ -51,9 +51,9 @@ def _tv_loss_on_grid(grid: Tensor) -> Tensor:
 
 
 def _feature_correlation_loss(sds_features: Tensor, regular_features: Tensor, density_cov_grid=None) -> Tensor:
-    """sum over voxels of (sum_c sigmoid(f_sds) - sigmoid(f_ref))^2 (sds_trainer.py:526-534; weight 0 by default)"""
-    diff = torch.sigmoid(sds_features) - torch.sigmoid(regular_features.detach())
-    return (diff.sum(dim=-1) ** 2).sum()
+    """sum over voxels of (sum_c sigmoid(f_sds) - sigmoid(f_ref))^2 (sds_trainer.py:526-534; weight 0 by default): one HIP
+    pass for value + gradient"""
+    return _ops.feature_correlation_loss(sds_features, regular_features.detach())
 
 
 def _pitch_yaw_from_Rt(pose: Tensor):  # noqa: N802 (reference name)
@@ -185,10 +185,15 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
     # reference) is evaluated INSIDE the fused grid step: no autograd node, no gradient tensor, no extra pass over the grid
     # (only with trainable densities: a features-only edit keeps the autograd term, whose gradient simply goes nowhere; the fused
     #  step runs with world == 1, where the regularisers' 1 / world scale is 1 -- passed anyway, so the two paths cannot diverge)
-    dcl_in_step = (isinstance(optimizer, FusedGridAdam) and not uncoupled_mode and not l2_mode and not l1_mode
+    # r06: with l2_mode / l1_mode (sds_trainer.py:494-503) and for the feature-correlation term (:526-534) as well
+    dcl_in_step = (isinstance(optimizer, FusedGridAdam) and not uncoupled_mode
                    and density_correlation_weight != 0.0 and optimizer.trains_densities)
     if dcl_in_step:
-        optimizer.set_density_correlation(regular_density, density_correlation_weight * (1.0 / world))
+        optimizer.set_density_correlation(regular_density, density_correlation_weight * (1.0 / world), l2_mode=l2_mode, l1_mode=l1_mode)
+    featcorr_in_step = (isinstance(optimizer, FusedGridAdam) and feature_correlation_weight > 0.0 and optimizer.trains_features
+                        and grid.features.shape[-1] <= 3)
+    if featcorr_in_step:
+        optimizer.set_feature_correlation(regular_features, feature_correlation_weight * (1.0 / world))
     extra_info = {CAMERA_BOUNDS: camera_bounds, CAMERA_INTRINSICS: camera_intrinsics, HEMISPHERICAL_RADIUS: extra_radius}
 
     log.info(f"SDS editing: grid {grid.grid_dims}, image [{im_h} x {im_w}], {num_iterations} iterations")
@@ -234,7 +239,7 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
             elif not dcl_in_step:
                 dcl, _ = density_correlation_loss_fn(grid.densities, regular_density, l2_mode=l2_mode, l1_mode=l1_mode)
                 total_loss = total_loss + dcl * (density_correlation_weight * reg_scale)
-            if feature_correlation_weight > 0.0:
+            if feature_correlation_weight > 0.0 and not featcorr_in_step:
                 total_loss = total_loss + _feature_correlation_loss(grid.features, regular_features) * (feature_correlation_weight * reg_scale)
             if tv_density_weight > 0:
                 total_loss = total_loss + _tv_loss_on_grid(torch.relu(grid.densities)) * (tv_density_weight * reg_scale)
@@ -256,6 +261,8 @@ def train_sh_vox_grid_vol_mod_with_posed_images_and_sds(
                 shown = float(total_loss.detach()) if torch.is_tensor(total_loss) else float(total_loss)
                 if dcl_in_step:    # (its value comes out of the grid step)
                     shown += density_correlation_weight * float(optimizer.dcl_loss)
+                if featcorr_in_step:
+                    shown += feature_correlation_weight * float(optimizer.featcorr_loss)
                 log.info(f"Iteration: {global_step}, total_loss: {shown: .3f}")
             if global_step % lr_freq == 0 and global_step >= lr_decay_start:
                 lr_scheduler.step()

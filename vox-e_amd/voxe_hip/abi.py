@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # VoxeStatus
 OK = 0
@@ -23,6 +23,9 @@ ACT_IDENTITY = 0
 ACT_ABS = 1
 ACT_RELU = 2
 ACT_SOFTPLUS = 3
+
+# density regulariser kinds of the edit (VOXE_DREG_*)
+DREG_CORRELATION, DREG_L2, DREG_L1 = 0, 1, 2
 
 # VoxeFeatureKind
 FEAT_SH = 0
@@ -112,6 +115,7 @@ class VoxeGridRegularisers(C.Structure):
     _fields_ = [
         ("dcl_reference", C.c_void_p), ("dcl_weight", C.c_float), ("dcl_loss", C.c_void_p),
         ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
+        ("density_kind", C.c_int32), ("feat_reference", C.c_void_p), ("feat_weight", C.c_float), ("feat_loss", C.c_void_p),
     ]
 
 
@@ -150,6 +154,8 @@ _COMMON = {
     "render_bwd": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32], True, True),
     "sample_probe": (C.c_int, [_GD, _RC, _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P], True, True),
     "dcl_fwd_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P, C.c_int32], True, True),
+    "density_diff_fwd_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P, _P, C.c_int32], True, True),
+    "feature_correlation_fwd_bwd": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_float, _P, _P, C.c_int32], True, True),
     "tv_fwd_bwd": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P, _P, C.c_int32], True, True),
     "adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64], False, True),
     "upsample_trilinear": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32], False, True),

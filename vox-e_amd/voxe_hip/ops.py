@@ -486,6 +486,76 @@ def density_correlation_loss(sds_density: torch.Tensor, regular_density: torch.T
     return _DclFn.apply(sds_density, regular_density)
 
 
+class _DiffFn(torch.autograd.Function):
+    """density_correlation_loss_fn's l2_mode / l1_mode (sds_trainer.py:494-503): value + gradient in one launch sequence"""
+
+    @staticmethod
+    def forward(ctx, sds_density, regular_density, kind):
+        require_device(sds_density, "density_diff_loss")
+        a, b = f32c(sds_density.detach()), f32c(regular_density.detach())
+        if a.numel() != b.numel():
+            raise VoxeError("density_diff_loss: shape mismatch")
+        device = a.device
+        ensure_gfx950(device)
+        L = lib()
+        with torch.cuda.device(device):
+            sc = _scratch_for(device, L.voxe_dcl_scratch_bytes(a.numel()))
+            loss = torch.empty((), dtype=torch.float32, device=device)
+            d_a = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+            check(L.voxe_density_diff_fwd_bwd(ptr(a), ptr(b), a.numel(), int(kind), 1.0, ptr(loss), ptr(d_a), 0, ptr(sc),
+                                              sc.numel(), stream_ptr(device)), "voxe_density_diff_fwd_bwd")
+        ctx.save_for_backward(d_a)
+        ctx.shape = sds_density.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_a,) = ctx.saved_tensors
+        if d_a is None:
+            return None, None, None
+        return (d_a * g).reshape(ctx.shape), None, None
+
+
+def density_diff_loss(sds_density: torch.Tensor, regular_density: torch.Tensor, l2_mode: bool) -> torch.Tensor:
+    """mse_loss (l2_mode) / l1_loss of the two density grids (thre3d_atom/modules/sds_trainer.py:494-503); differentiable w.r.t. sds."""
+    return _DiffFn.apply(sds_density, regular_density, abi.DREG_L2 if l2_mode else abi.DREG_L1)
+
+
+class _FeatCorrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sds_features, regular_features):
+        require_device(sds_features, "feature_correlation_loss")
+        f, r = f32c(sds_features.detach()), f32c(regular_features.detach())
+        if f.shape != r.shape or f.dim() < 1:
+            raise VoxeError("feature_correlation_loss: shape mismatch")
+        device = f.device
+        ensure_gfx950(device)
+        L = lib()
+        F = int(f.shape[-1])
+        nvox = f.numel() // F
+        with torch.cuda.device(device):
+            sc = _scratch_for(device, L.voxe_dcl_scratch_bytes(nvox))
+            loss = torch.empty((), dtype=torch.float32, device=device)
+            d_f = torch.empty_like(f) if ctx.needs_input_grad[0] else None
+            check(L.voxe_feature_correlation_fwd_bwd(ptr(f), ptr(r), nvox, F, 1.0, ptr(loss), ptr(d_f), 0, ptr(sc), sc.numel(),
+                                                     stream_ptr(device)), "voxe_feature_correlation_fwd_bwd")
+        ctx.save_for_backward(d_f)
+        ctx.shape = sds_features.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d_f,) = ctx.saved_tensors
+        if d_f is None:
+            return None, None
+        return (d_f * g).reshape(ctx.shape), None
+
+
+def feature_correlation_loss(sds_features: torch.Tensor, regular_features: torch.Tensor) -> torch.Tensor:
+    """sum_v (sum_c sigmoid(f_vc) - sigmoid(r_vc))^2 (thre3d_atom/modules/sds_trainer.py:526-534); differentiable w.r.t. sds."""
+    return _FeatCorrFn.apply(sds_features, regular_features)
+
+
 class _TvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, grid):
@@ -599,7 +669,9 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
                     beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
                     x_range: Optional[Tuple[int, int]] = None, step_features: Optional[int] = None,
                     dcl_reference: Optional[torch.Tensor] = None, dcl_weight: float = 0.0,
-                    dcl_loss: Optional[torch.Tensor] = None) -> None:
+                    dcl_loss: Optional[torch.Tensor] = None, density_kind: int = 0,
+                    feat_reference: Optional[torch.Tensor] = None, feat_weight: float = 0.0,
+                    feat_loss: Optional[torch.Tensor] = None) -> None:
     """voxe_grid_adam_step: consume the workspace gradient (+ optional extra gradients in tensor layout), update
     densities / features in place with torch.optim.Adam arithmetic, leave the NEW grid packed and a zeroed gradient
     region in the workspace.  state_* = (exp_avg, exp_avg_sq) or None to freeze that tensor.  x_range = (x_begin, x_end)
@@ -609,7 +681,10 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
     `dcl_reference` (densities of the pretrained field, same shape as `densities`): the density-correlation regulariser of the
     SDS edit (modules/sds_trainer.py:507-524) with weight `dcl_weight` is evaluated INSIDE the step -- its moments by two small
     launches on the current parameters, its gradient per voxel in the Adam pass -- and `dcl_loss` (float32 scalar tensor on the
-    device) receives the unweighted loss value."""
+    device) receives the unweighted loss value.  `density_kind` (abi.DREG_*): the same three arguments as the l2_mode / l1_mode
+    regulariser (sds_trainer.py:494-503: per-voxel terms, no reduction unless `dcl_loss` is given).  `feat_reference` /
+    `feat_weight` / `feat_loss`: _feature_correlation_loss (sds_trainer.py:526-534) against the pretrained field's features,
+    evaluated per voxel inside the step (SH-0 / attention grids)."""
     device = densities.device
     ensure_gfx950(device)
     tensors = [("densities", densities, densities), ("features", features, features)]
@@ -617,7 +692,7 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
         if st is not None:
             tensors += [(nm, st[0], ref), (nm, st[1], ref)]
     for nm, t, ref in (("extra_d_densities", extra_d_densities, densities), ("extra_d_features", extra_d_features, features),
-                       ("dcl_reference", dcl_reference, densities)):
+                       ("dcl_reference", dcl_reference, densities), ("feat_reference", feat_reference, features)):
         if t is not None:
             tensors.append((nm, t, ref))
     for nm, t, ref in tensors:
@@ -633,12 +708,17 @@ def grid_adam_step_(spec: GridSpec, densities, features, grad_layout: int, works
         ws = workspace.buf
         x0, x1 = (0, int(densities.shape[0])) if x_range is None else (int(x_range[0]), int(x_range[1]))
         reg = None
-        if dcl_reference is not None:
-            if dcl_loss is not None and (not dcl_loss.is_cuda or dcl_loss.dtype != torch.float32 or dcl_loss.numel() != 1):
-                raise VoxeError("grid_adam_step_: dcl_loss must be a float32 scalar tensor on the device")
+        if dcl_reference is not None or feat_reference is not None:
+            for nm, t in (("dcl_loss", dcl_loss), ("feat_loss", feat_loss)):
+                if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.numel() != 1):
+                    raise VoxeError(f"grid_adam_step_: {nm} must be a float32 scalar tensor on the device")
             sc = _scratch_for(device, lib().voxe_dcl_scratch_bytes(densities.numel()))
             reg = abi.VoxeGridRegularisers()
-            reg.dcl_reference, reg.dcl_weight, reg.dcl_loss = ptr(dcl_reference), float(dcl_weight), ptr(dcl_loss)
+            if dcl_reference is not None:
+                reg.dcl_reference, reg.dcl_weight, reg.dcl_loss = ptr(dcl_reference), float(dcl_weight), ptr(dcl_loss)
+                reg.density_kind = int(density_kind)
+            if feat_reference is not None:
+                reg.feat_reference, reg.feat_weight, reg.feat_loss = ptr(feat_reference), float(feat_weight), ptr(feat_loss)
             reg.scratch, reg.scratch_bytes = ptr(sc), sc.numel()
         check(lib().voxe_grid_adam_step(C.byref(g), int(grad_layout), x0, x1, ptr(extra_d_densities), ptr(extra_d_features),
                                         ptr(m_d), ptr(v_d), ptr(m_f), ptr(v_f), float(lr), float(beta1), float(beta2),
