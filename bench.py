@@ -67,7 +67,11 @@ def parse():
     ap.add_argument("--ray-order", choices=["image", "linear", "random"], default="image",
                     help="image: row-major image rays with the width hint (LDS-window backward); linear: same rays without the "
                          "hint; random: the rays in a random permutation (what a random-ray training batch looks like)")
-    ap.add_argument("--camera", type=int, default=3, help="index of the synthetic camera (of 100) rendered by rank 0")
+    ap.add_argument("--camera", type=int, default=None, help="index of the first synthetic camera (of 100) rendered by rank 0 (default 3); "
+                                                               "given explicitly it also means --views 1 unless --views says otherwise")
+    ap.add_argument("--views", type=int, default=None,
+                    help="cameras of the 100-view set the steps cycle through (BASELINE configs[1] is '100 views @ 400x400'): step i renders "
+                         "camera (camera + 5 (i mod V)) mod 100 (+ 37 per rank).  Default 20: the driver's --steps 20 renders each once")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: one camera per rank (total work grows with N); strong: ONE camera, every rank renders a band of "
                          "its rows (what a multi-GPU SDS iteration does: one image per step, modules/sds_trainer.py) -- same "
@@ -78,6 +82,11 @@ def parse():
 
 def main():
     args = parse()
+    n_views = args.views if args.views is not None else (1 if args.camera is not None else 20)
+    if args.camera is None:
+        args.camera = 3
+    if n_views < 1:
+        raise SystemExit("--views must be >= 1")
     from voxe_hip.workload import FAR, NEAR, RADIUS, focal_for, random_grid, sphere_grid, synth_pose_angles
     from thre3d_atom.utils.imaging_utils import pose_spherical
     from voxe_hip import abi, ops
@@ -127,21 +136,31 @@ def main():
     strong = args.scaling == "strong"
     if strong and args.ray_order != "image":
         raise SystemExit("--scaling strong shards an IMAGE by rows: use --ray-order image")
-    yaw, pitch = synth_pose_angles(args.camera + (0 if strong else rank), 100)
-    pose = pose_spherical(yaw, pitch, RADIUS)
-    rays_o, rays_d = ops.cast_rays(HW, HW, focal_for(HW), pose.rotation, pose.translation, dev)
+    def camera_of(view, rk):
+        return (args.camera + 5 * view + (0 if strong else 37 * rk)) % 100
+
     rows = (0, HW)
     if strong:
         from thre3d_atom.modules.parallel import shard_rows
 
         rows = shard_rows(HW, rank, world)
-        rays_o = rays_o[rows[0] * HW: rows[1] * HW].contiguous()
-        rays_d = rays_d[rows[0] * HW: rows[1] * HW].contiguous()
+    perm = torch.randperm((rows[1] - rows[0]) * HW, generator=torch.Generator().manual_seed(7)).to(dev) if args.ray_order == "random" else None
+    view_rays, view_cams = [], []
+    for j in range(n_views):
+        yaw, pitch = synth_pose_angles(camera_of(j, rank), 100)
+        pose_j = pose_spherical(yaw, pitch, RADIUS)
+        ro_j, rd_j = ops.cast_rays(HW, HW, focal_for(HW), pose_j.rotation, pose_j.translation, dev)
+        if strong:
+            ro_j = ro_j[rows[0] * HW: rows[1] * HW].contiguous()
+            rd_j = rd_j[rows[0] * HW: rows[1] * HW].contiguous()
+        if perm is not None:
+            ro_j, rd_j = ro_j[perm].contiguous(), rd_j[perm].contiguous()
+        view_rays.append((ro_j, rd_j))
+        view_cams.append(camera_of(j, rank))
+    pose = pose_spherical(*synth_pose_angles(args.camera, 100), RADIUS)     # (the first view: CPU / GPU baselines, secondary lines)
+    rays_o, rays_d = view_rays[0]
     R = rays_o.shape[0]
     R_job = HW * HW if strong else world * R          # rays of the whole job per step
-    if args.ray_order == "random":
-        perm = torch.randperm(R, generator=torch.Generator().manual_seed(7)).to(dev)
-        rays_o, rays_d = rays_o[perm].contiguous(), rays_d[perm].contiguous()
     hint = HW if args.ray_order == "image" else 0
     params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=not args.no_jitter, white_bkgd=True,
                               term_eps=args.term_eps, image_width=hint)
@@ -155,9 +174,11 @@ def main():
 
     # in-AABB sample count of this camera (un-jittered depths), outside the timed region
     probe_params = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, white_bkgd=True, image_width=hint)
-    inside = ops.sample_probe(spec, probe_params, dens, feat, rays_o, rays_d, outputs=("inside",))["inside"]
-    s_in_total = int(inside.sum().item())
-    del inside
+    s_in_views = []
+    for ro_j, rd_j in view_rays:
+        inside = ops.sample_probe(spec, probe_params, dens, feat, ro_j, rd_j, outputs=("inside",))["inside"]
+        s_in_views.append(int(inside.sum().item()))
+        del inside
 
     step_no = [0]
     # `--optimizer split`, N > 1: ONE all-reduce of the flat gradient, then the replicated Adam on every rank
@@ -187,7 +208,14 @@ def main():
         first[0] = False
         opt.step(wsx, layout)
 
+    view_of_step = []     # (which view every step() call rendered, in call order)
+
     def step():
+        ro_v, rd_v = view_rays[len(view_of_step) % n_views]
+        view_of_step.append(len(view_of_step) % n_views)
+        return step_on(ro_v, rd_v)
+
+    def step_on(rays_o, rays_d):
         if fused:
             return fused_step(params, rays_o, rays_d, (colour, depth, acc, disp), g_colour, ws)
         step_no[0] += 1
@@ -256,6 +284,7 @@ def main():
         opt.exchange_ms, opt.exchange_steps = 0.0, 0
     ops.profile_enable(True)
     barrier()
+    del view_of_step[:]         # (the timed steps start at view 0 whatever the warm-up rendered)
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record()
@@ -263,6 +292,9 @@ def main():
     marks[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_views = list(view_of_step)
+    # in-AABB samples of the launches that were timed (every view as often as it was rendered)
+    s_in_total = sum(s_in_views[v] for v in timed_views) / max(len(timed_views), 1)
     gc.enable()
     step_ms_in_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     step_ms = sorted(step_ms_in_order)
@@ -301,11 +333,11 @@ def main():
     # tell view imbalance from the cost of the exchange
     per_rank = None
     if dist is not None:
-        mine = torch.tensor([float(args.camera + (0 if strong else rank)), s_in_total / max(R, 1), ms_fwd, ms_bwd],
+        mine = torch.tensor([float(view_cams[0]), s_in_total / max(R, 1), ms_fwd, ms_bwd],
                             dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = {"camera": [int(t[0].item()) for t in allr], "in_aabb_samples_per_ray": [round(t[1].item(), 2) for t in allr],
+        per_rank = {"first_camera": [int(t[0].item()) for t in allr], "in_aabb_samples_per_ray": [round(t[1].item(), 2) for t in allr],
                     "fwd_ms": [round(t[2].item(), 4) for t in allr], "bwd_ms": [round(t[3].item(), 4) for t in allr]}
     # the forward kernel of this launch: image-ordered SH-0 renders march through the LDS texel window (r03) unless switched off
     from voxe_hip import dispatch as _dispatch
@@ -325,25 +357,26 @@ def main():
         kname, kbytes, kms = bwd_name, bytes_bwd, ms_bwd
     else:
         kname, kbytes, kms = fwd_kernel.replace("voxe::", "").replace(", ", ","), bytes_fwd, ms_fwd
-    achieved = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    # Physical side of the picture (PMC counters cannot be read from inside this process; they are collected by
-    # tools/gpu_pmc.sh -- rocprofv3 --pmc in separate passes over THIS script -- and committed as
-    # profiles/rNN_pmc_summary.json; only reported for the configuration they were measured on):
-    #   traffic          HBM-side bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md, HBM section:
-    #                    FETCH_SIZE tallies 128-B requests at 64 B on gfx950)
-    #   compulsory_bytes read the grid once + write the gradient once = 2 * G^3 * 4 ch * 4 B (131 MB at 160^3)
-    #   valu_issue_frac  SQ_INSTS_VALU * 4 clk / (1024 SIMDs * clk_hz * launch time): share of the launch the SIMDs'
-    #                    VALU issue ports are busy (a wave64 f32 instruction occupies its SIMD for 4 cycles)
-    #   lds_issue_frac   SQ_LDS_IDX_ACTIVE / (256 CUs * clk_hz * launch time): share the LDS pipelines are busy
-    # The kernel is bound by those two issue rates, not by HBM: `frac` (SURVEY.md 8(d)'s requested-bytes convention) can
-    # exceed 1 because corner fetches shared by neighbouring rays are served on chip; `binding` names the ceiling that
-    # actually limits the kernel and `binding_frac` its utilisation -- none of the physical fractions can exceed 1.
-    # The PMC summary is only valid for the kernels it was collected on: tools/pmc_to_json.py stamps it with a hash of
-    # vox-e_amd/csrc/* + include/voxe.h, and a summary whose hash differs from this tree's is reported as stale, not used.
+    alg_gbs = kbytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    # ---- what binds the dominant kernel (r06) ------------------------------------------------------------------------------
+    # The render kernels work out of the Infinity Cache / L2 / LDS: SURVEY 8(d)'s requested-bytes figure (`alg`) exceeds the HBM
+    # peak because corner fetches shared by neighbouring rays never reach HBM.  The top-level `frac` is therefore the fraction of
+    # the ceiling that PHYSICALLY binds the kernel (<= 1 by construction), out of three measured candidates:
+    #   valu_issue  sum over instruction classes of (dynamic count, PMC) x (clk per wave64 instruction per SIMD, measured by
+    #               tools/microbench/valu_rate.hip: profiles/r06_valu_rate.txt) / (1024 SIMDs x measured clock x launch time).
+    #               Counts: SQ_INSTS_VALU and its class counters (TRANS_F32, {ADD,MUL,FMA}_F64, CVT, {ADD,MUL,FMA}_F32) per launch
+    #               from the PMC summary; price of a class: the static mix of the kernel's sample loop
+    #               (tools/isa_issue_model.py -> profiles/r06_issue_model.json: which of its f32 / integer instructions are
+    #               double-rate forms without an SGPR operand -- 2.15 clk -- and which are not -- 4.2 clk)
+    #   lds_issue   SQ_LDS_IDX_ACTIVE / (256 CUs x clock x time): share of the launch the LDS pipelines are busy
+    #   hbm         (2 FETCH_SIZE + WRITE_SIZE) KiB / time against 8 TB/s (MI355X_MICROARCH.md, HBM section)
+    # Counters are per launch from the committed PMC summary whose source_hash equals this tree's (tools/gpu_pmc.sh: rocprofv3
+    # --pmc in separate passes over THIS script); launch time (HIP events on the launch stream) and shader clock
+    # (voxe_clock_probe right behind the timed steps) are this run's.  A summary of other sources is reported as stale, never used.
     from voxe_hip.build import source_hash
 
     src_hash = source_hash()
-    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, args.ray_order, strong) == (160, 400, 256, "random", 0.0, False, 3, "image", False)
+    default_cfg = (G, HW, S, args.scene, args.term_eps, args.no_jitter, args.camera, n_views, args.ray_order, strong) == (160, 400, 256, "random", 0.0, False, 3, 20, "image", False)
     pmc, pmc_rel, pmc_stale = None, None, None
     pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_summary.json"))
     if default_cfg and pmc_files:
@@ -352,6 +385,35 @@ def main():
         pmc_stale = summary.get("source_hash") != src_hash
         if not pmc_stale:
             pmc = summary["kernels"]
+    issue_models = {}
+    im_path = os.path.join(ROOT, "profiles", "r06_issue_model.json")
+    if os.path.exists(im_path):
+        im = json.load(open(im_path))
+        if im.get("source_hash") == src_hash:
+            issue_models = im["kernels"]
+
+    PMC_CLASSES = ("TRANS_F32", "ADD_F64", "MUL_F64", "FMA_F64", "CVT", "ADD_F32", "MUL_F32", "FMA_F32")
+
+    def issue_model(kernel_key, cnt):
+        """VALU issue cycles per launch (all SIMDs together) = sum_class count x clk; None without the inputs"""
+        model = issue_models.get(kernel_key)
+        if model is None or "SQ_INSTS_VALU" not in cnt:
+            return None
+        price = model["clk_per_valu_by_pmc_class"]
+        total, known, detail = 0.0, 0.0, {}
+        for cls in PMC_CLASSES:
+            n = cnt.get("SQ_INSTS_VALU_" + cls)
+            if n is None:
+                continue
+            c = price.get(cls, 8.1 if cls == "TRANS_F32" else 4.2)
+            total += n * c
+            known += n
+            detail[cls] = {"count": n, "clk": c}
+        rest = max(cnt["SQ_INSTS_VALU"] - known, 0.0)
+        c_rest = price.get("OTHER", model["clk_per_valu"]) if known > 0 else model["clk_per_valu"]
+        total += rest * c_rest
+        detail["OTHER" if known > 0 else "ALL (no class counters in the summary: static mean of the sample loop)"] = {"count": rest, "clk": c_rest}
+        return {"cycles": total, "clk_per_valu": total / max(cnt["SQ_INSTS_VALU"], 1.0), "classes": detail}
 
     def physical_of(prefix, accept, launch_ms):
         """ceilings of one kernel: counters per launch from the hash-matched PMC summary, launch time and clock from THIS run"""
@@ -366,7 +428,9 @@ def main():
             return None
         t = launch_ms * 1e-3
         hbm_bytes = int((2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"]) * 1024)
-        ceil = {"valu_issue": cnt["SQ_INSTS_VALU"] * 4.0 / (1024 * clock_hz * t), "lds_issue": cnt["SQ_LDS_IDX_ACTIVE"] / (256 * clock_hz * t),
+        im_ = issue_model(keys[0], cnt)
+        valu_cycles = im_["cycles"] if im_ else cnt["SQ_INSTS_VALU"] * 4.2     # (no static model: every instruction at the single rate -- an upper bound)
+        ceil = {"valu_issue": valu_cycles / (1024 * clock_hz * t), "lds_issue": cnt["SQ_LDS_IDX_ACTIVE"] / (256 * clock_hz * t),
                 "hbm": hbm_bytes / t / 1e9 / HBM_PEAK_GBS}
         binding = max(ceil, key=ceil.get)
         return {
@@ -374,44 +438,57 @@ def main():
             "valu_issue_frac": round(ceil["valu_issue"], 4), "lds_issue_frac": round(ceil["lds_issue"], 4),
             "hbm_frac_measured": round(ceil["hbm"], 4), "traffic_bytes": hbm_bytes,
             "binding": binding, "binding_frac": round(ceil[binding], 4),
-            "at_peak_clock": {"valu_issue_frac": round(ceil["valu_issue"] * clock_hz / SHADER_CLOCK_HZ, 4),
-                              "lds_issue_frac": round(ceil["lds_issue"] * clock_hz / SHADER_CLOCK_HZ, 4)},
-            "counters": {k: cnt[k] for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT",
-                                             "FETCH_SIZE", "WRITE_SIZE") if k in cnt},
+            "valu_issue_cycles_per_launch": round(valu_cycles, 0), "valu_clk_per_instruction": round(im_["clk_per_valu"], 3) if im_ else 4.2,
+            "valu_issue_model": ({k: {"count": round(v["count"], 0), "clk": v["clk"]} for k, v in im_["classes"].items()} if im_ else
+                                 "no static model for these sources (python tools/isa_issue_model.py --write): 4.2 clk per instruction"),
+            # the SQ's own busy counter next to the model (quad-cycles per MI355X_MICROARCH.md: x 4)
+            "sq_active_inst_valu_frac": (round(cnt["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * clock_hz * t), 4) if "SQ_ACTIVE_INST_VALU" in cnt else None),
+            "resident_waves_per_simd": model_occupancy.get(keys[0]),
+            "counters": {k: cnt[k] for k in ("SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_VALU",
+                                             "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "FETCH_SIZE", "WRITE_SIZE") if k in cnt},
         }
 
-    def _is_headline_bwd(name):
-        # template arguments of the backward: ..., MODE, window width KL[, deterministic]; 400x400 at 160^3 runs the 8-wide
-        # float-atomic one
-        targs = [a.strip() for a in name[name.index("<") + 1: name.rindex(">")].split(",")]
-        return len(targs) >= 7 and targs[6] == "8" and (len(targs) < 8 or targs[7] == "false")
-
-    phys_bwd = (physical_of("voxe::render_bwd_tile4_kernel<8, false, 0>", lambda k: True, ms_bwd) if lean else
-                physical_of("voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0,", _is_headline_bwd, ms_bwd))
+    model_occupancy = {k: v.get("occupancy_waves_per_simd") for k, v in issue_models.items()}
+    phys_bwd = physical_of("voxe::render_bwd_tile4_kernel<8, false, 0>", lambda k: True, ms_bwd) if lean else None
     phys_fwd = physical_of(fwd_kernel, lambda k: True, ms_fwd)
     physical = phys_bwd if ms_bwd >= ms_fwd else phys_fwd
-    traffic = physical.get("traffic_bytes") if physical and not physical.get("stale") else None
-    traffic_src = (f"{pmc_rel} (rocprofv3 --pmc, per launch; (2*FETCH_SIZE + WRITE_SIZE) KiB; source_hash {src_hash}), "
+    usable = bool(physical) and not physical.get("stale")
+    traffic = physical.get("traffic_bytes") if usable else None
+    traffic_src = (f"{pmc_rel} (rocprofv3 --pmc, per launch, mean over the {n_views} views; (2*FETCH_SIZE + WRITE_SIZE) KiB; source_hash {src_hash}), "
                    f"kernel {physical['kernel']}") if traffic else None
-    if physical and not physical.get("stale"):
+    if usable:
         physical = dict(physical)
         physical["compulsory_bytes"] = int(2 * nvox * 4 * 4)       # read the grid once + write the gradient once
         physical["traffic_over_compulsory"] = round(traffic / (2 * nvox * 4 * 4), 2)
-        physical["note"] = ("counters per launch from the committed PMC summary whose source_hash equals this tree's; launch time "
-                            "(HIP events) and shader clock (voxe_clock_probe: s_memtime / s_memrealtime under a VALU + LDS load, "
-                            "right behind the timed steps) are THIS run's; `at_peak_clock` = the same fractions against 2.4 GHz")
-    binding = physical.get("binding") if physical and not physical.get("stale") else None
+    binding = physical.get("binding") if usable else None
+    # top level: the binding ceiling in ITS units.  valu_issue / lds_issue: issue cycles used per second against the cycles the
+    # chip has (1024 SIMDs resp. 256 LDS pipelines x measured clock); hbm: measured traffic against 8 TB/s.  Without a usable PMC
+    # summary (other configurations than the headline one, stale sources) only the requested-bytes figure can be stated: `frac`
+    # is then null rather than a number above 1.
+    if binding == "valu_issue":
+        units, r_peak = "G issue-clk/s (1024 SIMDs)", 1024 * clock_hz / 1e9
+        r_ach = physical["valu_issue_frac"] * r_peak
+    elif binding == "lds_issue":
+        units, r_peak = "G issue-clk/s (256 LDS pipelines)", 256 * clock_hz / 1e9
+        r_ach = physical["lds_issue_frac"] * r_peak
+    elif binding == "hbm":
+        units, r_peak = "GB/s", HBM_PEAK_GBS
+        r_ach = physical["hbm_frac_measured"] * r_peak
+    else:
+        units, r_peak, r_ach = "GB/s", HBM_PEAK_GBS, None
     roofline = {
-        # `bound`: the ceiling that actually binds the dominant kernel when the PMC summary of THESE sources is at hand
-        # ("lds_issue" / "valu_issue" / "hbm": see `physical`); `achieved` / `peak` / `frac` are SURVEY 8(d)'s HBM-unit
-        # requested-bytes figures whatever binds (`bound_of_frac`)
-        "bound": binding or "hbm", "bound_of_frac": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-        "kernel": kname, "alg_bytes_per_launch": int(kbytes), "launch_ms": round(kms, 4),
-        # `achieved` / `frac` follow SURVEY.md 8(d)'s REQUESTED-bytes model (every trilinear corner fetch / scatter
-        # counted); they are a throughput figure in HBM units, not a physical utilisation -- see `physical`
-        "frac_is": "requested-bytes convention of SURVEY.md 8(d) (can exceed 1: corner fetches shared by neighbouring rays "
-                   "are served from L1 / L2 / the LDS gradient window); the physical ceilings are in `physical`",
+        "bound": binding or "unknown (no PMC summary for this configuration / these sources: see `alg`)",
+        "achieved": round(r_ach, 2) if r_ach is not None else None, "peak": round(r_peak, 2), "unit": units,
+        "frac": round(r_ach / r_peak, 4) if r_ach is not None else None,
+        "frac_is": "utilisation of the ceiling that binds the dominant kernel (<= 1): see `physical` for all three candidates and "
+                   "`alg` for SURVEY 8(d)'s requested-bytes throughput in HBM units",
+        "traffic": traffic, "traffic_source": traffic_src,
+        "kernel": kname, "launch_ms": round(kms, 4),
+        # SURVEY.md 8(d)'s REQUESTED-bytes model (every trilinear corner fetch / scatter counted): a throughput in HBM units that
+        # exceeds the HBM peak for these cache-resident kernels -- kept because the survey's contract quotes it
+        "alg": {"bytes_per_launch": int(kbytes), "gbs": round(alg_gbs, 2), "frac_of_hbm_peak": round(alg_gbs / HBM_PEAK_GBS, 4),
+                "note": "256 B per in-AABB sample + 56 B per ray (backward) / 128 B + 48 B (forward); corner fetches shared by neighbouring "
+                        "rays are served from L1 / L2 / the LDS gradient window, so this is not a physical utilisation"},
         "hbm_measured_gbs": (round(traffic / (kms * 1e-3) / 1e9, 1) if traffic else None),
         "physical": physical,
         # the other render kernel of the step (the forward when the backward dominates), same derivation
@@ -492,17 +569,6 @@ def main():
 
         secondary = small_step_bench(1)
         secondary["multi_view"] = small_step_bench(8)
-        # the headline camera looks along a grid axis; the same step from other views of the synthetic set (z-dominant, oblique):
-        # the backward's LDS window is view dependent (profiles/r03_ab_orientation.txt)
-        views = {}
-        for cam in [int(x) for x in os.environ.get("VOXE_BENCH_VIEWS", "0,12,26,40,77,90").split(",")]:
-            v = small_step_bench(1, hw2=HW, cam0=cam)
-            views[str(cam)] = {k: v[k] for k in ("value", "ms_per_step", "fwd_ms", "bwd_ms", "in_aabb_samples_per_ray")}
-        mean_ms = (sum(v["ms_per_step"] for v in views.values()) + ms_per_step) / (len(views) + 1)
-        secondary["views"] = {"workload": f"the headline step from 6 other cameras of the 100-view set ({HW}x{HW})", "cameras": views,
-                              "mean_rays_per_s_incl_headline_camera": round(HW * HW / (mean_ms * 1e-3), 1),
-                              "mean_ms_per_step": round(mean_ms, 4)}
-
         # the reconstruction trainer's iteration (BASELINE.json configs[1] scale: 32 768 random rays over 8 cameras, specular +
         # diffuse L1, fused Adam) as ONE library call, voxe_recon_step -- tools/recon_bench.py has the trainer-level version
         def recon_iteration_bench(iters):
@@ -740,7 +806,21 @@ def main():
                       f"threads = {dt * threads:.0f} core-seconds",
         }
 
+    views_report = None
     if rank == 0:
+        by_view = {}
+        for v, ms in zip(timed_views, step_ms_in_order):
+            by_view.setdefault(v, []).append(ms)
+        mean_ms = {v: sum(x) / len(x) for v, x in by_view.items()}
+        slow, fast = max(mean_ms, key=mean_ms.get), min(mean_ms, key=mean_ms.get)
+        views_report = {
+            "count": n_views, "cameras_of_rank0": view_cams,
+            "ms_per_step_by_view": [round(mean_ms[v], 4) if v in mean_ms else None for v in range(n_views)],
+            "in_aabb_samples_per_ray_by_view": [round(x / max(R, 1), 1) for x in s_in_views],
+            "min_rays_per_s": round(R / (mean_ms[slow] * 1e-3), 1), "min_camera": view_cams[slow],
+            "max_rays_per_s": round(R / (mean_ms[fast] * 1e-3), 1), "max_camera": view_cams[fast],
+            "note": "per-view figures are rank 0's rays over the device time of its step (events on the launch stream)",
+        }
         out = {
             "metric": "rendered rays/sec (fwd+bwd)", "value": round(rays_per_s, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -752,11 +832,16 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{G}^3 SH-0 softplus ReLU-field grid ({args.scene}), "
-                            + (f"ONE {HW}x{HW} camera split into row bands over the GPUs, " if strong else f"one {HW}x{HW} camera per GPU, ") +
+                            + (f"ONE {HW}x{HW} camera per step split into row bands over the GPUs, " if strong else f"one {HW}x{HW} camera per GPU and step, ") +
+                            (f"the steps cycle through {n_views} cameras of the 100-view set, " if n_views > 1 else f"camera {args.camera}, ") +
                             f"S={S}, jitter {'off' if args.no_jitter else 'on'}, white bkgd, ray order {args.ray_order}; step = render fwd + bwd"
                             f"{' + RCCL all-reduce of the grid gradient' if world > 1 else ''}"
                             f"{'' if args.no_adam else (' + Adam (fused grid step)' if fused else ' + Adam')}",
                 "grid": G, "image": [HW, HW], "samples_per_ray": S, "rays_per_gpu_per_step": R,
+                # r06 (the single headline camera was the fastest of seven): the timed steps cycle through
+                # `count` cameras of the 100-view set, so `value` IS the mean over views; per view (rank 0): device time between
+                # the step's events on the launch stream
+                "views": views_report,
                 "grad_exchange": (opt.mode if fused else ("all-reduce" if dist is not None else "none")), "parallelism": (f"rows of one image sharded over {world} GPU(s), grid replicated" if strong else f"rays sharded by camera over {world} GPU(s), grid replicated"),
                 "rows_of_rank0": list(rows),
                 "replicas_consistent": replicas_consistent, "backend": (backend if dist is not None else None),

@@ -38,7 +38,8 @@ def test_two_rank_bench_on_one_gpu(exchange, expect):
     assert cfg["replicas_consistent"] is True and cfg["backend"] == "gloo" and cfg["optimizer"] == "fused"
     assert cfg["grad_exchange"].startswith(expect)
     assert cfg["rays_per_gpu_per_step"] == 96 * 96
-    assert cfg["per_rank"]["camera"] == [3, 4] and all(x > 0 for x in cfg["per_rank"]["bwd_ms"])
+    assert cfg["per_rank"]["first_camera"] == [3, 40] and all(x > 0 for x in cfg["per_rank"]["bwd_ms"])
+    assert cfg["views"]["count"] == 20 and cfg["views"]["cameras_of_rank0"][:3] == [3, 8, 13]      # the steps cycle through the view set
     if exchange == "auto":
         assert set(cfg["exchange_autotune_ms"]) == {"reduce-scatter", "all-to-all", "all-reduce"}
 
@@ -101,8 +102,9 @@ def test_two_rank_sds_loop_equals_one_process():
 @pytest.mark.timeout(600)
 def test_default_bench_line_has_the_contract_fields():
     """the driver's N = 1 command line (short): one JSON line with the contract's fields, the roofline object fed by a PMC
-    summary that belongs to these kernel sources (not stale), the CPU / same-GPU baselines and the other-views sweep"""
-    env = dict(os.environ, VOXE_BENCH_PRE_WARM_MS="20", VOXE_BENCH_VIEWS="12,26")
+    summary that belongs to these kernel sources (not stale), the CPU / same-GPU baselines; r06: the steps cycle through 20 cameras
+    of the 100-view set (value = mean over views) and `roofline.frac` is the utilisation of the ceiling that binds (<= 1)"""
+    env = dict(os.environ, VOXE_BENCH_PRE_WARM_MS="20")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--cpu-sample", "40"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=560)
     assert res.returncode == 0, res.stderr[-2000:]
@@ -114,18 +116,22 @@ def test_default_bench_line_has_the_contract_fields():
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["dtype"] == "f32" and out["value"] > 1e7
     roof = out["roofline"]
-    assert roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["bound_of_frac"] == "hbm"
+    assert roof["alg"]["frac_of_hbm_peak"] > 0 and roof["alg"]["bytes_per_launch"] > 0          # SURVEY 8(d)'s requested-bytes figure
     if roof["physical"].get("stale"):
         # the committed PMC summary was collected on other kernel sources (a kernel edit since the last tools/gpu_pmc.sh run):
-        # the line must say so instead of mixing those counters with this run's timings
-        assert "source_hash" in roof["physical"]["reason"] and roof["traffic"] is None and roof["bound"] == "hbm"
+        # the line must say so instead of mixing those counters with this run's timings -- and states NO fraction
+        assert "source_hash" in roof["physical"]["reason"] and roof["traffic"] is None and roof["frac"] is None
     else:
         assert roof["traffic"] > 0 and roof["bound"] == roof["physical"]["binding"]
         assert roof["physical"]["binding"] in ("lds_issue", "valu_issue", "hbm") and 0 < roof["physical"]["binding_frac"] <= 1
+        assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+        assert abs(roof["frac"] - roof["physical"]["binding_frac"]) < 1e-3
         assert roof["physical_other"]["kernel"].startswith("voxe::render_fwd_tile")   # tile4 (lean, r05) or tile (general)
     assert out["ms_per_step_min"] <= out["ms_per_step_median"] <= out["ms_per_step_max"] and out["config"]["untimed_warmup_ms"] >= 5
     assert out["cpu_baseline"]["reps"] == 3 and out["gpu_baseline"]["reps"] == 3
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     assert out["gpu_baseline"]["value"] > 0 and out["gpu_baseline"]["speedup"] > 10
-    views = out["secondary"]["views"]
-    assert set(views["cameras"]) == {"12", "26"} and all(v["value"] > 1e7 for v in views["cameras"].values())
+    views = out["config"]["views"]
+    assert views["count"] == 20 and len(views["cameras_of_rank0"]) == 20 and views["cameras_of_rank0"][:4] == [3, 8, 13, 18]
+    assert views["ms_per_step_by_view"][:4] == [x for x in views["ms_per_step_by_view"][:4] if x and x > 0]     # steps 0..3 rendered views 0..3
+    assert views["min_rays_per_s"] <= views["max_rays_per_s"] and views["min_rays_per_s"] > 1e7
