@@ -727,6 +727,62 @@ def main():
                     "bwd_ms_per_render": round(pr3["ms_bwd"] / max(pr3["n_bwd"], 1), 4),
                     "autograd_loop_ms_per_iteration": round(1e3 * e3a, 4)}
 
+        # ---- what the 1 -> 8 GPU curve should look like: a MODEL, from this GPU's measured render times and
+        # the link rates of SURVEY.md section 5 -- there is no multi-GPU node in the builder's pool, the driver's SCALE_rNN.json is
+        # to be read against these predictions.  Per step and rank: render (fwd + bwd of its rays) + Adam on 1/N of the grid +
+        # exchange of the grid gradient (reduce-scatter) and of the packed grid (all-gather), G = 16 B x voxels each way.
+        #   direct  every rank sends slab j straight to rank j over its own xGMI link (all-to-all / "pipelined"): 2 (G / N) / link
+        #   ring    per-link bound ring collectives:                                                       2 (N - 1) / N G / link
+        def scaling_model():
+            from thre3d_atom.modules.parallel import shard_rows
+
+            link = 153.0e9                                   # B/s per xGMI link and direction
+            g_bytes = nvox * 16.0
+            t_adam = max(ms_per_step - ms_fwd - ms_bwd, 0.0)   # everything of the 1-GPU step that is not the two render phases
+            ro0, rd0 = view_rays[0]
+
+            def band_ms(lo, hi):
+                ro_b, rd_b = ro0[lo * HW: hi * HW].contiguous(), rd0[lo * HW: hi * HW].contiguous()
+                Rb = ro_b.shape[0]
+                pb = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True, image_width=HW)
+                outs = [torch.empty((Rb, n), dtype=torch.float32, device=dev) for n in (3, 1, 1, 1)]
+                gb = g_colour[lo * HW: hi * HW].contiguous()
+                wsb = ops.Workspace()
+                for i in range(9):
+                    if i == 3:
+                        torch.cuda.synchronize()
+                        ops.profile_enable(True)
+                    ops.render_fwd_into(spec, pb, dens, feat, ro_b, rd_b, None, *outs, wsb, (42, 900 + i))
+                    ops.render_bwd_acc(spec, pb, dens, feat, ro_b, rd_b, None, outs[0], outs[1], outs[2], gb, None, None, wsb,
+                                       (42, 900 + i), zero_first=True)
+                torch.cuda.synchronize()
+                prb = ops.profile_read()
+                ops.profile_enable(False)
+                return (prb["ms_fwd"] + prb["ms_memset"] + prb["ms_bwd"]) / max(prb["n_bwd"], 1)
+
+            rows_out = {}
+            for n in (2, 4, 8):
+                bands = [shard_rows(HW, r, n) for r in range(n)]
+                times = [band_ms(lo, hi) for lo, hi in bands]
+                t_band = max(times)
+                x_direct = 2.0 * (g_bytes / n) / link * 1e3
+                x_ring = 2.0 * (n - 1) / n * g_bytes / link * 1e3
+                t_full = ms_fwd + ms_bwd
+                rows_out[str(n)] = {
+                    "band_rows": [hi - lo for lo, hi in bands], "band_render_ms_max": round(t_band, 4), "band_render_ms_mean": round(sum(times) / n, 4),
+                    "adam_ms": round(t_adam / n, 4), "exchange_ms_direct": round(x_direct, 4), "exchange_ms_ring": round(x_ring, 4),
+                    "weak": {"rays_per_s_direct": round(n * HW * HW / ((t_full + t_adam / n + x_direct) * 1e-3), 1),
+                             "rays_per_s_ring": round(n * HW * HW / ((t_full + t_adam / n + x_ring) * 1e-3), 1)},
+                    "strong": {"rays_per_s_direct": round(HW * HW / ((t_band + t_adam / n + x_direct) * 1e-3), 1),
+                               "rays_per_s_ring": round(HW * HW / ((t_band + t_adam / n + x_ring) * 1e-3), 1)},
+                }
+            return {"what": "PREDICTION, not a measurement: 1-GPU render times of this run (row bands of the first view for --scaling strong: "
+                            "the slowest band of the N) + Adam / N + gradient and packed-grid exchange at 153 GB/s per xGMI link and direction "
+                            "(direct: all N - 1 links at once; ring: per-link bound).  Nothing overlaps the exchange (DESIGN.md section 6)",
+                    "one_gpu": {"render_ms": round(ms_fwd + ms_bwd, 4), "adam_and_rest_ms": round(t_adam, 4), "rays_per_s": round(rays_per_s, 1)},
+                    "grid_bytes_each_way": int(g_bytes), "by_gpus": rows_out}
+
+        secondary["scaling_model"] = scaling_model()
         secondary["sds_iteration"] = sds_iteration_bench(max(args.steps, 20))
         secondary["refine_iteration"] = refine_iteration_bench(max(args.steps, 20))
 

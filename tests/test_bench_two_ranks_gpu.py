@@ -23,7 +23,8 @@ def _free_port():
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("exchange,expect", [("reduce-scatter", "reduce-scatter + sharded step"), ("all-to-all", "all-to-all + local sum"),
-                                             ("all-reduce", "all-reduce + replicated step"), ("auto", "")])
+                                             ("all-reduce", "all-reduce + replicated step"),
+                                             ("pipelined", "pipelined direct exchange"), ("auto", "")])
 def test_two_rank_bench_on_one_gpu(exchange, expect):
     env = dict(os.environ, VOXE_BENCH_BACKEND="gloo", VOXE_GRAD_EXCHANGE=exchange, VOXE_BENCH_PRE_WARM_MS="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -41,7 +42,7 @@ def test_two_rank_bench_on_one_gpu(exchange, expect):
     assert cfg["per_rank"]["first_camera"] == [3, 40] and all(x > 0 for x in cfg["per_rank"]["bwd_ms"])
     assert cfg["views"]["count"] == 20 and cfg["views"]["cameras_of_rank0"][:3] == [3, 8, 13]      # the steps cycle through the view set
     if exchange == "auto":
-        assert set(cfg["exchange_autotune_ms"]) == {"reduce-scatter", "all-to-all", "all-reduce"}
+        assert set(cfg["exchange_autotune_ms"]) == {"reduce-scatter", "all-to-all", "all-reduce", "pipelined"}
 
 
 @pytest.mark.timeout(600)
@@ -64,7 +65,7 @@ def test_two_rank_strong_scaling_bench_on_one_gpu():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("exchange", ["reduce-scatter", "all-to-all", "all-reduce"])
+@pytest.mark.parametrize("exchange", ["reduce-scatter", "all-to-all", "all-reduce", "pipelined"])
 def test_two_ranks_equal_one_process(exchange):
     """4 optimiser steps of the 2-rank job (one camera per rank, gradient exchange, sharded / replicated fused Adam) land
     on the parameters of ONE process that accumulates both cameras' gradients before each step -- up to the float

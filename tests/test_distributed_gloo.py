@@ -195,10 +195,12 @@ def _sharded_worker(rank, world, port, results):
             for k, per_rank in enumerate(grads):
                 _CpuOps.store_gradient(rws, sum(per_rank[1:], per_rank[0]), layout)
                 _CpuOps.grid_adam_step_(None, rd, rf, layout, rws, k + 1, 0.05, rm[0], rm[1])
-        for exchange in ("reduce-scatter", "all-to-all", "all-reduce", "auto"):
+        for exchange in ("reduce-scatter", "all-to-all", "all-reduce", "pipelined", "pipelined-3", "auto"):
             d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
-            opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps,
-                                           exchange="reduce-scatter" if exchange == "auto" else exchange)
+            # r06: the chunked, software-pipelined direct exchange (4 sub-slabs per rank by default; 3: sub-slabs that do not
+            # divide a slab's planes, empty sub-slabs where a slab has fewer planes than chunks)
+            opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps, chunks=3 if exchange == "pipelined-3" else 4,
+                                           exchange="reduce-scatter" if exchange == "auto" else exchange.split("-3")[0])
             if exchange == "auto":
                 ws.packed.copy_(torch.cat((f, d), dim=-1).reshape(-1))
                 ws.grad.fill_(123.0)                       # autotune clears the region itself
@@ -223,6 +225,8 @@ def _sharded_worker(rank, world, port, results):
             assert opt.exchange_steps == len(grads) and opt.read_exchange_ms() == 0.0      # (CPU tensors: no device timing)
             if exchange == "all-reduce":
                 assert opt.mode.startswith("all-reduce")
+            if exchange.startswith("pipelined"):
+                assert opt.mode.startswith("pipelined direct exchange"), opt.mode
         d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
         opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps)
         for per_rank in grads:
@@ -247,7 +251,7 @@ def _sharded_worker(rank, world, port, results):
             # "reduce-scatter" and "all-to-all" only once when they are the same code path
             d, f, ws = dens0.clone(), feat0.clone(), _CpuWorkspace(X, Y, Z, C)
             opt = parallel.ShardedGridAdam(None, d, f, lr=0.05, backend=_CpuOps)
-            opt.supported = {"reduce-scatter": True, "all-to-all": False, "all-reduce": True}
+            opt.supported = {"reduce-scatter": True, "all-to-all": False, "all-reduce": True, "pipelined": False}
             for per_rank in grads:
                 _CpuOps.store_gradient(ws, per_rank[rank], layout)
                 opt.step(ws, layout)
@@ -261,7 +265,7 @@ def _sharded_worker(rank, world, port, results):
     assert modes["linear"].startswith("reduce-scatter") and modes["bricked"].startswith("reduce-scatter")
     assert modes["bricked_odd_x"].startswith("all-to-all (uneven slabs)")    # e.g. 6 x-planes = 3 brick pairs on 2 ranks
     assert modes["indivisible"].startswith("all-to-all (uneven slabs)")
-    assert opt.probe_exchanges() == {"reduce-scatter": True, "all-to-all": True, "all-reduce": True}
+    assert opt.probe_exchanges() == {"reduce-scatter": True, "all-to-all": True, "all-reduce": True, "pipelined": True}
     results[rank] = True
     dist.destroy_process_group()
 

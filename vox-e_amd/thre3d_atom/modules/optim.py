@@ -236,6 +236,14 @@ class FusedGridAdam(torch.optim.Optimizer):
             raise RuntimeError("attention_refinement_step after detach()")
         if d.dirty:
             raise RuntimeError("attention_refinement_step: an accumulated render gradient is waiting for step()")
+        #  the library call does not go through Optimizer.step(): step hooks are not invoked, and an autograd gradient
+        # a caller left on the attention tensor (an extra regulariser) would be silently ignored -- refuse it instead; the same
+        # for a request the library would only turn down AFTER the error path below has invalidated the workspace
+        if self._feat.grad is not None:
+            raise RuntimeError("attention_refinement_step: the attention tensor carries an autograd .grad (an extra loss term?): the fused "
+                               "call would ignore it -- use render + loss.backward() + step(), or clear the gradient first")
+        if getattr(render_params, "deterministic", False):
+            raise RuntimeError("attention_refinement_step: voxe_attn_refine_step has no deterministic mode (render_params.deterministic)")
         group = self.param_groups[0]
         beta1, beta2 = group["betas"]
         st = self._state_of(self._feat)

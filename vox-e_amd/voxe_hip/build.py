@@ -57,8 +57,12 @@ def _newer(target: str, deps) -> bool:
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
-    os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(INCLUDE, "voxe.h"), os.path.abspath(__file__)]
+    # the library is newer than every source it is made of: nothing to do, whether or not the object files are at hand (they do
+    # not travel to the GPU box: .gpurunignore)
+    if not force and not extra_flags and _newer(LIB, [os.path.join(CSRC, s) for s in SOURCES] + hdrs):
+        return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
     objs = []
     todo = []
     for src in SOURCES:
