@@ -109,6 +109,10 @@ typedef struct VoxeDispatch {
                                   and backward of one render must agree on it (the forward saves the segment states).       */
   int32_t region_lds_ranks;    /* ABI v9.  Space-binned route, segment pass: 0 = segments are ranked per block in an LDS table
                                   (no global atomic; grids up to ~200^3) | -1 one returning global atomic per segment (r02)   */
+  int32_t tile_phases;         /* ABI v11.  SH-0 image-ordered backward, tiles that do not fit the window and run as 2 / 4 parts:
+                                  0 = the lanes outside a part take the other SAMPLE PHASES of the part's rays (32 rays x 2
+                                  consecutive samples, 16 rays x 4: every wave instruction works on 64 lanes) | -1 = one
+                                  sample per ray and iteration, the other lanes idle (r05)                                    */
 } VoxeDispatch;
 
 typedef struct VoxeRenderCfg {

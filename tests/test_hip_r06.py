@@ -197,3 +197,36 @@ def test_wide_texels_refuse_the_in_step_feature_term_and_the_trainer_falls_back(
     loss.backward()
     ref_loss, ref_grad = vo.feature_correlation_fwd_bwd(gh.n(fr), gh.n(fr) * 0 + gh.n(fr))   # (shape check only: D = 0)
     assert ref_loss == 0.0 and fr.grad.shape == f.shape and torch.isfinite(fr.grad).all()
+
+
+# ---- r06: per-lane sample indices in the lean backward (skewed march of oblique tiles, sample phases of split tiles) ----------------
+@pytest.mark.parametrize("case", ["oblique_400px_like", "coarse_image_quadrants", "coarse_image_halves", "z_march_pairs", "term_eps",
+                                  "depth_and_acc_gradients", "odd_image_side"])
+def test_skewed_and_phased_march_vs_oracle_and_the_one_sample_march(case, disp):
+    """VoxeDispatch::tile_phases (ABI v11): lanes of a wave at DIFFERENT samples of their rays -- shifted by the layers a ray is
+    ahead of the pass's reference ray (oblique views), and, in the parts of a tile that does not fit the window, 2 / 4 consecutive
+    samples of one ray in 2 / 4 lanes (transmittance and running sum exchanged between them).  Against the oracle (accumulate.py:
+    49-84, the backward of SURVEY 8(a16)) and against the r05 march (tile_phases = -1): same gradients to float summation order."""
+    side, hw, cam, S, kl = {"oblique_400px_like": (64, 160, 12, 128, 8), "coarse_image_quadrants": (96, 56, 3, 96, 0),
+                            "coarse_image_halves": (72, 72, 58, 96, 8), "z_march_pairs": (64, 160, 0, 128, 8),
+                            "term_eps": (64, 120, 88, 96, 8), "depth_and_acc_gradients": (64, 136, 38, 112, 8),
+                            "odd_image_side": (80, 75, 12, 96, 0)}[case]
+    grid = _grid(side, seed=21, scale=3.0 * side / 32)
+    o, d = _rays(hw, cam)
+    cfg = make_render_cfg(S, NEAR, FAR, perturb=True, white_bkgd=True, seed=9, rng_offset=4,
+                          term_eps=1e-3 if case == "term_eps" else 0.0)
+    r = np.random.default_rng(5)
+    gc = r.standard_normal((o.shape[0], 3)).astype(np.float32)
+    gdep = (0.1 * r.standard_normal(o.shape[0])).astype(np.float32) if case == "depth_and_acc_gradients" else None
+    gacc = (0.1 * r.standard_normal(o.shape[0])).astype(np.float32) if case == "depth_and_acc_gradients" else None
+    disp.set(tile_min_rays=-1, tile_kl=kl)
+    new = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, g_acc=gacc, rng=(9, 4), image_width=hw)
+    disp.set(tile_min_rays=-1, tile_kl=kl, tile_phases=-1)
+    old = gh.hip_backward(grid, cfg, o, d, gc, g_depth=gdep, g_acc=gacc, rng=(9, 4), image_width=hw)
+    # (term_eps: a phased pass truncates a ray behind the wave's 2 / 4 samples, the one-sample march behind the sample itself: the
+    #  gradients of up to 3 samples at T < 1e-3 differ)
+    tol = 2e-3 if case == "term_eps" else 5e-6
+    assert rel_l2(new[0], old[0]) < tol and rel_l2(new[1], old[1]) < tol, (rel_l2(new[0], old[0]), rel_l2(new[1], old[1]))
+    if case != "term_eps":      # (the truncation is not in the reference: the two marches are compared with each other only)
+        rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, d_acc=gacc)
+        assert rel_l2(new[0], rd) < 1e-4 and rel_l2(new[1], rf) < 1e-4, (rel_l2(new[0], rd), rel_l2(new[1], rf))

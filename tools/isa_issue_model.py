@@ -85,10 +85,11 @@ def classify(op, operands, vcc_writer):
 
 
 def assembly(src_file):
-    out = f"/tmp/isa_issue_{os.path.basename(src_file)}.s"
+    extra = os.environ.get("ISA_EXTRA_FLAGS", "").split()          # (variants: -DVOXE_... experiments)
+    out = f"/tmp/isa_issue_{os.path.basename(src_file)}{'_' + str(abs(hash(tuple(extra))) % 100000) if extra else ''}.s"
     src = os.path.join(b.CSRC, src_file)
     if not (os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(os.path.join(b.CSRC, f)) for f in os.listdir(b.CSRC))):
-        subprocess.check_call([b.hipcc(), *b.FLAGS, "-I", b.INCLUDE, "-S", "--cuda-device-only", src, "-o", out],
+        subprocess.check_call([b.hipcc(), *b.FLAGS, *extra, "-I", b.INCLUDE, "-S", "--cuda-device-only", src, "-o", out],
                               stderr=subprocess.DEVNULL)
     return open(out).read()
 

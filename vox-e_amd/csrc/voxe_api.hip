@@ -204,7 +204,7 @@ struct FwdStamp {
   float near_, far_, density_scale, lo[3], hi[3];
   // the dispatch fields (VoxeDispatch, field by field: the struct's padding is the caller's)
   int64_t d_tile_min_rays, d_region_min_rays;
-  int32_t d_bwd_mode, d_tile_map, d_two_phase, d_qsplit, d_kl, d_fwd_window, d_fwd_spt, d_lean, d_precise, d_lds_ranks;
+  int32_t d_bwd_mode, d_tile_map, d_two_phase, d_qsplit, d_kl, d_fwd_window, d_fwd_spt, d_lean, d_precise, d_lds_ranks, d_phases;
   float d_fit_m, d_fit_lat, d_ffit_lat, d_ffit_m, d_zdom, d_max_adv, d_image_ratio;
 };
 FwdStamp make_stamp(const VoxeGridDesc* g, const VoxeRenderCfg* c, const float* rays_o, const float* rays_d, int64_t R,
@@ -224,7 +224,7 @@ FwdStamp make_stamp(const VoxeGridDesc* g, const VoxeRenderCfg* c, const float* 
   const VoxeDispatch& d = disp_of(c);
   k.d_tile_min_rays = d.tile_min_rays; k.d_region_min_rays = d.region_min_rays; k.d_bwd_mode = d.bwd_mode; k.d_tile_map = d.tile_map;
   k.d_two_phase = d.tile_two_phase; k.d_qsplit = d.tile_qsplit; k.d_kl = d.tile_kl; k.d_fwd_window = d.fwd_window;
-  k.d_fwd_spt = d.fwd_segments_per_thread; k.d_lean = d.tile_lean; k.d_precise = d.precise_grad; k.d_lds_ranks = d.region_lds_ranks;
+  k.d_fwd_spt = d.fwd_segments_per_thread; k.d_lean = d.tile_lean; k.d_precise = d.precise_grad; k.d_lds_ranks = d.region_lds_ranks; k.d_phases = d.tile_phases;
   k.d_fit_m = d.tile_fit_m; k.d_fit_lat = d.tile_fit_lat; k.d_ffit_lat = d.fwd_fit_lat; k.d_ffit_m = d.fwd_fit_m; k.d_zdom = d.fwd_zdom;
   k.d_max_adv = d.fwd_max_adv; k.d_image_ratio = d.region_image_ratio;
   return k;

@@ -43,6 +43,16 @@ namespace voxe {
 #define VOXE_T4_EXP 0     // timing experiments, WRONG RESULTS by construction (tools/variants.py): 1 every lane gathers the same texels |
                           // 2 no LDS adds (products kept) | 4 no flush | 8 flush without the global atomics | 16 no deposit at all
 #endif
+#ifndef VOXE_T4_SKEW
+#define VOXE_T4_SKEW 0    // r06: per-lane sample shift of oblique tiles (bwd4_march, LK): measured, NOT shipped -- the extra march variant pushes the
+                          // whole kernel over its register budget (profiles/r06_phases_skew.txt)
+#endif
+#ifndef VOXE_T4_CHJ
+#define VOXE_T4_CHJ 1     // r06: b-parity bit folded into the b term per sample (4 lane constants instead of 8)
+#endif
+#ifndef VOXE_T4_REMAT
+#define VOXE_T4_REMAT 0   // r06 experiment: the deposit's lane constants re-derived from the lane index per sample instead of living in ~14 VGPRs
+#endif
 #ifndef VOXE_T4_DEBUG
 #define VOXE_T4_DEBUG 0   // debugging builds (tools/variants.py): 1 every sample through the per-corner path | 2 ... and no corner in the window
 #endif
@@ -53,6 +63,7 @@ struct Tile4Args {
   int qsplit;
   float fit_m, fit_lat;
   int want_d, want_f;
+  int phases;             // VoxeDispatch::tile_phases >= 0: parts of a split tile run 2 / 4 sample phases per ray (r06)
   const double* segsum;   // PREC kernels: the forward's segment-local sums in double (FwdArgs::segsum_d)
   // deposit passes of view-dependent grids (DEP kernels): the per-sample gradient sources of the source pass, channel groups of
   // the launch (group g = texel channels 4 g .. 4 g + 3), gradient channels in all, voxels of the grid.  `gpacked` is then the
@@ -171,12 +182,28 @@ __device__ __forceinline__ bool tile_lanes_down_columns(const DevGrid& g, const 
 // DEP (deposit pass of a view-dependent grid, r05): no gather, no activations, no ray state -- the sample's four gradient sources
 // come from the source pass's buffer (16 bytes per sample, coalesced), times this ray's basis values for the block's channel
 // group; the window, its flush and the march are the SH-0 kernel's with the texel stride of the wide grid (`a.tex_bytes`).
-template <int MA, int KL, bool PREC, bool DEP>
+// NP (r06): SAMPLE PHASES per ray.  A tile whose footprint outgrows the window runs as 2 or 4 parts of 32 / 16 rays; with NP = 1
+// the other lanes of those passes idle (every VALU / LDS instruction of the pass costs what a full wave's costs).  With NP = 2 / 4
+// the lanes outside the part take the other phases of the part's rays: lane (ray, phase p) is at sample kb + p while the wave is
+// at kb, kb advances by NP.  Everything per sample is per lane as before (depth, footprint, gather, activation, deposit); what
+// chains the samples of a ray -- the transmittance T and the running sum of dL/dw w -- is carried per ray as the value IN
+// FRONT OF the wave's NP samples, and the NP lanes of a ray exchange (1 - alpha) and dL/dw w through the LDS crossbar
+// (ds_bpermute: xor masks xm1 / xm2 of the part's lane bits) and apply them in sample order -- the products and sums of the
+// one-sample-per-iteration march, in the same order.
+// LK (r06, "skew"): per-LANE sample index.  The lanes of a wave need not be at the same sample of their rays: nothing couples
+// different rays but the window, and the window wants the lanes in the same LAYERS.  A tile seen obliquely puts its rays several
+// layers apart at equal sample index (the reason such tiles ran as two passes of 32 lanes: "alongm > fit_m"); with a per-lane
+// shift `sh` -- the layers a ray is ahead of the pass's reference ray, rounded to samples -- lane l works on sample kb + koff,
+// koff = phase - sh, and the wave's footprint along the march axis is that of ONE ray (+ rounding) whatever the view.  The
+// strata then come through the LDS crossbar (the stratum index differs from lane to lane: no v_readlane).
+template <int MA, int KL, bool PREC, bool DEP, int NP = 1, bool LK = (NP > 1)>
 __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, const Tile4Args& a, RayCtx<3, 1, 1>& rc,
                                            double* __restrict__ win, int2* __restrict__ tab, const int lane, const long long r,
                                            bool has, const int k_lo, int k_hi, const int kmin, const int kmax, const int seg,
                                            const int ks, const Geo4 geo, const float strat_lo, const float strat_sp,
-                                           const DepCtx& dep) {
+                                           const DepCtx& dep, const int phase = 0, const int xm1 = 0, const int xm2 = 0, const int koff = 0) {
+  static_assert(!LK || (!PREC && !DEP), "per-lane sample indices (phases, skew): the SH-0 float kernel only");
+  static_assert(NP == 1 || LK, "sample phases need the per-lane sample index");
   constexpr int UA = (MA == 0) ? 1 : 0, VA = (MA == 2) ? 1 : 2;
   constexpr int COUT = 3;
   constexpr int kCtr = Lat<KL>::kCentre;
@@ -256,11 +283,22 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   const int crot = (lane & 1) | ((lane >> 3) & 2);
   const int k0u = 1 - hu, k1u = hu, k0v = 1 - hv, k1v = hv;      // the corner with parity h is (x + 1 - h) & ~1 | h
   const int KU0 = hu << 4, KU1 = (1 - hu) << 4;                  // byte offset of the a-parity bit
+#if VOXE_T4_CHJ
+  const int KV0 = hv << 3, KV1 = (1 - hv) << 3;                  // ... of the b-parity bit (r06: folded into the b term per sample --
+                                                                 // four adds -- instead of eight lane constants b-parity + channel)
+  int CHJ[4];                                                    // channel of instruction j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) CHJ[j] = ((j + crot) & 3) << 6;
+#define VOXE_CH(bv, j) CHJ[j]
+#else
+  const int KV0 = 0, KV1 = 0;
   int CH[2][4];                                                  // b-parity bit + channel of instruction j
 #pragma unroll
   for (int cv = 0; cv < 2; ++cv)
 #pragma unroll
     for (int j = 0; j < 4; ++j) CH[cv][j] = ((hv ^ cv) << 3) + (((j + crot) & 3) << 6);
+#define VOXE_CH(bv, j) CH[bv][j]
+#endif
   const bool c1 = crot & 1, c2 = crot & 2;
 
   // ---- window geometry -> per-layer table -----------------------------------------------------------------------------
@@ -284,7 +322,26 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
     const float su = sp * jitter_uniform(rc.dg.base, k);
     return lo + su;
   };
-  // first sample of every ray (rolling: z_cur / fp always describe sample max(k, k_lo))
+  // (LK) depth of this LANE's sample k: the stratum comes through the LDS crossbar (lane j of the wave holds sample ks + j's);
+  // call with all 64 lanes active
+  auto depth_lane = [&](int k) {
+    const int j = (k - ks) & 63;
+    const float lo = __shfl(strat_lo, j, 64), sp = __shfl(strat_sp, j, 64);
+    const float su = sp * jitter_uniform(rc.dg.base, k);
+    return lo + su;
+  };
+  // first sample of every ray (rolling: z_cur / fp always describe sample max(k, k_lo)); NP > 1: of every lane -- the first
+  // sample >= k_lo of this lane's phase (samples kmin + phase, kmin + phase + NP, ...)
+  int kf = k_lo;
+  int kb0 = kmin, kb1 = kmax;          // range of the wave's loop variable
+  if constexpr (LK) {
+    // lane l is at sample kb + koff: the loop starts where the first lane has a sample and ends behind the last one's
+    kb0 = wave_min_i32(has ? k_lo - koff : INT_MAX);
+    kb1 = wave_max_i32(has ? k_hi - koff : -(1 << 30));
+    const int m = (kb0 + koff - k_lo) % NP;      // this lane's samples: k = kb0 + koff (mod NP)
+    kf = k_lo + (m < 0 ? m + NP : m);
+    if (kf > k_hi) has = false;
+  }
   float z_cur = 0.0f;
   Footprint fp;
   fp.inside = false;
@@ -292,8 +349,8 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = 0; fp.w[ax][0] = fp.w[ax][1] = 0.0f; }
   int nextkey = INT_MAX;      // lowest layer key this lane's NEXT sample can write (INT_MAX: no sample left)
   if (has) {   // (the first sample index differs from lane to lane: its stratum is evaluated per lane, DepthGen's expressions)
-    const float2 st0 = depth_stratum(rc.dg, k_lo);
-    const float su0 = st0.y * jitter_uniform(rc.dg.base, k_lo);
+    const float2 st0 = depth_stratum(rc.dg, kf);
+    const float su0 = st0.y * jitter_uniform(rc.dg.base, kf);
     z_cur = st0.x + su0;
     float p[3];
     rc.point(z_cur, p);
@@ -457,9 +514,15 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
   const int nk0 = -key0;   // (re-based with the table)
   int nkey0 = nk0;
 
-  for (int k = kmin; k <= kmax; ++k) {
+  for (int kb = kb0; kb <= kb1; kb += NP) {
+    const int k = LK ? kb + koff : kb;
     const bool on = has && (k >= k_lo) && (k <= k_hi);
     const bool live = on && fp.inside;
+    float z_n1 = 0.0f, z_nP = 0.0f;      // (NP > 1) depths of this lane's samples k + 1 (the interval) and k + NP (its next sample)
+    if constexpr (LK) {
+      z_n1 = depth_lane(k + 1);
+      z_nP = (NP > 1) ? depth_lane(k + NP) : z_n1;
+    }
     // ---- phase 1: the cell of this sample, its 8 texel loads and the two window-table reads go out -- in STRAIGHT-LINE code,
     // executed by every lane (lanes without a sample gather texel 0 and read table entry 0): the compiler's wait-count pass is
     // not path sensitive, loads issued under one `if` and consumed under a later one leave it with "possibly outstanding" at
@@ -507,10 +570,192 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
     // AFTER this sample's texels are in: vmcnt counts in order, so loads behind an atomic would wait for it, and atomics issued
     // between the loads and their use make the wait-count pass wait for the atomics as well (they sit in conditional blocks).
     flush_consume();
+    // the deposit of one sample (this lane's cell, table entries and gradient channels) into the LDS window; a lambda so that the
+    // one-sample march and the phased march (NP > 1) share the text
+    auto do_deposit = [&](const float (&gch)[4]) __attribute__((always_inline)) {
+#if VOXE_T4_REMAT
+      int ln = lane;
+      asm volatile("" : "+v"(ln));     // (opaque: the derivations below must not be hoisted out of the sample loop)
+      const int hu = (ln >> 2) & 1, hv = (ln >> 3) & 1;
+      const int crot = (ln & 1) | ((ln >> 3) & 2);
+      const int k0u = 1 - hu, k1u = hu, k0v = 1 - hv, k1v = hv;
+      const int KU0 = hu << 4, KU1 = (1 - hu) << 4;
+      const int KV0 = hv << 3, KV1 = (1 - hv) << 3;
+      int CHJ[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) CHJ[j] = ((j + crot) & 3) << 6;
+      const bool c1 = crot & 1, c2 = crot & 2;
+#endif
+      // ---- the cell in (march, lateral u, lateral v) order ---------------------------------------------------------
+      const int pm = cell.i[MA], pu = cell.i[UA], pv = cell.i[VA];
+      const float wm0 = cell.w[MA][0], wm1 = cell.w[MA][1];
+      const float wu0 = cell.w[UA][0], wu1 = cell.w[UA][1], wv0 = cell.w[VA][0], wv1 = cell.w[VA][1];
+      // (the table entries stay packed until HERE: left alone the compiler derives the eight window coordinates right behind
+      //  the LDS reads of phase 1 and carries them -- eight registers for two -- across the whole per-sample math)
+      int eAx = eA.x, eBx = eB.x;
+      asm volatile("" : "+v"(eAx), "+v"(eBx));
+      const int ouA = (int)(short)(eAx & 0xffff), ovA = eAx >> 16, ouB = (int)(short)(eBx & 0xffff), ovB = eBx >> 16;
+      const int PU0 = pu + k0u, PU1 = pu + k1u, PV0 = pv + k0v, PV1 = pv + k1v;
+      const int xA0 = PU0 - ouA, xA1 = PU1 - ouA, yA0 = PV0 - ovA, yA1 = PV1 - ovA;   // {a, a + 1}, {b, b + 1} of layer A
+      const int xB0 = PU0 - ouB, xB1 = PU1 - ouB, yB0 = PV0 - ovB, yB1 = PV1 - ovB;
+      // window test: both layers inside the ring, every lateral coordinate inside [0, KL)
+      const int klrel = min(relA, relB);
+      bool fits = (unsigned)(klrel - (base + nkey0)) < (unsigned)(kRing - 1);   // (base - key0 <= 32: both entries are tabulated)
+      if constexpr (KL == 8) fits = fits && ((unsigned)(xA0 | xA1 | yA0 | yA1 | xB0 | xB1 | yB0 | yB1) < 8u);
+      else fits = fits && (max(max(max((unsigned)xA0, (unsigned)xA1), max((unsigned)yA0, (unsigned)yA1)),
+                               max(max((unsigned)xB0, (unsigned)xB1), max((unsigned)yB0, (unsigned)yB1))) < (unsigned)KL);
+      if (VOXE_T4_DEBUG & 3) fits = false;
+      if (fits) {
+        // weights in role order: x0 = weight of the corner with parity h (the low corner iff its coordinate has parity h)
+        const float wmA = tm ? wm1 : wm0, wmB = tm ? wm0 : wm1;
+        auto pick2 = [](int x1, float w0, float w1, float& o0, float& o1) {   // x1 = coordinate + h: odd <=> the HIGH corner has parity h
+          const bool hi = x1 & 1;
+          o0 = hi ? w1 : w0;
+          o1 = hi ? w0 : w1;
+        };
+        float wuA[2], wuB[2], wvA[2], wvB[2];
+        pick2(xA1, wu0, wu1, wuA[0], wuA[1]);
+        pick2(xB1, wu0, wu1, wuB[0], wuB[1]);
+        pick2(yA1, wv0, wv1, wvA[0], wvA[1]);
+        pick2(yB1, wv0, wv1, wvB[0], wvB[1]);
+        const float wmuA[2] = {wmA * wuA[0], wmA * wuA[1]}, wmuB[2] = {wmB * wuB[0], wmB * wuB[1]};
+        // byte addresses: slot term (table) + a term + b term + parity bits + channel
+        const int MA0 = eA.y + KU0, MA1 = eA.y + KU1, MB0 = eB.y + KU0, MB1 = eB.y + KU1;
+        const int muA[2] = {P::aterm(xA0 & ~1) + MA0, P::aterm(xA1 & ~1) + MA1};
+        const int muB[2] = {P::aterm(xB0 & ~1) + MB0, P::aterm(xB1 & ~1) + MB1};
+        const int bvA[2] = {P::bterm(yA0 & ~1) + KV0, P::bterm(yA1 & ~1) + KV1}, bvB[2] = {P::bterm(yB0 & ~1) + KV0, P::bterm(yB1 & ~1) + KV1};
+        // gr[j] = gch[(j + crot) & 3], as doubles
+        const float q0 = c1 ? gch[1] : gch[0], q1 = c1 ? gch[2] : gch[1], q2 = c1 ? gch[3] : gch[2], q3 = c1 ? gch[0] : gch[3];
+        const double gr[4] = {(double)(c2 ? q2 : q0), (double)(c2 ? q3 : q1), (double)(c2 ? q0 : q2), (double)(c2 ? q1 : q3)};
+        char* const wb = reinterpret_cast<char*>(win);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;   // compile-time bits of this instruction
+          const double wgt = (double)((bm ? wmuB[bu] : wmuA[bu]) * (bm ? wvB[bv] : wvA[bv]));
+          const int idx = (bm ? muB[bu] : muA[bu]) + (bm ? bvB[bv] : bvA[bv]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (VOXE_T4_EXP & 2) { const double pr = gr[j] * wgt; const int ad = idx + VOXE_CH(bv, j); asm volatile("" ::"v"(pr), "v"(ad)); continue; }
+            __hip_atomic_fetch_add(reinterpret_cast<double*>(wb + (idx + VOXE_CH(bv, j))), gr[j] * wgt, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      } else {
+        // Some corner outside the window (oblique tile borders, ring overflow, grid faces): per corner, in natural order --
+        // inside the window the LDS add (bank conflicts do not matter here), else a global float atomic.
+        const int brel = base + nkey0;
+        const int2 e0 = tm ? eB : eA, e1 = tm ? eA : eB;                    // table entries of layers pm, pm + 1
+        const int rel0 = tm ? relB : relA, rel1 = tm ? relA : relB;
+        const unsigned vo = (unsigned)(pm * stride_m + pu * stride_u + pv * stride_v) * TB;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
+          const float wgt = ((cm ? wm1 : wm0) * (cu ? wu1 : wu0)) * (cv ? wv1 : wv0);
+          if (wgt != 0.0f) {
+            const int2 es = cm ? e1 : e0;
+            const int aa = pu + cu - (int)(short)(es.x & 0xffff), bb = pv + cv - (es.x >> 16);
+            const bool inwin = !(VOXE_T4_DEBUG & 2) && ((unsigned)((cm ? rel1 : rel0) - brel) < (unsigned)kRing) &&
+                               ((unsigned)aa < (unsigned)KL) && ((unsigned)bb < (unsigned)KL);
+            if (inwin) {
+              double* const wp = reinterpret_cast<double*>(reinterpret_cast<char*>(win) +
+                                                           (es.y + (aa >> 1) * P::SA + ((aa & 1) << 4) + (bb >> 1) * P::SB + ((bb & 1) << 3)));
+#pragma unroll
+              for (int ch = 0; ch < 4; ++ch)
+                __hip_atomic_fetch_add(wp + ch * 8, (double)(gch[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              float* const gp = reinterpret_cast<float*>(gbytes + (size_t)(vo + (unsigned)(cm * stride_m + cu * stride_u + cv * stride_v) * TB));
+#pragma unroll
+              for (int ch = 0; ch < 4; ++ch)
+                atomicAdd(gp + ch, gch[ch] * wgt);
+            }
+          }
+        }
+      }
+    };
+    if constexpr (NP > 1) {
+      // ---- stage A (lanes with a live sample): everything of the sample that does not need the transmittance ---------------
+      const float z = z_cur;
+      const bool last = (k == Sm1);
+      const bool act = on && fp.inside;
+      float om = 1.0f, alpha = 0.0f, dldw = 0.0f, de = 0.0f, dpost = 0.0f, c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+      if (act) {
+        const float rad[COUT] = {kC0 * f0, kC0 * f1, kC0 * f2};
+        float sigma;
+        post_activate_vg(g.post_act, v, sigma, dpost);
+        const float dl = last ? kInfinity : (z_n1 - z);
+        const float delta = dl * rc.dnorm;
+        const float e = fast_exp(-(sigma * delta));
+        alpha = 1.0f - e;
+        om = 1.0f - alpha;
+        de = delta * e;
+        c0 = sigmoidf(rad[0]); c1 = sigmoidf(rad[1]); c2 = sigmoidf(rad[2]);
+        dldw = fmaf(gdep, z, gacc);
+        dldw = fmaf(gc[0], c0, dldw); dldw = fmaf(gc[1], c1, dldw); dldw = fmaf(gc[2], c2, dldw);
+        dldw -= gsumw;
+      }
+      // ---- stage B (all 64 lanes): the NP samples of a ray, in sample order ------------------------------------------------
+      // value of phase q of this lane's ray: own for q == phase, else the partner lane's (phase ^ q: xor of the part's lane bits)
+      auto of_phase = [&](float own, float (&out)[NP]) __attribute__((always_inline)) {
+        if constexpr (NP == 1) { out[0] = own; return; }
+        const float s1 = __shfl_xor(own, xm1, 64);
+        float s2 = 0.0f, s3 = 0.0f;
+        if constexpr (NP == 4) { s2 = __shfl_xor(own, xm2, 64); s3 = __shfl_xor(own, xm1 ^ xm2, 64); }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int x = phase ^ q;
+          out[q] = (x == 0) ? own : ((x == 1) ? s1 : ((x == 2) ? s2 : s3));
+        }
+      };
+      float omv[NP], dlv[NP], wkv[NP];
+      of_phase(om, omv);
+      float Tk = T, Tn = T;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        if (q < phase) Tk = Tk * omv[q];
+        Tn = Tn * omv[q];
+      }
+      const float wk = alpha * Tk;
+      // the running sum of dL/dw w in sample order, one fused multiply-add per sample like the one-sample march (lanes without a
+      // live sample contribute dL/dw = 0: fma(0, w, run) = run)
+      of_phase(dldw, dlv);
+      of_phase(wk, wkv);
+      float run_k = run, run_n = run;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        run_n = fmaf(dlv[q], wkv[q], run_n);
+        if (q == phase) run_k = run_n;
+      }
+      T = Tn;
+      run = run_n;
+      // ---- stage C: the sample's gradient channels and their deposit ------------------------------------------------------
+      if (act) {
+        const float suffix = last ? 0.0f : (suffix0 - run_k);
+        const float tail = (om > 0.0f) ? suffix * fast_rcp(om) : 0.0f;
+        const float dsig = de * fmaf(Tk, dldw, -tail);
+        float gch[4];
+        gch[0] = ((wk * gcf[0]) * (c0 * (1.0f - c0))) * kC0;
+        gch[1] = ((wk * gcf[1]) * (c1 * (1.0f - c1))) * kC0;
+        gch[2] = ((wk * gcf[2]) * (c2 * (1.0f - c2))) * kC0;
+        gch[3] = (dsig * dpost) * dmask;
+        if (!(VOXE_T4_EXP & 16) && (wk != 0.0f || gch[3] != 0.0f)) do_deposit(gch);
+      }
+      if (term_eps > 0.0f && Tn < term_eps && k <= k_hi) k_hi = k;   // gradient truncation (not in the reference): per ray, behind the wave's NP samples
+      // ---- this lane's next sample: k + NP --------------------------------------------------------------------------------
+      if (on) {
+        nextkey = INT_MAX;
+        if (k + NP <= k_hi) {
+          float pn[3];
+          rc.point(z_nP, pn);
+          footprint(g, pn, fp);
+          z_cur = z_nP;
+          nextkey = fp.i0[MA] ^ smask;
+        }
+      }
+    } else {
     if (on) {
       const float z = z_cur;
-      const bool last = (k == Sm1);        // wave-uniform
-      const float z_next = last ? z : depth_of(k + 1);
+      const bool last = (k == Sm1);        // wave-uniform (LK: per lane)
+      const float z_next = last ? z : (LK ? z_n1 : depth_of(k + 1));
       if (fp.inside) {
         float gch[4];
         bool deposit;
@@ -564,93 +809,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
         deposit = wk != 0.0f || gch[3] != 0.0f;
         }
 
-        if (!(VOXE_T4_EXP & 16) && deposit) {
-          // ---- the cell in (march, lateral u, lateral v) order ---------------------------------------------------------
-          const int pm = cell.i[MA], pu = cell.i[UA], pv = cell.i[VA];
-          const float wm0 = cell.w[MA][0], wm1 = cell.w[MA][1];
-          const float wu0 = cell.w[UA][0], wu1 = cell.w[UA][1], wv0 = cell.w[VA][0], wv1 = cell.w[VA][1];
-          // (the table entries stay packed until HERE: left alone the compiler derives the eight window coordinates right behind
-          //  the LDS reads of phase 1 and carries them -- eight registers for two -- across the whole per-sample math)
-          int eAx = eA.x, eBx = eB.x;
-          asm volatile("" : "+v"(eAx), "+v"(eBx));
-          const int ouA = (int)(short)(eAx & 0xffff), ovA = eAx >> 16, ouB = (int)(short)(eBx & 0xffff), ovB = eBx >> 16;
-          const int PU0 = pu + k0u, PU1 = pu + k1u, PV0 = pv + k0v, PV1 = pv + k1v;
-          const int xA0 = PU0 - ouA, xA1 = PU1 - ouA, yA0 = PV0 - ovA, yA1 = PV1 - ovA;   // {a, a + 1}, {b, b + 1} of layer A
-          const int xB0 = PU0 - ouB, xB1 = PU1 - ouB, yB0 = PV0 - ovB, yB1 = PV1 - ovB;
-          // window test: both layers inside the ring, every lateral coordinate inside [0, KL)
-          const int klrel = min(relA, relB);
-          bool fits = (unsigned)(klrel - (base + nkey0)) < (unsigned)(kRing - 1);   // (base - key0 <= 32: both entries are tabulated)
-          if constexpr (KL == 8) fits = fits && ((unsigned)(xA0 | xA1 | yA0 | yA1 | xB0 | xB1 | yB0 | yB1) < 8u);
-          else fits = fits && (max(max(max((unsigned)xA0, (unsigned)xA1), max((unsigned)yA0, (unsigned)yA1)),
-                                   max(max((unsigned)xB0, (unsigned)xB1), max((unsigned)yB0, (unsigned)yB1))) < (unsigned)KL);
-          if (VOXE_T4_DEBUG & 3) fits = false;
-          if (fits) {
-            // weights in role order: x0 = weight of the corner with parity h (the low corner iff its coordinate has parity h)
-            const float wmA = tm ? wm1 : wm0, wmB = tm ? wm0 : wm1;
-            auto pick2 = [](int x1, float w0, float w1, float& o0, float& o1) {   // x1 = coordinate + h: odd <=> the HIGH corner has parity h
-              const bool hi = x1 & 1;
-              o0 = hi ? w1 : w0;
-              o1 = hi ? w0 : w1;
-            };
-            float wuA[2], wuB[2], wvA[2], wvB[2];
-            pick2(xA1, wu0, wu1, wuA[0], wuA[1]);
-            pick2(xB1, wu0, wu1, wuB[0], wuB[1]);
-            pick2(yA1, wv0, wv1, wvA[0], wvA[1]);
-            pick2(yB1, wv0, wv1, wvB[0], wvB[1]);
-            const float wmuA[2] = {wmA * wuA[0], wmA * wuA[1]}, wmuB[2] = {wmB * wuB[0], wmB * wuB[1]};
-            // byte addresses: slot term (table) + a term + b term + parity bits + channel
-            const int MA0 = eA.y + KU0, MA1 = eA.y + KU1, MB0 = eB.y + KU0, MB1 = eB.y + KU1;
-            const int muA[2] = {P::aterm(xA0 & ~1) + MA0, P::aterm(xA1 & ~1) + MA1};
-            const int muB[2] = {P::aterm(xB0 & ~1) + MB0, P::aterm(xB1 & ~1) + MB1};
-            const int bvA[2] = {P::bterm(yA0 & ~1), P::bterm(yA1 & ~1)}, bvB[2] = {P::bterm(yB0 & ~1), P::bterm(yB1 & ~1)};
-            // gr[j] = gch[(j + crot) & 3], as doubles
-            const float q0 = c1 ? gch[1] : gch[0], q1 = c1 ? gch[2] : gch[1], q2 = c1 ? gch[3] : gch[2], q3 = c1 ? gch[0] : gch[3];
-            const double gr[4] = {(double)(c2 ? q2 : q0), (double)(c2 ? q3 : q1), (double)(c2 ? q0 : q2), (double)(c2 ? q1 : q3)};
-            char* const wb = reinterpret_cast<char*>(win);
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              const int bm = cc & 1, bu = (cc >> 1) & 1, bv = cc >> 2;   // compile-time bits of this instruction
-              const double wgt = (double)((bm ? wmuB[bu] : wmuA[bu]) * (bm ? wvB[bv] : wvA[bv]));
-              const int idx = (bm ? muB[bu] : muA[bu]) + (bm ? bvB[bv] : bvA[bv]);
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (VOXE_T4_EXP & 2) { const double pr = gr[j] * wgt; const int ad = idx + CH[bv][j]; asm volatile("" ::"v"(pr), "v"(ad)); continue; }
-                __hip_atomic_fetch_add(reinterpret_cast<double*>(wb + (idx + CH[bv][j])), gr[j] * wgt, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-              }
-            }
-          } else {
-            // Some corner outside the window (oblique tile borders, ring overflow, grid faces): per corner, in natural order --
-            // inside the window the LDS add (bank conflicts do not matter here), else a global float atomic.
-            const int brel = base + nkey0;
-            const int2 e0 = tm ? eB : eA, e1 = tm ? eA : eB;                    // table entries of layers pm, pm + 1
-            const int rel0 = tm ? relB : relA, rel1 = tm ? relA : relB;
-            const unsigned vo = (unsigned)(pm * stride_m + pu * stride_u + pv * stride_v) * TB;
-#pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-              const int cm = cc & 1, cu = (cc >> 1) & 1, cv = cc >> 2;
-              const float wgt = ((cm ? wm1 : wm0) * (cu ? wu1 : wu0)) * (cv ? wv1 : wv0);
-              if (wgt != 0.0f) {
-                const int2 es = cm ? e1 : e0;
-                const int aa = pu + cu - (int)(short)(es.x & 0xffff), bb = pv + cv - (es.x >> 16);
-                const bool inwin = !(VOXE_T4_DEBUG & 2) && ((unsigned)((cm ? rel1 : rel0) - brel) < (unsigned)kRing) &&
-                                   ((unsigned)aa < (unsigned)KL) && ((unsigned)bb < (unsigned)KL);
-                if (inwin) {
-                  double* const wp = reinterpret_cast<double*>(reinterpret_cast<char*>(win) +
-                                                               (es.y + (aa >> 1) * P::SA + ((aa & 1) << 4) + (bb >> 1) * P::SB + ((bb & 1) << 3)));
-#pragma unroll
-                  for (int ch = 0; ch < 4; ++ch)
-                    __hip_atomic_fetch_add(wp + ch * 8, (double)(gch[ch] * wgt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                  float* const gp = reinterpret_cast<float*>(gbytes + (size_t)(vo + (unsigned)(cm * stride_m + cu * stride_u + cv * stride_v) * TB));
-#pragma unroll
-                  for (int ch = 0; ch < 4; ++ch)
-                    atomicAdd(gp + ch, gch[ch] * wgt);
-                }
-              }
-            }
-          }
-        }
+        if (!(VOXE_T4_EXP & 16) && deposit) do_deposit(gch);
       }
       // ---- the next sample's footprint (after the deposit: nothing of it is live across the 32 LDS adds) -------------------
       nextkey = INT_MAX;
@@ -662,6 +821,7 @@ __device__ __forceinline__ void bwd4_march(const DevGrid& g, const DevCfg& c, co
         nextkey = fp.i0[MA] ^ smask;
       }
     }
+    }   // (NP == 1)
     // ---- slide the window: flush every layer no lane can reach any more -------------------------------------------------
     // (one compare per iteration: does ANY lane's next sample still reach layer `base`?)
     if (__ballot(nextkey <= base) == 0ull) {   // wave-uniform
@@ -727,6 +887,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
 #ifndef VOXE_T4_ORIENT
 #define VOXE_T4_ORIENT 1   // 0: lanes always along the pixel rows
 #endif
+  bool columns = false;           // lanes run down the image columns (wave-uniform)
   if (VOXE_T4_ORIENT && !DEP) {   // lanes along the image rows or down the columns (tile_lanes_down_columns): fewer cache lines per gather
                                   // (a deposit pass gathers nothing, and its lanes must sit where the source pass's did)
     const unsigned long long am0 = __ballot(alive);
@@ -735,6 +896,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
       const float dx[3] = {readlane_f32(rc.d[0], 1), readlane_f32(rc.d[1], 1), readlane_f32(rc.d[2], 1)};
       const float dy[3] = {readlane_f32(rc.d[0], 8), readlane_f32(rc.d[1], 8), readlane_f32(rc.d[2], 8)};
       if (tile_lanes_down_columns(g, d0, dx, dy)) {   // wave-uniform
+        columns = true;
         alive = tile_pixel_ray(c, ty, lane & 7, (tx << 3) + (lane >> 3), 8, r_px);
         r = alive ? r_px : 0;
         rc.init(g, c, r, a.rays_o, a.rays_d, nullptr);
@@ -760,14 +922,21 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
       }
       const int m = (d0[0] >= d0[1] && d0[0] >= d0[2]) ? 0 : ((d0[1] >= d0[2]) ? 1 : 2);
       const float fit_lat = a.fit_lat > 0.0f ? a.fit_lat : (float)KL - 2.5f;
+      // r06: with the per-lane sample shift of the skewed march (bwd4_march, LK) a pass's extent along the march axis is no
+      // constraint any more; what counts is its lateral extent at equal LAYER: sliding a ray back by its lead along m moves it
+      // sideways by lead x |d_lat / d_m|
+      const bool skew_ok = VOXE_T4_SKEW && !PREC && !DEP && a.phases >= 0;
       auto fits_pass = [&](float wx, float wy) {
-        float lat = 0.0f, alongm = 0.0f;
+        float e[3];
 #pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-          const float e = wx * ex3[ax] + wy * ey3[ax];
-          if (ax == m) alongm = e; else lat = fmaxf(lat, e);
-        }
-        return lat <= fit_lat && alongm <= a.fit_m;
+        for (int ax = 0; ax < 3; ++ax) e[ax] = wx * ex3[ax] + wy * ey3[ax];
+        const float alongm = (m == 0) ? e[0] : ((m == 1) ? e[1] : e[2]);
+        const float dm = (m == 0) ? d0[0] : ((m == 1) ? d0[1] : d0[2]);
+        float lat = 0.0f;
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax)
+          if (ax != m) lat = fmaxf(lat, skew_ok ? e[ax] + alongm * (d0[ax] / dm) : e[ax]);
+        return lat <= fit_lat && (skew_ok || alongm <= a.fit_m);
       };
       if (!fits_pass(7.0f, 7.0f)) {
         const bool hx = fits_pass(3.0f, 7.0f), hy = fits_pass(7.0f, 3.0f);
@@ -816,7 +985,10 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
     dep.src_base = ((long long)tile * nseg + seg) * c.seg_len * 64 + lane - (long long)ks * 64;
   }
 
-  auto run_pass = [&](const bool alive_q, const int centre_lane, const int centre_lane2) {
+  // PH (r06): sample phases per ray of this pass (1 | 2 | 4); phase / xm1 / xm2: this lane's phase and the xor masks between the
+  // lanes of one ray (bwd4_march)
+  auto run_pass = [&](const bool alive_q, const int centre_lane, const int centre_lane2, auto ph_tag, const int phase, const int xm1, const int xm2) {
+    constexpr int PH = decltype(ph_tag)::value;
     const int k_lo = max(rc.k_lo, ks);
     int k_hi = alive_q ? min(rc.k_hi, ke) : k_lo - 1;
     bool has = k_lo <= k_hi;
@@ -828,10 +1000,11 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
     if (kmin > kmax) return;  // wave-uniform: no ray of this pass meets the volume in this segment
     // ---- window geometry from the reference ray (render_bwd_tile_kernel) ----
     Geo4 geo;
-    int m;
+    int m, ref_lane;
     {
       const unsigned long long hmk = __ballot(has);
       const int ref = ((hmk >> centre_lane) & 1ull) ? centre_lane : (__ffsll((long long)hmk) - 1);
+      ref_lane = ref;
       const int ref2 = (VOXE_TILE_CENTRE2 && ref == centre_lane && ((hmk >> centre_lane2) & 1ull)) ? centre_lane2 : ref;
       const int N[3] = {g.X, g.Y, g.Z};
       float U0[3], DU[3];
@@ -854,9 +1027,45 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
       geo.Bu = DUu * inv; geo.Au = U0u - geo.Bu * U0m;
       geo.Bv = DUv * inv; geo.Av = U0v - geo.Bv * U0m;
     }
-    if (m == 0) bwd4_march<0, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep);
-    else if (m == 1) bwd4_march<1, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep);
-    else bwd4_march<2, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep);
+    // ---- skew (r06): how many samples is this lane's ray ahead of the reference ray along the march axis?  Position along m of
+    // a ray at depth z (voxel units): ((o + d z) scale + bias + 1) N / 2 - 1 / 2; evaluated at the middle of the segment; one
+    // sample advances the reference ray by |DU_m| dz layers (dz: the launch's sample spacing at that depth)
+    int sh = 0;
+    if constexpr (VOXE_T4_SKEW && !PREC && !DEP) {
+      if (a.phases >= 0 && has) {
+        const int kmid = (kmin + kmax) >> 1;
+        const float zmid = readlane_f32(rc.dg.zlin(kmid), ref_lane), zmid1 = readlane_f32(rc.dg.zlin(min(kmid + 1, c.S - 1)), ref_lane);
+        const float om_ = (m == 0) ? rc.o[0] : ((m == 1) ? rc.o[1] : rc.o[2]), dm_ = (m == 0) ? rc.d[0] : ((m == 1) ? rc.d[1] : rc.d[2]);
+        const float sc_ = (m == 0) ? g.scale[0] : ((m == 1) ? g.scale[1] : g.scale[2]);
+        const float half_ = 0.5f * (float)((m == 0) ? g.X : ((m == 1) ? g.Y : g.Z));
+        const float pos = (om_ + dm_ * zmid) * sc_ * half_;                   // (+ constants that cancel in the difference)
+        const float pos_ref = readlane_f32(pos, ref_lane);
+        const float per_sample = fabsf(readlane_f32(dm_, ref_lane) * sc_ * half_ * (zmid1 - zmid));
+        if (per_sample > 1e-6f) {
+          const float ahead = (float)geo.sgn * (pos - pos_ref) / per_sample;
+          sh = (int)rintf(fminf(fmaxf(ahead, -12.0f), 12.0f));
+        }
+      }
+    }
+    const bool skew = __ballot(sh != 0) != 0ull;     // wave-uniform
+#define VOXE_T4_MARCH(AX)                                                                                                           \
+    do {                                                                                                                            \
+      if constexpr (PH > 1)                                                                                                         \
+        bwd4_march<AX, KL, PREC, DEP, PH, true>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, \
+                                                strat_sp, dep, phase, xm1, xm2, phase - sh);                                   \
+      else if constexpr (VOXE_T4_SKEW && !PREC && !DEP) {                                                                           \
+        if (skew)                                                                                                                   \
+          bwd4_march<AX, KL, PREC, DEP, 1, true>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, \
+                                                 strat_sp, dep, 0, 0, 0, -sh);                                                      \
+        else                                                                                                                        \
+          bwd4_march<AX, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep); \
+      } else                                                                                                                        \
+        bwd4_march<AX, KL, PREC, DEP>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, strat_sp, dep); \
+    } while (0)
+    if (m == 0) VOXE_T4_MARCH(0);
+    else if (m == 1) VOXE_T4_MARCH(1);
+    else VOXE_T4_MARCH(2);
+#undef VOXE_T4_MARCH
   };
   auto in_part = [&](int q) {
     const int hx = (lane >> 2) & 1, hy = (lane >> 5) & 1;
@@ -871,8 +1080,31 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
   const int nparts = split == 0 ? 1 : (split == 3 ? 4 : 2);
   const int q_begin = a.qsplit == 4 ? quad : 0;
   const int q_end = a.qsplit == 4 ? min(quad + 1, nparts) : nparts;
+  // r06: the parts of a split tile with 2 / 4 sample phases per ray -- the lanes outside part q take the other phases of the
+  // part's rays (lane bits 2 / 5 say which part a lane's own pixel is in: xor-ing them with q gives the phase, forcing them to q
+  // the lane whose ray this lane works on)
+  constexpr bool kPhases = !PREC && !DEP;
+  if constexpr (kPhases) {
+   if (split != 0 && a.phases >= 0) {
+    const int bx = (lane >> 2) & 1, by = (lane >> 5) & 1;
+    for (int q = q_begin; q < q_end; ++q) {
+      int phase, rl, xm1, xm2 = 0;
+      if (split == 1) { phase = bx ^ q; rl = (lane & ~4) | (q << 2); xm1 = 4; }
+      else if (split == 2) { phase = by ^ q; rl = (lane & ~32) | (q << 5); xm1 = 32; }
+      else { phase = (bx ^ (q & 1)) | ((by ^ (q >> 1)) << 1); rl = (lane & ~36) | ((q & 1) << 2) | ((q >> 1) << 5); xm1 = 4; xm2 = 32; }
+      const bool alive_q = columns ? tile_pixel_ray(c, ty, rl & 7, (tx << 3) + (rl >> 3), 8, r_px)
+                                   : tile_pixel_ray(c, ty, rl >> 3, (tx << 3) + (rl & 7), 8, r_px);
+      r = alive_q ? r_px : 0;
+      rc.init(g, c, r, a.rays_o, a.rays_d, nullptr);
+      if (split == 3) run_pass(alive_q, centre_of(q), centre2_of(q), std::integral_constant<int, 4>(), phase, xm1, xm2);
+      else run_pass(alive_q, centre_of(q), centre2_of(q), std::integral_constant<int, 2>(), phase, xm1, xm2);
+      __syncthreads();
+    }
+    return;
+   }
+  }
   for (int q = q_begin; q < q_end; ++q) {
-    run_pass(alive && in_part(q), centre_of(q), centre2_of(q));
+    run_pass(alive && in_part(q), centre_of(q), centre2_of(q), std::integral_constant<int, 1>(), 0, 0, 0);
     __syncthreads();
   }
 }
@@ -1142,7 +1374,7 @@ void launch_bwd_tile4_dep(const DevGrid& g, const HostCfg& c, const BwdArgs& a, 
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
   t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.grad_planar;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = 1; t.want_f = 1;
-  t.segsum = nullptr;
+  t.segsum = nullptr; t.phases = -1;
   t.sample_src = reinterpret_cast<const float4*>(a.sample_src);
   const int cm = 3 * ncu + 1;
   t.ngrp = ngrp; t.ng = cm; t.nvox = (long long)g.X * g.Y * g.Z;
@@ -1162,7 +1394,7 @@ void launch_bwd_tile4(const DevGrid& g, const HostCfg& c, const BwdArgs& a, int 
   t.packed = a.packed; t.rays_o = a.rays_o; t.rays_d = a.rays_d; t.colour = a.colour; t.depth = a.depth; t.acc = a.acc;
   t.d_colour = a.d_colour; t.d_depth = a.d_depth; t.d_acc = a.d_acc; t.ray_state = a.ray_state; t.gpacked = a.gpacked;
   t.qsplit = qsplit; t.fit_m = fit_m; t.fit_lat = fit_lat; t.want_d = a.want_d ? 1 : 0; t.want_f = a.want_f ? 1 : 0;
-  t.segsum = a.segsum_d;
+  t.segsum = a.segsum_d; t.phases = c.disp.tile_phases;
   if (a.segsum_d) {   // VoxeDispatch::precise_grad
     if (kl == 10) render_bwd_tile4_kernel<10, true><<<nb, 64, 0, st>>>(g, c, t);
     else render_bwd_tile4_kernel<8, true><<<nb, 64, 0, st>>>(g, c, t);

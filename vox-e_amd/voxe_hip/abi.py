@@ -75,6 +75,7 @@ class VoxeDispatch(C.Structure):
         ("tile_lean", C.c_int32),
         ("precise_grad", C.c_int32),
         ("region_lds_ranks", C.c_int32),
+        ("tile_phases", C.c_int32),
     ]
 
 

@@ -45,6 +45,7 @@ class Dispatch:
     tile_lean: int = 0               # 0 lean SH-0 tile backward where it applies | -1 always the general kernel
     precise_grad: int = 0            # 0 float in-segment suffix sums | 1 double (image-ordered SH-0 backward)
     region_lds_ranks: int = 0        # 0 block-local LDS ranks in the space-binned segment pass | -1 global returning atomics
+    tile_phases: int = 0             # 0 split tiles run 2 / 4 sample phases per ray (full waves) | -1 one sample per ray, idle lanes
 
     def struct(self) -> abi.VoxeDispatch:
         return _struct_of(self)
@@ -119,6 +120,8 @@ def from_env() -> Dispatch:
         kw["precise_grad"] = 1
     if os.environ.get("VOXE_REGION_LDS_RANKS", "")[:1] == "0":
         kw["region_lds_ranks"] = -1
+    if os.environ.get("VOXE_TILE_PHASES", "")[:1] == "0":
+        kw["tile_phases"] = -1
     return Dispatch(**kw)
 
 
