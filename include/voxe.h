@@ -241,7 +241,17 @@ int voxe_random_subset(int64_t n, int64_t count, uint64_t seed, uint64_t rng_off
 /* Workspace: [packed grid | packed gradient | per-ray depth-segment states | segment partials | per-sample gradient
  * sources].  voxe_workspace_bytes() is the size that lets every kernel take its fast route; the forward needs only the
  * packed grid, and the backward needs everything but the last region (16 B per sample of image-ordered renders of SH
- * degree >= 1, capped at 4 GB): without it their gradient-channel groups re-march the rays instead of sharing one march. */
+ * degree >= 1, capped at 4 GB): without it their gradient-channel groups re-march the rays instead of sharing one march.
+ * What the optional regions cost, so that a caller can size its pools:
+ *   - view-dependent grids, image-ordered renders: besides the 2 x 16 B per sample above, the GROUP-PLANAR staging gradient of
+ *     the lean deposit passes, voxels x 16 B x ceil((F + 1) / 4) (262 MB for SH-1 at 160^3, ~850 MB for SH-3), cleared and
+ *     folded into the packed gradient on every such backward whatever the image size;
+ *   - unordered / sparse rays (space-binned route): segment tables + per-segment states, and for grids whose region table fits
+ *     LDS (up to ~200^3) the per-block rank tables of the segment pass, blocks x (regions + 1) x 24 B (blocks <= 1024: ~48 MB
+ *     at 160^3 for a 32 768-ray batch, ~120 MB at 160 000 rays), allocated whether or not VoxeDispatch::region_lds_ranks
+ *     takes that pass;
+ *   - VoxeDispatch::precise_grad: 5 doubles per (ray, depth segment); cfg->deterministic: 8 B per gradient value.
+ * cfg->ray_state_valid = -1 (inference) returns the size without any of these. */
 size_t voxe_workspace_bytes(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, int64_t R);
 
 int voxe_render_fwd(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg,
