@@ -50,6 +50,9 @@ namespace voxe {
 #ifndef VOXE_T4_CHJ
 #define VOXE_T4_CHJ 1     // r06: b-parity bit folded into the b term per sample (4 lane constants instead of 8)
 #endif
+#ifndef VOXE_T4_PHASE_MARGIN
+#define VOXE_T4_PHASE_MARGIN 0.0f   // layers added to fit_m in the "do this tile's parts leave room for sample phases" test
+#endif
 #ifndef VOXE_T4_REMAT
 #define VOXE_T4_REMAT 0   // r06 experiment: the deposit's lane constants re-derived from the lane index per sample instead of living in ~14 VGPRs
 #endif
@@ -906,6 +909,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
 
   // ---- does the 8x8 tile fit the lateral window?  (the split decision of render_bwd_tile_kernel) -------------------------
   int split = 0;
+  bool phases_fit = false;     // (r06) the parts of this tile leave room in the ring for 2 / 4 consecutive samples of a ray
   {
     const unsigned long long am = __ballot(alive);
     if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
@@ -943,6 +947,14 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
         const float sx = ex3[0] + ex3[1] + ex3[2], sy = ey3[0] + ey3[1] + ey3[2];
         if (hx && hy) split = (sx >= sy) ? 1 : 2;
         else split = hx ? 1 : (hy ? 2 : 3);
+        // sample phases (bwd4_march, NP) put NP consecutive samples of a ray into one wave iteration: the part's extent along the
+        // march axis grows by (NP - 1) x the layers a sample advances.  Only parts that still fit the ring run phased -- the others
+        // would send their samples down the per-corner global-atomic path (100x100, oblique views: 0.25 -> 0.34 ms, r06l)
+        const float pe = ((split == 2) ? 7.0f : 3.0f) * ((m == 0) ? ex3[0] : ((m == 1) ? ex3[1] : ex3[2])) +
+                         ((split == 1) ? 7.0f : 3.0f) * ((m == 0) ? ey3[0] : ((m == 1) ? ey3[1] : ey3[2]));
+        const float dzs = fabsf(zref - readlane_f32(rc.dg.zlin(max(ke - 1, 0)), 0));
+        const float per_sample = ((m == 0) ? d0[0] : ((m == 1) ? d0[1] : d0[2])) * dzs;
+        phases_fit = pe + (float)((split == 3) ? 3 : 1) * per_sample <= a.fit_m + VOXE_T4_PHASE_MARGIN;
       }
     }
   }
@@ -1085,7 +1097,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
   // the lane whose ray this lane works on)
   constexpr bool kPhases = !PREC && !DEP;
   if constexpr (kPhases) {
-   if (split != 0 && a.phases >= 0) {
+   if (split != 0 && a.phases >= 0 && phases_fit) {
     const int bx = (lane >> 2) & 1, by = (lane >> 5) & 1;
     for (int q = q_begin; q < q_end; ++q) {
       int phase, rl, xm1, xm2 = 0;
