@@ -23,7 +23,7 @@ timeout 300 python bench.py --image 266 --no-cpu-baseline --no-gpu-baseline 2>/d
 timeout 300 python bench.py --optimizer split --no-cpu-baseline --no-gpu-baseline 2>/dev/null | tail -1 > $O/bench_400_split_optimizer.json
 timeout 300 env VOXE_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-gpu-baseline --no-secondary 2>/dev/null | tail -1 > $O/bench_400_rccl_1rank.json
 # two ranks sharing the one GPU, exchanging through gloo: the N > 1 code path with the real kernels (correctness, not a measurement)
-for ex in reduce-scatter all-to-all all-reduce auto; do timeout 600 env VOXE_GRAD_EXCHANGE=$ex VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | tail -1; done > $O/two_ranks_one_gpu_gloo.jsonl
+for ex in reduce-scatter all-to-all all-reduce pipelined auto; do timeout 600 env VOXE_GRAD_EXCHANGE=$ex VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 2>/dev/null | tail -1; done > $O/two_ranks_one_gpu_gloo.jsonl
 # ... and the driver's N = 8 command line, eight ranks sharing the GPU
 timeout 600 env VOXE_GRAD_EXCHANGE=reduce-scatter VOXE_BENCH_BACKEND=gloo VOXE_BENCH_PRE_WARM_MS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 8 --steps 2 --warmup 1 2>/dev/null | tail -1 > $O/eight_ranks_one_gpu_gloo.json
 timeout 300 python tools/refine_bench.py 160 2>/dev/null | tail -4 > $O/refine_bench.txt; cat $O/refine_bench.txt
