@@ -486,3 +486,34 @@ def test_newest_pmc_summary_belongs_to_these_kernel_sources():
     key = [k for k in summary["kernels"] if k.startswith(("voxe::render_bwd_tile4_kernel<8, false, 0>",
                                                             "voxe::render_bwd_tile_kernel<3, 1, 1, true, true, 0, 8"))]
     assert key and {"FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE"} <= set(summary["kernels"][key[0]])
+
+
+def test_isa_issue_model_prices_instructions_like_the_microbenchmark():
+    """tools/isa_issue_model.py (r06): the class a VALU instruction is priced in follows profiles/r06_valu_rate.txt -- double rate only
+    for the plain f32 / integer forms WITHOUT an SGPR source, DPP or SDWA; v_cndmask_b32 behind a scalar write of vcc is the 22.8-clk
+    case; the committed profile names the two headline kernels with the sample loops found in their assembly"""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("isa_issue_model", os.path.join(ROOT, "tools", "isa_issue_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.classify("v_fma_f32", "v1, v2, v3, v4", "V") == "fast"
+    assert m.classify("v_fma_f32", "v1, v2, s20, v4", "V") == "slow"            # one SGPR source: 4.27 clk measured
+    assert m.classify("v_mul_f32_e32", "v1, 0x3f800000, v2", "V") == "fast"     # literals / inline constants stay double rate
+    assert m.classify("v_add_f32_dpp", "v1, v2, v3 row_shr:1 row_mask:0xf bank_mask:0xf", "V") == "slow"
+    assert m.classify("v_lshlrev_b32_e32", "v1, 4, v2", "V") == "slow" and m.classify("v_lshrrev_b32_e32", "v1, 4, v2", "V") == "fast"
+    assert m.classify("v_exp_f32_e32", "v1, v2", "V") == "trans" and m.classify("v_mul_f64", "v[0:1], v[2:3], v[4:5]", "V") == "slow"
+    assert m.classify("v_cndmask_b32_e32", "v1, v2, v3, vcc", "S") == "cnd_salu_vcc"
+    assert m.classify("v_cndmask_b32_e32", "v1, v2, v3, vcc", "V") == "slow"
+    assert m.classify("v_cndmask_b32_e64", "v1, v2, v3, s[4:5]", "S") == "slow"
+    assert m.pmc_class("v_mul_f64") == "MUL_F64" and m.pmc_class("v_cvt_f64_f32_e32") == "CVT" and m.pmc_class("v_exp_f32_e32") == "TRANS_F32"
+    assert m.pmc_class("v_fmac_f32_e32") == "FMA_F32" and m.pmc_class("v_and_b32_e32") == "OTHER"
+    blocks = m.price(m.blocks_of("k:\n.LBB0_1:\n\ts_and_b64 vcc, s[0:1], s[2:3]\n\tv_cndmask_b32_e32 v1, v2, v3, vcc\n\tv_cmp_lt_f32_e32 vcc, v1, v2\n"
+                                 "\tv_cndmask_b32_e32 v1, v2, v3, vcc\n\tv_fma_f32 v1, v1, v2, v3\n\ts_cbranch_scc1 .LBB0_1\n"))
+    assert dict(blocks[1]["cls"]) == {"cnd_salu_vcc": 1, "slow": 2, "fast": 1} and m.loops_of(blocks) == [(1, 1)]
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r06_issue_model.json")))
+    assert prof["cost_table_clk"] == m.COST
+    for key in ("voxe::render_bwd_tile4_kernel<8, false, 0>", "voxe::render_fwd_tile4_kernel<3, false>"):
+        k = prof["kernels"][key]
+        assert 2.15 < k["clk_per_valu"] < 4.3 and k["hot_loops"] and k["occupancy_waves_per_simd"] >= 3

@@ -38,6 +38,9 @@ timeout 300 python bench.py --scene sphere --term-eps 1e-4 --no-cpu-baseline --n
 timeout 300 env RECON_PYTHON_ITER=1 python tools/recon_bench.py 2>/dev/null | tail -6 > $O/recon_bench_python_iteration.txt
 for f in $O/bench_*.json; do echo "$f: $(python -c "import json,sys; d=json.load(open('$f')); print(round(d['value']/1e6,2),'Mrays/s', d['ms_per_step'],'ms', d['roofline']['phases_ms'])" 2>&1)"; done
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o $TAG -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --no-cpu-baseline --no-gpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_bench.log 2>&1
+# r06: the headline step alone (no secondary lines: every launch of the render kernels is a 400x400 view of the timed set), so that the
+# kernels' average durations can be held against the bench line's HIP-event times
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_headline -o ${TAG}_headline -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-secondary --no-cpu-baseline --no-gpu-baseline > $GRAFT_REPO_ROOT/$O/rocprof_headline.log 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_refine -o ${TAG}_refine -- python $GRAFT_REPO_ROOT/tools/refine_bench.py 160 > /dev/null 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_recon -o ${TAG}_recon -- python $GRAFT_REPO_ROOT/tools/recon_bench.py 20 > /dev/null 2>&1
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_grid -o ${TAG}_grid -- python $GRAFT_REPO_ROOT/tools/grid_pass_bench.py > /dev/null 2>&1
