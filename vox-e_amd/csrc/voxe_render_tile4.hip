@@ -44,8 +44,9 @@ namespace voxe {
                           // 2 no LDS adds (products kept) | 4 no flush | 8 flush without the global atomics | 16 no deposit at all
 #endif
 #ifndef VOXE_T4_SKEW
-#define VOXE_T4_SKEW 0    // r06: per-lane sample shift of oblique tiles (bwd4_march, LK): measured, NOT shipped -- the extra march variant pushes the
-                          // whole kernel over its register budget (profiles/r06_phases_skew.txt)
+#define VOXE_T4_SKEW 0    // r06: per-lane sample shift of oblique tiles (bwd4_march, LK).  1 = every oblique tile in ONE skewed pass: measured, NOT
+                          // shipped -- the extra march variant pushes the whole kernel over its register budget (profiles/r06_phases_skew.txt);
+                          // 2 = only inside the phased passes of tiles that split for their march extent (no new march variant)
 #endif
 #ifndef VOXE_T4_CHJ
 #define VOXE_T4_CHJ 1     // r06: b-parity bit folded into the b term per sample (4 lane constants instead of 8)
@@ -910,6 +911,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
   // ---- does the 8x8 tile fit the lateral window?  (the split decision of render_bwd_tile_kernel) -------------------------
   int split = 0;
   bool phases_fit = false;     // (r06) the parts of this tile leave room in the ring for 2 / 4 consecutive samples of a ray
+  bool phases_skew = false;    // (r06) ... only when their lanes are shifted by the samples a ray is ahead of the part's reference ray
   {
     const unsigned long long am = __ballot(alive);
     if ((am >> 1 & 1ull) && (am >> 8 & 1ull)) {
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
       // r06: with the per-lane sample shift of the skewed march (bwd4_march, LK) a pass's extent along the march axis is no
       // constraint any more; what counts is its lateral extent at equal LAYER: sliding a ray back by its lead along m moves it
       // sideways by lead x |d_lat / d_m|
-      const bool skew_ok = VOXE_T4_SKEW && !PREC && !DEP && a.phases >= 0;
+      const bool skew_ok = VOXE_T4_SKEW == 1 && !PREC && !DEP && a.phases >= 0;
       auto fits_pass = [&](float wx, float wy) {
         float e[3];
 #pragma unroll
@@ -954,7 +956,21 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
                          ((split == 1) ? 7.0f : 3.0f) * ((m == 0) ? ey3[0] : ((m == 1) ? ey3[1] : ey3[2]));
         const float dzs = fabsf(zref - readlane_f32(rc.dg.zlin(max(ke - 1, 0)), 0));
         const float per_sample = ((m == 0) ? d0[0] : ((m == 1) ? d0[1] : d0[2])) * dzs;
-        phases_fit = pe + (float)((split == 3) ? 3 : 1) * per_sample <= a.fit_m + VOXE_T4_PHASE_MARGIN;
+        const float more = (float)((split == 3) ? 3 : 1) * per_sample;
+        phases_fit = pe + more <= a.fit_m + VOXE_T4_PHASE_MARGIN;
+        if (VOXE_T4_SKEW == 2 && !phases_fit) {
+          // a part that splits for its extent ALONG the march axis: with every lane shifted by its ray's lead (bwd4_march: koff) the
+          // part occupies one ray's layers (+ 1 for the rounding of the shift) -- at the price of its lateral extent at equal layer,
+          // lead x |d_lat / d_m| wider, which has to fit the window as well
+          const float wx = (split == 2) ? 7.0f : 3.0f, wy = (split == 1) ? 7.0f : 3.0f;
+          const float dmm = (m == 0) ? d0[0] : ((m == 1) ? d0[1] : d0[2]);
+          float lat = 0.0f;
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax)
+            if (ax != m) lat = fmaxf(lat, wx * ex3[ax] + wy * ey3[ax] + pe * (d0[ax] / dmm));
+          phases_skew = lat <= fit_lat && 1.0f + more <= a.fit_m + VOXE_T4_PHASE_MARGIN;
+          phases_fit = phases_skew;
+        }
       }
     }
   }
@@ -1043,8 +1059,8 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
     // a ray at depth z (voxel units): ((o + d z) scale + bias + 1) N / 2 - 1 / 2; evaluated at the middle of the segment; one
     // sample advances the reference ray by |DU_m| dz layers (dz: the launch's sample spacing at that depth)
     int sh = 0;
-    if constexpr (VOXE_T4_SKEW && !PREC && !DEP) {
-      if (a.phases >= 0 && has) {
+    if constexpr ((VOXE_T4_SKEW == 1 || (VOXE_T4_SKEW == 2 && PH > 1)) && !PREC && !DEP) {
+      if (a.phases >= 0 && has && (VOXE_T4_SKEW == 1 || phases_skew)) {
         const int kmid = (kmin + kmax) >> 1;
         const float zmid = readlane_f32(rc.dg.zlin(kmid), ref_lane), zmid1 = readlane_f32(rc.dg.zlin(min(kmid + 1, c.S - 1)), ref_lane);
         const float om_ = (m == 0) ? rc.o[0] : ((m == 1) ? rc.o[1] : rc.o[2]), dm_ = (m == 0) ? rc.d[0] : ((m == 1) ? rc.d[1] : rc.d[2]);
@@ -1065,7 +1081,7 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
       if constexpr (PH > 1)                                                                                                         \
         bwd4_march<AX, KL, PREC, DEP, PH, true>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, \
                                                 strat_sp, dep, phase, xm1, xm2, phase - sh);                                   \
-      else if constexpr (VOXE_T4_SKEW && !PREC && !DEP) {                                                                           \
+      else if constexpr (VOXE_T4_SKEW == 1 && !PREC && !DEP) {                                                                           \
         if (skew)                                                                                                                   \
           bwd4_march<AX, KL, PREC, DEP, 1, true>(g, c, a, rc, win, tab, lane, r, has, k_lo, k_hi, kmin, kmax, seg, ks, geo, strat_lo, \
                                                  strat_sp, dep, 0, 0, 0, -sh);                                                      \
