@@ -91,7 +91,9 @@ typedef struct VoxeDispatch {
   float tile_fit_m;            /* a pass fits the window when its spread along the march axis is below this many layers:
                                   0 = by launch size (4.0 ... 5.5)                                                            */
   float tile_fit_lat;          /* ... and its lateral extent below this many voxels: 0 = window edge - 2.5                     */
-  int32_t fwd_window;          /* LDS texel window of the SH-0 image-ordered forward: 0 on | -1 off (ray-ordered forward)      */
+  int32_t fwd_window;          /* LDS texel window of the image-ordered forward (SH-0: 16-byte texels; r06: SH 1 - 3, whole texels):
+                                  0 on | -1 off (ray-ordered forward) | 2 test aid (SH 1 - 3): samples the window did not serve
+                                  render as NaN                                                                               */
   float fwd_fit_lat, fwd_fit_m;/* window forward: fit bounds of a tile (0 = 5.5 voxels / 4.5 layers)                           */
   float fwd_zdom;              /* a tile marches along z (ray by ray) when |d_z| >= this x max(|d_x|, |d_y|):
                                   0 = 1.0 | < 0: z-dominant tiles go through the window too (experiment)                      */

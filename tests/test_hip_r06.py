@@ -230,3 +230,82 @@ def test_skewed_and_phased_march_vs_oracle_and_the_one_sample_march(case, disp):
     if case != "term_eps":      # (the truncation is not in the reference: the two marches are compared with each other only)
         rd, rf = vo.render_bwd(grid, cfg, o, d, gc, d_depth=gdep, d_acc=gacc)
         assert rel_l2(new[0], rd) < 1e-4 and rel_l2(new[1], rf) < 1e-4, (rel_l2(new[0], rd), rel_l2(new[1], rf))
+
+
+# ---- the forward of view-dependent grids through an LDS window of whole texels -----------------------------
+def _sh_grid(side, deg, seed=3, dims=None):
+    rng = np.random.default_rng(seed)
+    shape = tuple(dims) if dims else (side,) * 3
+    nf = 3 * (deg + 1) ** 2
+    dens = rng.uniform(-1, 1, shape + (1,)).astype(np.float32)
+    feat = (0.4 * rng.uniform(-1, 1, shape + (nf,))).astype(np.float32)
+    return vo.Grid(dens, feat, AABB, 8.0, abi.ACT_IDENTITY, abi.ACT_SOFTPLUS)
+
+
+@pytest.mark.parametrize("deg,case", [(1, "plain"), (2, "plain"), (3, "plain"), (2, "x_march"), (1, "z_march"), (2, "z_march"),
+                                      (3, "z_march"), (2, "oblique"), (1, "multi_view"), (2, "clip_jitter_tensor"), (3, "lindisp"),
+                                      (2, "tiny_grid"), (1, "coarse_pixels"), (2, "no_jitter_S100")])
+def test_wide_window_forward_is_bit_identical_to_the_ray_ordered_forward(deg, case, disp):
+    """render_fwd_tilew_kernel against render_fwd_seg_kernel (spherical_harmonics.py:87-116, process.py:45-67): the same contraction
+    with the corner texels read from LDS -- every output bit equal, the oracle within the forward tolerance, and the gradients of the
+    two-phase backward (it reads the forward's per-sample (rad, v)) equal too"""
+    disp.set(region_min_rays=-1, tile_min_rays=-1)
+    rng = np.random.default_rng(100 * deg + len(case))
+    kw, over, jit, S = dict(white_bkgd=True, sh_degree=deg), {}, None, 96
+    side, hw, cam = 64, 168, 3        # ~0.38 voxel per pixel, like 400x400 on 160^3
+    if case == "tiny_grid":
+        grid, hw, cam = _sh_grid(0, deg, dims=(5, 6, 7)), 40, 5
+    else:
+        grid = _sh_grid(side, deg)
+    if case == "x_march":
+        cam = 77
+    if case == "z_march":
+        cam = 12
+        disp.set(fwd_zdom=-1.0)
+    if case == "oblique":
+        cam = 40
+    if case == "coarse_pixels":
+        hw = 72
+    o, d = _rays(hw, cam)
+    if case == "multi_view":
+        o2, d2 = _rays(hw, cam + 30)
+        o, d = np.concatenate([o, o2]), np.concatenate([d, d2])
+        over["image_height"] = hw
+    if case in ("plain", "x_march", "z_march", "oblique", "multi_view", "tiny_grid", "coarse_pixels"):
+        kw.update(perturb=True, seed=4, rng_offset=2)
+    if case == "clip_jitter_tensor":
+        kw.update(perturb=True, aabb_clip=True)
+        jit = rng.random((o.shape[0], S)).astype(np.float32)
+    if case == "lindisp":
+        kw.update(linear_disparity=True)
+    if case == "no_jitter_S100":
+        S = 100
+    cfg = make_render_cfg(S, NEAR, FAR, **kw)
+    disp.set(fwd_window=-1)
+    a = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+    disp.set(fwd_window=0)
+    b = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+    for key in ("colour", "depth", "acc"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    np.testing.assert_array_equal(np.isnan(a["disparity"]), np.isnan(b["disparity"]))
+    ref = vo.render_fwd(grid, cfg, o, d, jitter=jit)
+    np.testing.assert_allclose(b["colour"], ref["colour"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(b["acc"], ref["acc"], rtol=0, atol=1e-5)
+    # the window really served the render: in the test-aid mode everything it did not serve is NaN
+    if case in ("plain", "x_march", "z_march", "multi_view"):
+        disp.set(fwd_window=2)
+        s = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+        hit = a["acc"] > 0
+        served = hit & ~np.isnan(s["acc"])
+        assert served.sum() > 0.6 * hit.sum(), (int(served.sum()), int(hit.sum()))
+        np.testing.assert_array_equal(a["colour"][served], s["colour"][served])
+    if case in ("plain", "oblique", "z_march", "clip_jitter_tensor"):
+        gc = rng.standard_normal((o.shape[0], 3)).astype(np.float32)
+        disp.set(fwd_window=-1)
+        g0 = gh.hip_backward(grid, cfg, o, d, gc, jitter=jit, rng=(4, 2), image_width=hw, **over)
+        disp.set(fwd_window=0)
+        g1 = gh.hip_backward(grid, cfg, o, d, gc, jitter=jit, rng=(4, 2), image_width=hw, **over)
+        # (float atomics: the two runs differ by summation order only)
+        assert rel_l2(g1[0], g0[0]) < 1e-5 and rel_l2(g1[1], g0[1]) < 1e-5
+        rd, rf = vo.render_bwd(grid, cfg, o, d, gc, jitter=jit)
+        assert rel_l2(g1[0], rd) < 1e-4 and rel_l2(g1[1], rf) < 1e-4

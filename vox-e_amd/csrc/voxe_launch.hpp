@@ -112,6 +112,9 @@ void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipS
 // the ordinary combine pass)
 bool fwd_tile_supported(const DevGrid& g, const HostCfg& c, int cout, int ncm);
 void launch_fwd_tile(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipStream_t st);
+// ... and for view-dependent grids (SH degree 1 - 3, full evaluation): whole texels staged (voxe_render_tilew.hip)
+bool fwd_tilew_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, int cout, int ncm, int ncu);
+void launch_fwd_tilew(const DevGrid& g, const HostCfg& c, int ncm, const FwdArgs& a, hipStream_t st);
 // deterministic (ordered-accumulation) backward: single-group image-ordered renders only
 bool det_bwd_supported(const DevCfg& c, int deg, int diffuse);
 size_t det_bytes(long long nvox, int C);   // [fixed-point gradient | 4 floats], 256-byte aligned parts

@@ -1248,6 +1248,8 @@ static void launch_fwd_t(const DevGrid& g, const HostCfg& c, const FwdArgs& a, h
       launch_fwd_tile4(g, c, a, st);     // r05: the lean tile-ordered forward (voxe_render_tile4.hip)
     else if (NCU == 1 && fseg == 1 && fwd_tile_supported(g, c, COUT, NCM))
       launch_fwd_tile(g, c, a, st);      // texels of a tile staged in LDS (voxe_render_tile.hip)
+    else if (NCU > 1 && fseg == 1 && fwd_tilew_supported(g, c, a, COUT, NCM, NCU))
+      launch_fwd_tilew(g, c, NCM, a, st);   // r06: whole view-dependent texels of a tile staged in LDS (voxe_render_tilew.hip)
     else
       render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
           g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf, reinterpret_cast<float4*>(a.sample_fwd));

@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libvoxe_hip.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
 
-SOURCES = ["voxe_render.hip", "voxe_render_tile.hip", "voxe_render_tile4.hip", "voxe_render_scatter.hip", "voxe_render_region.hip", "voxe_grid_ops.hip", "voxe_refine.hip", "voxe_api.hip"]
+SOURCES = ["voxe_render.hip", "voxe_render_tile.hip", "voxe_render_tile4.hip", "voxe_render_tilew.hip", "voxe_render_scatter.hip", "voxe_render_region.hip", "voxe_grid_ops.hip", "voxe_refine.hip", "voxe_api.hip"]
 HEADERS = ["voxe_device.hpp", "voxe_launch.hpp", "voxe_render_common.hpp", "voxe_tile_window.hpp"]
 
 # -ffp-contract=off : the voxel-index arithmetic must round like the reference (no implicit FMA)
