@@ -94,9 +94,10 @@ typedef struct VoxeDispatch {
   int32_t fwd_window;          /* LDS texel window of the image-ordered forward (SH-0: 16-byte texels; r06: SH 1 - 3, whole texels):
                                   0 on | -1 off (ray-ordered forward) | 2 test aid (SH 1 - 3): samples the window did not serve
                                   render as NaN                                                                               */
-  float fwd_fit_lat, fwd_fit_m;/* window forward: fit bounds of a tile (0 = 5.5 voxels / 4.5 layers)                           */
-  float fwd_zdom;              /* a tile marches along z (ray by ray) when |d_z| >= this x max(|d_x|, |d_y|):
-                                  0 = 1.0 | < 0: z-dominant tiles go through the window too (experiment)                      */
+  float fwd_fit_lat, fwd_fit_m;/* window forward: fit bounds of a tile (0 = 5.5 voxels / 4.5 layers; SH 1 - 3: 5.5 / 12 -- its
+                                  lanes wait for a layer instead of leaving the window)                                       */
+  float fwd_zdom;              /* a tile is z-dominant when |d_z| >= |this| x max(|d_x|, |d_y|); > 0: such tiles march ray by ray,
+                                  < 0: along z through the window.  0 = 1.0 for SH-0, -1.0 for SH 1 - 3 (4.4)    */
   float fwd_max_adv;           /* layers a window tile may advance per sample: 0 = 1.7                                         */
   int32_t fwd_segments_per_thread; /* depth segments one thread of the ray-ordered forward walks: 0 = 1                        */
   int64_t region_min_rays;     /* space-binned route for unordered / sparse rays from this many rays on: 0 = 16384 | > 0

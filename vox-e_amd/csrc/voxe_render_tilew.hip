@@ -474,9 +474,9 @@ bool fwd_tilew_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, i
 void launch_fwd_tilew(const DevGrid& g, const HostCfg& c, int ncm, const FwdArgs& a, hipStream_t st) {
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
-  // z-dominant tiles: a layer normal to z is 64 separate texels -- through the window as well from 112-byte texels on (measured,
-  // profiles/r06_sh_window.txt: SH-2 / 3 -8 / -7 % on camera 12, SH-1 +6 % on camera 3)
-  const float zdom = disp_or(c.disp.fwd_zdom, ncm == 4 ? 1.0f : -1.0f), max_adv = disp_or(c.disp.fwd_max_adv, 1.7f);
+  // z-dominant tiles march along z through the window as well (a layer normal to z is 64 separate texels of 52 - 196 bytes: the
+  // copy pays from 52-byte texels on, unlike the 16-byte texels of SH-0; profiles/r06_sh_window.txt: camera 26 -35 ... -40 %)
+  const float zdom = disp_or(c.disp.fwd_zdom, -1.0f), max_adv = disp_or(c.disp.fwd_max_adv, 1.7f);
   const float fit_lat = disp_or(c.disp.fwd_fit_lat, 5.5f);
   float4* sf = reinterpret_cast<float4*>(a.sample_fwd);
 #define VOXE_FWDW(NCM)                                                                                                        \

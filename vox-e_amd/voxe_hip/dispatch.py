@@ -37,7 +37,7 @@ class Dispatch:
     fwd_window: int = 0              # 0 on | -1 off
     fwd_fit_lat: float = 0.0
     fwd_fit_m: float = 0.0
-    fwd_zdom: float = 0.0            # 0 = 1.0 | < 0: z-dominant tiles through the window as well
+    fwd_zdom: float = 0.0            # 0 = 1.0 (SH-0) / -1.0 (SH 1-3) | < 0: z-dominant tiles through the window as well
     fwd_max_adv: float = 0.0
     fwd_segments_per_thread: int = 0
     region_min_rays: int = 0         # 0 = 16384 | > 0 | -1: route off
