@@ -49,7 +49,7 @@ head -6 $O/prof_recon/${TAG}_recon_kernel_stats.csv | cut -c1-160
 head -12 $O/prof_refine/${TAG}_refine_kernel_stats.csv | cut -c1-160
 head -8 $O/prof/${TAG}_kernel_stats.csv | cut -c1-200
 # r04: bit-identity of the LDS-window forward over random cases, and the wide fuzz soak (shipped dispatch + tile kernel on small images)
-timeout 900 python tools/fwd_identity_sweep.py 60 2>/dev/null | tail -2 > $O/fwd_identity_sweep.txt; cat $O/fwd_identity_sweep.txt
+(timeout 900 python tools/fwd_identity_sweep.py 60 2>/dev/null | tail -1; timeout 900 python tools/fwd_identity_sweep.py 60 123 2>/dev/null | tail -1) > $O/fwd_identity_sweep.txt; cat $O/fwd_identity_sweep.txt
 VOXE_FUZZ_SEEDS=4000 timeout 1500 python -m pytest tests/test_hip_fuzz.py -q -m gpu 2>&1 | tail -3 > $O/fuzz_soak.txt; cat $O/fuzz_soak.txt
 # (PMC counters: run tools/gpu_pmc.sh BEFORE this script and tools/pmc_to_json.py <tag> locally -- bench.py only uses a PMC summary
 #  whose source_hash equals the kernels it runs, so the summary has to exist, with the final sources, when the lines above are taken)

@@ -258,7 +258,9 @@ __device__ __forceinline__ void fwd_wide_march(const DevGrid& g, const DevCfg& c
           const int4 ol = org[ilc], oh = org[ilc + 1];
           const int4 o0 = sgn > 0 ? ol : oh, o1 = sgn > 0 ? oh : ol;   // origins / ring slots of layers pm, pm + 1
           const int a0 = pu - o0.x, b0 = pv - o0.y, a1 = pu - o1.x, b1 = pv - o1.y;
-          const bool fits = (il == ilc) && ((unsigned)a0 < 7u) && ((unsigned)b0 < 7u) && ((unsigned)a1 < 7u) && ((unsigned)b1 < 7u);
+          // (kl >= base by construction -- base is the minimum over the lanes' current keys -- asserted here so that a ray running
+          //  against the tile's march direction could only ever fall back to the gather, never read a recycled layer)
+          const bool fits = (kl >= base) && (il == ilc) && ((unsigned)a0 < 7u) && ((unsigned)b0 < 7u) && ((unsigned)a1 < 7u) && ((unsigned)b1 < 7u);
           float v, rad[COUT];
           if (fits) {
             // corner texel (layer dm, lateral du, dv): float offset in the ring
