@@ -344,7 +344,7 @@ def main():
 
     # (r05: the lean tile-ordered kernels of voxe_render_tile4.hip wherever they apply -- the headline configuration included)
     lean = args.ray_order == "image" and _dispatch.current().tile_lean >= 0 and not args.no_jitter
-    fwd_kernel = ("voxe::render_fwd_tile4_kernel<3, false>" if lean else
+    fwd_kernel = (("voxe::render_fwd_tile4w_kernel<false>" if _dispatch.current().fwd_window >= 0 else "voxe::render_fwd_tile4_kernel<3, false>") if lean else
                   "voxe::render_fwd_tile_kernel" if args.ray_order == "image" and _dispatch.current().fwd_window >= 0
                   else "voxe::render_fwd_seg_kernel<3, 1, 1>")
     # algorithmic bytes: per in-AABB sample 8 corners x 4 ch x 4 B = 128 B read (fwd),

@@ -482,9 +482,11 @@ def test_lds_staged_forward_is_bit_identical_to_the_ray_ordered_forward(case, di
     a = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
     disp.set(fwd_window=0, tile_lean=-1)                  # the LDS-window forward (render_fwd_tile_kernel)
     b = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
-    disp.set(fwd_window=0, tile_lean=0)                   # r05: the lean tile-ordered forward where it applies (shipped)
+    disp.set(fwd_window=-1, tile_lean=0)                  # r05: the lean tile-ordered forward where it applies (gathers)
     b5 = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
-    for other in (b, b5):
+    disp.set(fwd_window=0, tile_lean=0)                   # r06: ... with the corners from the LDS window (render_fwd_tile4w_kernel; shipped)
+    b6 = gh.hip_forward(grid, cfg, o, d, jitter=jit, rng=(4, 2), image_width=hw, **over)
+    for other in (b, b5, b6):
         for key in ("colour", "depth", "acc"):
             np.testing.assert_array_equal(a[key], other[key], err_msg=key)
         np.testing.assert_array_equal(np.isnan(a["disparity"]), np.isnan(other["disparity"]))

@@ -514,6 +514,6 @@ def test_isa_issue_model_prices_instructions_like_the_microbenchmark():
     assert dict(blocks[1]["cls"]) == {"cnd_salu_vcc": 1, "slow": 2, "fast": 1} and m.loops_of(blocks) == [(1, 1)]
     prof = json.load(open(os.path.join(ROOT, "profiles", "r06_issue_model.json")))
     assert prof["cost_table_clk"] == m.COST
-    for key in ("voxe::render_bwd_tile4_kernel<8, false, 0>", "voxe::render_fwd_tile4_kernel<3, false>"):
+    for key in ("voxe::render_bwd_tile4_kernel<8, false, 0>", "voxe::render_fwd_tile4w_kernel<false>"):
         k = prof["kernels"][key]
         assert 2.15 < k["clk_per_valu"] < 4.3 and k["hot_loops"] and k["occupancy_waves_per_simd"] >= 3

@@ -213,7 +213,7 @@ def model(src_file, kernel_filter):
     return out, blocks, loops
 
 
-HEADLINE = [("voxe_render_tile4.hip", "render_bwd_tile4_kernel<8, false, 0>"), ("voxe_render_tile4.hip", "render_fwd_tile4_kernel<3, false>")]
+HEADLINE = [("voxe_render_tile4.hip", "render_bwd_tile4_kernel<8, false, 0>"), ("voxe_render_tile4.hip", "render_fwd_tile4w_kernel<false>")]
 
 
 def occupancy_of(src_file):

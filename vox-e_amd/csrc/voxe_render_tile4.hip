@@ -1323,6 +1323,321 @@ __global__ __launch_bounds__(64, VOXE_FWD4_LB) void render_fwd_tile4_kernel(cons
   segbuf[(base + 2 + COUT) * c.R + r] = dsum;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// r06: the lean forward WITH the tile's texels in an LDS window.  The lean forward above is paced by its divergent 16-byte
+// gathers (texture-address path: SQ_WAIT_INST_ANY 48 % of its wave cycles, and the whole view dependence of the forward --
+// profiles/r06_pmc_by_camera.txt; with four of the eight loads dropped it runs in 0.147 instead of 0.182 ms,
+// profiles/r06_fwd_window4.txt).  r03's window forward (voxe_render_tile.hip) removed the gathers but paid 230 VALU
+// instructions per wave-sample and 121 registers; this is the same window -- a ring of layers along the march axis x 8 x 8
+// lateral texels, sheared along the tile's reference ray, one coalesced 1 KB copy per layer -- inside the lean kernel's loop:
+// strata through v_readlane, every lane reads its 8 corners with ds_read_b128 at two base addresses + immediates, and only
+// when some lane's footprint is outside the window (ballot) do those lanes gather from global memory.  Tiles that do not fit
+// the window (coarse pixels, z-dominant views by default) run the lean loop unchanged (WIN = false).  The interpolation is
+// interp_texels4() on the same eight texels: outputs bit-identical to render_fwd_seg_kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+#ifndef VOXE_FWD4W_RING
+#define VOXE_FWD4W_RING 6
+#endif
+#ifndef VOXE_FWD4W_LB
+#define VOXE_FWD4W_LB 4
+#endif
+#ifndef VOXE_FWD4W_PREFETCH
+#define VOXE_FWD4W_PREFETCH 1
+#endif
+#ifndef VOXE_FWD4W_ZDOM
+#define VOXE_FWD4W_ZDOM 1.0f   // > 0: z-dominant tiles run the lean loop; < 0: along z through the window
+#endif
+constexpr int kF4Ring = VOXE_FWD4W_RING;   // layers of the texel ring (6 KB)
+constexpr int kF4Table = 64;               // layers tabulated per block: keys key0 .. key0 + 63
+
+template <int M, bool WIN, bool PREC>
+__device__ __forceinline__ void fwd4w_march(const DevGrid& g, const DevCfg& c, const float* __restrict__ packed, RayCtx<3, 1, 1>& rc,
+                                            const int lane, const bool has, const int k_lo, const int k_hi, const int kmin,
+                                            const int kmax, const int ks, const int ke, const int ref, float4* __restrict__ tex,
+                                            int4* __restrict__ org, float (&csum)[3], double (&csum_d)[3], float& asum, float& dsum,
+                                            float& T, double& asum_d, double& dsum_d) {
+  constexpr int COUT = 3;
+  constexpr int U = (M == 0) ? 1 : 0, V = (M == 2) ? 1 : 2;   // lateral axes (v = z whenever m != z: a layer is eight 128-byte runs)
+  constexpr int kCtr = Lat<8>::kCentre;
+  // the strata of this depth segment: lane l holds (lower, span) of sample ks + l (DepthGen's own expressions)
+  float strat_lo = 0.0f, strat_sp = 0.0f;
+  if (ks + lane < c.S && lane <= ke + 1 - ks) {
+    const float2 st = depth_stratum(rc.dg, ks + lane);
+    strat_lo = st.x; strat_sp = st.y;
+  }
+  float z_next = 0.0f;
+  if (has) {   // (the first sample index differs from lane to lane: its stratum is evaluated per lane)
+    const float2 st = depth_stratum(rc.dg, k_lo);
+    const float su = st.y * jitter_uniform(rc.dg.base, k_lo);
+    z_next = st.x + su;
+  }
+  constexpr unsigned TB = 16;   // bytes of a packed texel
+  const unsigned sxb = g.X > 1 ? (unsigned)(g.Y * g.Z) * TB : 0u, syb = g.Y > 1 ? (unsigned)g.Z * TB : 0u;
+  const unsigned szb = g.Z > 1 ? TB : 0u;
+  const unsigned sxi = (unsigned)(g.Y * g.Z) * TB, syi = (unsigned)g.Z * TB;
+  const char* const pbytes = reinterpret_cast<const char*>(packed);
+  const int Sm1 = c.S - 1;
+  // ---- window geometry from the reference ray, per-layer table, first layers (as fwd_window_march) ----
+  int sgn = 1, key0 = 0, base = 0, up0 = 0;
+  const int N[3] = {g.X, g.Y, g.Z};
+  const int Nm2 = N[M] - 2;
+  const int la = lane >> 3, lb8 = lane & 7;
+  const int sx = g.Y * g.Z, sy = g.Z;
+  const int stride_u = (U == 0) ? sx : sy, stride_v = (V == 1) ? sy : 1;
+  const int lane_off = la * stride_u + lb8 * stride_v;
+  auto minkey = [&](int pm) { return sgn > 0 ? pm : -(pm + 1); };
+  // one coalesced read per layer: lane (a, b) fetches voxel (im, origin u + a, origin v + b)
+  auto fetch_layer = [&](int key) -> float4 {
+    const int idx = key - key0;      // wave-uniform
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (idx < kF4Table) {
+      const int4 o = org[idx];
+      const int im = sgn * key;
+      if ((unsigned)im < (unsigned)N[M] && (unsigned)(o.x + la) < (unsigned)N[U] && (unsigned)(o.y + lb8) < (unsigned)N[V])
+        t = reinterpret_cast<const float4*>(packed)[o.z + lane_off];
+    }
+    return t;
+  };
+  auto store_layer = [&](int key, const float4 t) { tex[((key - key0) % kF4Ring) * 64 + lane] = t; };
+  auto load_layer = [&](int key) { store_layer(key, fetch_layer(key)); };
+  float4 pend = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // layer base + ring, requested one slide early (VOXE_FWD4W_PREFETCH)
+  bool have_pend = false;                               // wave-uniform
+  if constexpr (WIN) {
+    float U0[3], DU[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float ro = readlane_f32(rc.o[a], ref), rd = readlane_f32(rc.d[a], ref);
+      const float half = 0.5f * (float)N[a];
+      U0[a] = ((ro * g.scale[a] + g.bias[a]) + 1.0f) * half - 0.5f;
+      DU[a] = rd * g.scale[a] * half;
+    }
+    sgn = (DU[M] < 0.0f) ? -1 : 1;
+    const float inv = (DU[M] != 0.0f) ? 1.0f / DU[M] : 0.0f;
+    const float Bu = DU[U] * inv, Au = U0[U] - Bu * U0[M];
+    const float Bv = DU[V] * inv, Av = U0[V] - Bv * U0[M];
+    const int stride_m = (M == 0) ? sx : ((M == 1) ? sy : 1);
+    int first_key = INT_MAX;
+    if (has) {
+      float p0[3];
+      rc.point(z_next, p0);
+      Footprint f0;
+      footprint(g, p0, f0);
+      first_key = minkey(min(max(f0.i0[M], 0), Nm2));   // (the index make_cell() uses)
+    }
+    key0 = wave_min_dpp(first_key);
+    up0 = sgn > 0 ? 0 : 1;
+    {
+      const int im = sgn * (key0 + lane);
+      const int ou = (int)floorf(Au + Bu * (float)im) - kCtr, ov = (int)floorf(Av + Bv * (float)im) - kCtr;
+      // (origin u, origin v, voxel offset of the origin -- used only when in range --, ring slot x 64)
+      org[lane] = make_int4(ou, ov, im * stride_m + ou * stride_u + ov * stride_v, (lane % kF4Ring) * 64);
+    }
+    __syncthreads();
+    base = key0;
+#pragma unroll
+    for (int i = 0; i < kF4Ring; ++i) load_layer(base + i);
+    __syncthreads();
+  }
+  for (int k = kmin; k <= kmax; ++k) {
+    const bool on = has && (k >= k_lo) && (k <= k_hi);
+    const bool last = (k == Sm1);        // wave-uniform
+    const float z = z_next;
+    if (on && !last) {
+      const int j = k + 1 - ks;          // wave-uniform
+      const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(strat_lo), j));
+      const float sp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(strat_sp), j));
+      const float su = sp * jitter_uniform(rc.dg.base, k + 1);
+      z_next = lo + su;
+    }
+    float p[3];
+    rc.point(z, p);
+    Footprint fp;
+    footprint(g, p, fp);
+    const bool live = on && fp.inside;
+    if (__builtin_amdgcn_ballot_w64(live && !cell_is_interior(g, fp)) != 0ull) {   // (rare: a sample next to a grid face)
+      Cell cf;
+      make_cell(g, fp, cf);
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) { fp.i0[ax] = cf.i[ax]; fp.w[ax][0] = cf.w[ax][0]; fp.w[ax][1] = cf.w[ax][1]; }
+    }
+    Cell cell;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) { cell.i[ax] = fp.i0[ax]; cell.w[ax][0] = fp.w[ax][0]; cell.w[ax][1] = fp.w[ax][1]; }
+    float4 t[8];
+    bool need = live;   // lanes whose corners come from global memory
+    if constexpr (WIN) {
+      const int kl = minkey(cell.i[M]);                  // lower key of the footprint's two layers; the other is kl + 1
+      const int nb = wave_min_dpp(live ? kl : INT_MAX);  // the window starts at the layer the tile's rearmost live sample needs
+      if (nb != INT_MAX && nb > base) {                  // wave-uniform: bring in the layers the march has reached
+        for (int key = max(base + kF4Ring, nb); key < nb + kF4Ring; ++key) {
+          if (have_pend && key == base + kF4Ring) store_layer(key, pend);
+          else load_layer(key);
+        }
+        base = nb;
+        if (VOXE_FWD4W_PREFETCH) { pend = fetch_layer(base + kF4Ring); have_pend = true; }   // travels while the samples of this layer are interpolated
+        __syncthreads();
+      }
+      const int il = kl - key0;
+      const int ilc = (int)min((unsigned)il, (unsigned)(kF4Table - 2));   // (il >= 0 for live lanes: key0 is the minimum of the first keys)
+      const int4 o0 = org[ilc + up0], o1 = org[ilc + 1 - up0];   // origins / ring slots of layers pm, pm + 1 (keys kl, kl + 1 or the reverse)
+      const int pu = cell.i[U], pv = cell.i[V];
+      const unsigned a0 = (unsigned)(pu - o0.x), b0 = (unsigned)(pv - o0.y), a1 = (unsigned)(pu - o1.x), b1 = (unsigned)(pv - o1.y);
+      // inside the ring, inside the table, laterally inside both layers (one unsigned maximum)
+      const bool fits = live && ((unsigned)(kl - base) < (unsigned)(kF4Ring - 1)) && ((unsigned)il < (unsigned)(kF4Table - 1)) &&
+                        (max(max(a0, b0), max(a1, b1)) < 7u);
+      // (addresses of lanes that do not fit stay inside the ring: their reads are overwritten by the gather below or never used)
+      constexpr unsigned kLast = kF4Ring * 64 - 10;
+      const float4* __restrict__ t0 = tex + min((unsigned)o0.w + a0 * 8u + b0, kLast);
+      const float4* __restrict__ t1 = tex + min((unsigned)o1.w + a1 * 8u + b1, kLast);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {   // corner q = (x + (q & 1), y + ((q >> 1) & 1), z + (q >> 2))
+        const int dm = (q >> M) & 1, du = (q >> U) & 1, dv = (q >> V) & 1;   // compile-time after unrolling
+        t[q] = (dm ? t1 : t0)[du * 8 + dv];
+      }
+      need = live && !fits;
+    }
+    if (!WIN || __builtin_amdgcn_ballot_w64(need) != 0ull) {
+      unsigned off0 = mad24((unsigned)cell.i[0], sxi, mad24((unsigned)cell.i[1], syi, (unsigned)cell.i[2] * TB));
+      if constexpr (WIN) {
+        if (need) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+            t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+          }
+        }
+      } else {
+        if (!live) off0 = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const unsigned o = off0 + ((q & 1) ? sxb : 0u) + ((q & 2) ? syb : 0u);
+          t[q] = *reinterpret_cast<const float4*>(pbytes + ((size_t)o + ((q & 4) ? szb : 0u)));
+        }
+      }
+    }
+    float fch[COUT], v;
+    interp_texels4(t, cell, fch[0], fch[1], fch[2], v);
+    asm volatile("" ::"v"(fch[0]), "v"(fch[1]), "v"(fch[2]), "v"(v));   // (reads consumed by every lane, in straight-line code)
+    if (live) {
+      float rad[COUT];
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) rad[ch] = kC0 * fch[ch];
+      const float sigma = post_activate(g.post_act, v);
+      const float dl = last ? kInfinity : (z_next - z);
+      const float delta = dl * rc.dnorm;
+      const float e = fast_exp(-(sigma * delta));
+      const float alpha = 1.0f - e;
+      const float om = 1.0f - alpha;
+      const float w = alpha * T;
+      T = T * om;
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) {
+        const float col = sigmoidf(rad[ch]);
+        csum[ch] = fmaf(col, w, csum[ch]);
+        if constexpr (PREC) csum_d[ch] = fma((double)col, (double)w, csum_d[ch]);
+      }
+      asum = asum + w;
+      dsum = fmaf(z, w, dsum);
+      if constexpr (PREC) { asum_d += (double)w; dsum_d = fma((double)z, (double)w, dsum_d); }
+    }
+  }
+}
+
+template <bool PREC>
+__global__ __launch_bounds__(64, VOXE_FWD4W_LB) void render_fwd_tile4w_kernel(const DevGrid g, const DevCfg c,
+                                                                              const float* __restrict__ packed,
+                                                                              const float* __restrict__ rays_o,
+                                                                              const float* __restrict__ rays_d,
+                                                                              float* __restrict__ segbuf, double* __restrict__ segsum,
+                                                                              const float fit_lat, const float fit_m, const float zdom,
+                                                                              const float max_adv) {
+  constexpr int COUT = 3, NC = COUT + 3;
+  __shared__ float4 tex[kF4Ring * 64];
+  __shared__ int4 org[kF4Table];
+  const int lane = threadIdx.x;
+  const int nseg = num_segments(c.S, c.seg_len);
+  const int nrb = gridDim.x / nseg;                    // tile slots (segment-major block order, like render_fwd_seg_kernel)
+  const int seg = blockIdx.x / nrb, rb = blockIdx.x - seg * nrb;
+  const int W = c.image_width;
+  const int ntx = (W + 7) >> 3, nty = (int)tile_rows_total(c, 8);
+  const int tile = logical_tile_of(c, rb, nrb, ntx, nty);
+  if (tile < 0) return;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  long long r_px;
+  bool alive = tile_pixel_ray(c, ty, lane >> 3, (tx << 3) + (lane & 7), 8, r_px);
+  long long r = alive ? r_px : 0;
+  RayCtx<COUT, 1, 1> rc;
+  rc.init(g, c, r, rays_o, rays_d, nullptr);
+  const int ks = seg * c.seg_len, ke = min(c.S, ks + c.seg_len) - 1;
+  // ---- per tile (wave-uniform): through the window along axis m, or the lean loop (render_fwd_tile_kernel's decision) ----
+  int m = -1, ref = 0;
+  {
+    const int k_lo0 = max(rc.k_lo, ks), k_hi0 = alive ? min(rc.k_hi, ke) : k_lo0 - 1;
+    const unsigned long long hm = __ballot(k_lo0 <= k_hi0), am = __ballot(alive);
+    if (hm != 0ull && (am & 1ull) && (am >> 1 & 1ull) && (am >> 8 & 1ull)) {
+      ref = ((hm >> 27) & 1ull) ? 27 : (__ffsll((long long)hm) - 1);
+      const int N[3] = {g.X, g.Y, g.Z};
+      const float zref = readlane_f32(rc.dg.zlin(ke), 0);
+      float ad[3], e3[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float sc = g.scale[a] * 0.5f * (float)N[a];
+        const float da = readlane_f32(rc.d[a], 0);
+        ad[a] = fabsf(readlane_f32(rc.d[a], ref) * sc);
+        e3[a] = 7.0f * (fabsf((readlane_f32(rc.d[a], 1) - da) * sc * zref) + fabsf((readlane_f32(rc.d[a], 8) - da) * sc * zref));
+      }
+      const int mxy = ad[0] >= ad[1] ? 0 : 1;
+      const int mm = (ad[2] >= fabsf(zdom) * ad[mxy]) ? 2 : mxy;
+      float lat = 0.0f, alongm = 0.0f;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { if (a == mm) alongm = e3[a]; else lat = fmaxf(lat, e3[a]); }
+      const float adv = ad[mm] * fabsf(readlane_f32(rc.dg.zlin(ke) - rc.dg.zlin(ke > 0 ? ke - 1 : 0), ref));
+      if (lat <= fit_lat && alongm <= fit_m && adv <= max_adv && (mm != 2 || zdom < 0.0f) && g.X > 1 && g.Y > 1 && g.Z > 1) m = mm;
+    }
+    if (m < 0 && (am & 1ull) && (am >> 1 & 1ull) && (am >> 8 & 1ull)) {   // gathers from global memory: the lane orientation that touches fewer lines
+      const float d0[3] = {readlane_f32(rc.d[0], 0), readlane_f32(rc.d[1], 0), readlane_f32(rc.d[2], 0)};
+      const float dx[3] = {readlane_f32(rc.d[0], 1), readlane_f32(rc.d[1], 1), readlane_f32(rc.d[2], 1)};
+      const float dy[3] = {readlane_f32(rc.d[0], 8), readlane_f32(rc.d[1], 8), readlane_f32(rc.d[2], 8)};
+      if (tile_lanes_down_columns(g, d0, dx, dy)) {   // wave-uniform
+        alive = tile_pixel_ray(c, ty, lane & 7, (tx << 3) + (lane >> 3), 8, r_px);
+        r = alive ? r_px : 0;
+        rc.init(g, c, r, rays_o, rays_d, nullptr);
+      }
+    }
+  }
+  const int k_lo = max(rc.k_lo, ks);
+  const int k_hi = alive ? min(rc.k_hi, ke) : k_lo - 1;
+  const bool has = k_lo <= k_hi;
+  const int kmin = wave_min_dpp(has ? k_lo : INT_MAX);
+  const int kmax = -wave_min_dpp(has ? -k_hi : INT_MAX);
+  float csum[COUT];
+  double csum_d[COUT];
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) { csum[ch] = 0.0f; csum_d[ch] = 0.0; }
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  double asum_d = 0.0, dsum_d = 0.0;
+  if (kmin <= kmax) {   // wave-uniform
+    if (m == 0) fwd4w_march<0, true, PREC>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ks, ke, ref, tex, org, csum, csum_d, asum, dsum, T, asum_d, dsum_d);
+    else if (m == 1) fwd4w_march<1, true, PREC>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ks, ke, ref, tex, org, csum, csum_d, asum, dsum, T, asum_d, dsum_d);
+    else if (m == 2) fwd4w_march<2, true, PREC>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ks, ke, ref, tex, org, csum, csum_d, asum, dsum, T, asum_d, dsum_d);
+    else fwd4w_march<0, false, PREC>(g, c, packed, rc, lane, has, k_lo, k_hi, kmin, kmax, ks, ke, ref, tex, org, csum, csum_d, asum, dsum, T, asum_d, dsum_d);
+  }
+  if (!alive) return;
+  if constexpr (PREC) {
+    const long long pb = (long long)seg * 5;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) segsum[(pb + ch) * c.R + r] = csum_d[ch];
+    segsum[(pb + 3) * c.R + r] = asum_d;
+    segsum[(pb + 4) * c.R + r] = dsum_d;
+  }
+  const long long base = (long long)seg * NC;
+  segbuf[(base + 0) * c.R + r] = T;
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) segbuf[(base + 1 + ch) * c.R + r] = csum[ch];
+  segbuf[(base + 1 + COUT) * c.R + r] = asum;
+  segbuf[(base + 2 + COUT) * c.R + r] = dsum;
+}
+
 // the lean forward takes what the lean backward takes (the window width does not matter to it)
 bool fwd_tile4_supported(const DevGrid& g, const HostCfg& c, const FwdArgs& a, int cout, int ncm) {
   if (c.disp.tile_lean < 0 || ncm != 1 || !((cout == 3 && !c.attn) || (cout == 1 && c.attn))) return false;
@@ -1335,6 +1650,12 @@ void launch_fwd_tile4(const DevGrid& g, const HostCfg& c, const FwdArgs& a, hipS
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8)) * nseg;
   if (c.attn) render_fwd_tile4_kernel<1, false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr);
+  else if (c.disp.fwd_window >= 0 && (reinterpret_cast<uintptr_t>(a.packed) & 15) == 0) {   // r06: corners from an LDS window of the tile's texels
+    const float fit_lat = disp_or(c.disp.fwd_fit_lat, 5.5f), fit_m = disp_or(c.disp.fwd_fit_m, (float)kF4Ring - 1.5f);
+    const float zdom = disp_or(c.disp.fwd_zdom, VOXE_FWD4W_ZDOM), max_adv = disp_or(c.disp.fwd_max_adv, 1.7f);
+    if (a.segsum_d) render_fwd_tile4w_kernel<true><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, a.segsum_d, fit_lat, fit_m, zdom, max_adv);
+    else render_fwd_tile4w_kernel<false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr, fit_lat, fit_m, zdom, max_adv);
+  }
   else if (a.segsum_d) render_fwd_tile4_kernel<3, true><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, a.segsum_d);
   else render_fwd_tile4_kernel<3, false><<<nb, 64, 0, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.segbuf, nullptr);
 }
