@@ -597,25 +597,34 @@ def main():
             ws_a, ws_b = ops.Workspace(), ops.Workspace()
             pr = ops.RenderParams(num_samples=S, near=NEAR, far=FAR, perturb=True, white_bkgd=True)
 
-            def it(n):
+            def it(n, hint):
                 ops.recon_step_(spec, pr, d2, f2, ws_a, ws_b, HW, HW, focal_for(HW), poses, None, images, B, True, st_d, st_f,
                                 n, n, 1e-4, losses, (77, 10 * n), zero_gradient_first=(n == 1))
+                if hint:   # voxe_recon_prefetch: iteration n + 1's batch + segment tables behind this iteration's backward / Adam
+                    ops.recon_prefetch_(spec, pr, d2, f2, ws_a, ws_b, HW, HW, focal_for(HW), poses, None, images, B, True, losses,
+                                        (77, 10 * (n + 1)))
+
+            def timed(first, hint):
+                for n in range(first, first + 10):
+                    it(n, hint)
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for n in range(first + 10, first + 10 + iters):
+                    it(n, hint)
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t3) / iters
 
             gc.collect()
             gc.disable()
-            for n in range(1, 11):
-                it(n)
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            for n in range(11, 11 + iters):
-                it(n)
-            torch.cuda.synchronize()
-            e3 = (time.perf_counter() - t3) / iters
+            e_plain = timed(1, False)
+            e3 = timed(11 + iters, True)
             gc.enable()
             return {"workload": f"voxe_recon_step: {B} random rays over {K} cameras ({HW}x{HW}), specular + diffuse render, L1 losses, "
-                                "backward, fused Adam -- one library call per iteration",
+                                "backward, fused Adam -- one library call per iteration, the next iteration's batch + segment tables "
+                                "assembled behind this one's backward / Adam (voxe_recon_prefetch, as the trainer does)",
                     "ms_per_iteration": round(1e3 * e3, 4), "iterations_per_s": round(1.0 / e3, 1),
-                    "value": round(2 * B / e3, 1), "unit": "rendered rays/s (2 renders, fwd + bwd)"}
+                    "value": round(2 * B / e3, 1), "unit": "rendered rays/s (2 renders, fwd + bwd)",
+                    "ms_per_iteration_without_prefetch": round(1e3 * e_plain, 4)}
 
         secondary["recon_iteration"] = recon_iteration_bench(max(args.steps, 20))
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VOXE_ABI_VERSION 11
+#define VOXE_ABI_VERSION 12
 
 typedef enum VoxeStatus {
   VOXE_OK = 0,
@@ -485,6 +485,29 @@ size_t voxe_recon_scratch_bytes(int64_t batch);
 int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* step,
                     void* workspace, size_t workspace_bytes, void* workspace2, size_t workspace2_bytes,
                     void* scratch, size_t scratch_bytes, void* stream);
+/* ABI v12.  The NEXT iteration's batch, assembled ahead of its call -- a hint, never a requirement.
+ *   Batch assembly (subset, rays, target pixels) and the space-binning passes of the paired SH-0 render read the cameras,
+ *   the images and the jitter streams, never the grid: modules/trainers.py:288-312 of iteration i + 1 does not depend on
+ *   optimizer.step() of iteration i.  Call this right after voxe_recon_step(i) with the arguments voxe_recon_step(i + 1) WILL
+ *   be called with (same pointers and sizes; only cfg->rng_offset, step->poses / image_rows and the Adam step counters
+ *   normally differ -- the Adam fields, `losses` and cfg->reuse_packed_grid / ray_state_valid are not looked at): the library
+ *   enqueues that work on a stream of its own, ordered behind iteration i's forward, where it overlaps iteration i's
+ *   backward and grid step (160^3, 32768 rays: see DESIGN 4.5).  The following voxe_recon_step waits for it and skips its own
+ *   batch assembly / binning iff every argument that decides them equals the announced one; otherwise it waits and proceeds
+ *   exactly as if no hint had been given.  Results do not depend on whether, or with what, this was called.
+ *   The tables of the hint live in the region scratch of `workspace2` (which must hold voxe_workspace_bytes(grid, cfg,
+ *   2 * batch) bytes like `workspace`) and alternate with those of `workspace`; `scratch` holds both batches
+ *   (voxe_recon_scratch_bytes).  ORDER: the side stream is ordered behind the forward of the voxe_recon_step that was
+ *   enqueued last on this workspace -- not behind this call -- so next_step->poses / image_rows / images must be complete on
+ *   `stream` BEFORE that step was enqueued (draw the next iteration's cameras first, then call the step, then this), and
+ *   stay valid and unchanged until the step that consumes the hint has been enqueued.  Freeing or reusing `workspace2` / `scratch` while a hint is in flight needs a device
+ *   synchronisation first (the side stream is the library's own).  Returns VOXE_OK without doing anything when the iteration
+ *   would not take the paired route (view-dependent grid, no diffuse regularisation, workspaces too small).            */
+int voxe_recon_prefetch(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* next_step,
+                        void* workspace, size_t workspace_bytes, void* workspace2, size_t workspace2_bytes,
+                        void* scratch, size_t scratch_bytes, void* stream);
+/* (test aid) out[3]: hints issued | taken by the step that followed | dropped by it (arguments differed), process-wide */
+int voxe_recon_prefetch_stats(int64_t* out);
 
 /* ------------------------------------------------------------------------------------------------
  * One attention grid's share of an iteration of the refinement loop in ONE call (ABI v10)

@@ -225,3 +225,82 @@ def test_recon_step_bounds_its_image_rows_and_a_failed_call_leaves_the_optimiser
         assert ws.deferred.clean_ptr == 0 and ws.key is None      # the next call clears the gradient region and re-packs
         opt.reconstruction_step(rp, hw, hw, focal_for(hw), poses, None, images, 4096, True, losses, (5, 2))
         assert opt.state[grid.densities]["step"] == 2 and bool(torch.isfinite(losses).all())
+
+
+def _prefetch_stats():
+    import ctypes
+
+    out = (ctypes.c_int64 * 3)()
+    assert ops.lib().voxe_recon_prefetch_stats(out) == 0
+    return list(out)
+
+
+def _run_recon(hint, steps, batch=20000, wrong_hint_at=(), side=48, hw=64, K=6):
+    """`steps` iterations over changing cameras; hint: None | "ahead" (voxe_recon_prefetch after every step, cameras drawn BEFORE the
+    step as the trainer does).  Iterations in `wrong_hint_at` are announced with ANOTHER stream offset than the step then passes."""
+    dens0, feat0, poses_all, images, spec, params = _setup(side, hw, 12)
+    gen = torch.Generator().manual_seed(5)
+    d_b, f_b = dens0.clone(), feat0.clone()
+    st_d = (torch.zeros_like(d_b), torch.zeros_like(d_b))
+    st_f = (torch.zeros_like(f_b), torch.zeros_like(f_b))
+    wa, wb = ops.Workspace(), ops.Workspace()
+    losses = torch.zeros(4, device=DEV)
+    out = []
+
+    def draw(it):
+        rows = torch.randint(0, 12, (K,), generator=gen).to(DEV)
+        return rows, poses_all[rows].contiguous(), (11, 1000 * it)
+
+    upcoming = draw(0)
+    for it in range(steps):
+        rows, poses, rng = upcoming
+        upcoming = draw(it + 1)
+        ops.recon_step_(spec, params, d_b, f_b, wa, wb, hw, hw, focal_for(hw), poses, rows, images, batch, True, st_d, st_f, it + 1,
+                        it + 1, 2e-2, losses, rng, zero_gradient_first=(it == 0))
+        if hint == "ahead":
+            nrng = upcoming[2] if (it + 1) not in wrong_hint_at else (11, 1000 * (it + 1) + 500)
+            ops.recon_prefetch_(spec, params, d_b, f_b, wa, wb, hw, hw, focal_for(hw), upcoming[1], upcoming[0], images, batch, True,
+                                losses, nrng)
+        out.append(losses.tolist())
+    torch.cuda.synchronize()
+    return out, d_b, f_b, dens0, feat0
+
+
+def test_recon_prefetch_changes_nothing_but_the_schedule():
+    """voxe_recon_prefetch (ABI v12): the batch + segment tables of iteration i + 1 assembled on the library's side stream behind
+    iteration i's forward.  Same batches, same tables -> the same iterations: the first iteration's losses are bit-identical (the
+    forward is deterministic), the later ones agree to the rounding noise of the float-atomic gradient sums, and every hint is
+    TAKEN (the stats say so).  A hint for other arguments than the step's is dropped and costs nothing but the wait."""
+    steps = 7
+    s0 = _prefetch_stats()
+    plain, d_p, f_p, dens0, feat0 = _run_recon(None, steps)
+    assert _prefetch_stats() == s0                     # (no hint: the counters do not move)
+    ahead, d_a, f_a, _, _ = _run_recon("ahead", steps)
+    s1 = _prefetch_stats()
+    assert s1[0] - s0[0] == steps and s1[1] - s0[1] == steps - 1 and s1[2] == s0[2], (s0, s1)   # (the last hint has no step behind it)
+    assert plain[0] == ahead[0]
+    for it in range(steps):
+        for j in (0, 1, 2, 3):
+            assert abs(plain[it][j] - ahead[it][j]) < 2e-6 + 2e-5 * abs(plain[it][j]), (it, j, plain[it], ahead[it])
+    for a, b, x0 in ((d_p, d_a, dens0), (f_p, f_a, feat0)):
+        rel = float(torch.linalg.vector_norm(a - b) / torch.linalg.vector_norm(a - x0))
+        assert rel < 0.05, rel
+    # two of the hints announce another jitter stream than the step then uses: dropped, the iterations are the plain ones
+    mixed, d_m, f_m, _, _ = _run_recon("ahead", steps, wrong_hint_at=(2, 5))
+    s2 = _prefetch_stats()
+    # (+ 1 when the allocator hands this run the previous run's workspace address: that run's last hint is still on record there
+    #  and is dropped by the first step here -- a stale hint costs a wait, nothing else)
+    assert s2[2] - s1[2] in (2, 3) and s2[1] - s1[1] == steps - 3, (s1, s2)
+    assert plain[0] == mixed[0]
+    for it in range(steps):
+        for j in (0, 1, 2, 3):
+            assert abs(plain[it][j] - mixed[it][j]) < 2e-6 + 2e-5 * abs(plain[it][j]), (it, j, plain[it], mixed[it])
+
+
+def test_recon_prefetch_is_dropped_where_no_paired_render_runs():
+    """small batches (ray-ordered route) and view-dependent grids take no hint: the call returns without touching anything"""
+    s0 = _prefetch_stats()
+    out, *_ = _run_recon("ahead", 3, batch=3000)
+    assert _prefetch_stats() == s0
+    ref, *_ = _run_recon(None, 3, batch=3000)
+    assert out[0] == ref[0]

@@ -1,7 +1,8 @@
 """Per-iteration time of the reconstruction trainer's inner loop at BASELINE.json configs[1] scale: 160^3 SH-0
 softplus field, 100 views @ 400x400 (synthetic images), 32768 random rays over 8 cached images per iteration,
 specular + diffuse L1, fused Adam.   gpurun -- python tools/recon_bench.py [iters]
-RECON_PYTHON_ITER=1: the iteration composed in Python from the separate ops (r02) instead of voxe_recon_step."""
+RECON_PYTHON_ITER=1: the iteration composed in Python from the separate ops (r02) instead of voxe_recon_step;
+RECON_NO_PREFETCH=1: without the hint that lets the next iteration's batch / segment tables be assembled ahead (r06)."""
 import os
 import sys
 import time
@@ -59,12 +60,25 @@ def main():
     from thre3d_atom.thre3d_reprs.renderers import _render_params
     rparams = _render_params(vm.thre3d_repr, None, vm.render_config, attn=False)
 
+    prefetch = one_call and not os.environ.get("RECON_NO_PREFETCH")
+    upcoming = []
+
+    def draw():
+        picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
+        return picks, poses[picks].contiguous(), ops._next_rng()
+
     def iteration(profile):
         t = time.perf_counter()
-        if one_call:   # what the trainer runs: the whole iteration as ONE library call (voxe_recon_step)
-            picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
-            opt.reconstruction_step(rparams, HW, HW, focal_for(HW), poses[picks].contiguous(), picks, images, B, True, losses,
-                                    ops._next_rng())
+        if one_call:   # what the trainer runs: the whole iteration as ONE library call (voxe_recon_step), the next iteration's
+            #            cameras drawn BEFORE it and announced behind it (voxe_recon_prefetch; RECON_NO_PREFETCH=1: no hint)
+            if not upcoming:
+                upcoming.append(draw())
+            picks, poses_it, rng_it = upcoming.pop()
+            upcoming.append(draw())
+            opt.reconstruction_step(rparams, HW, HW, focal_for(HW), poses_it, picks, images, B, True, losses, rng_it)
+            if prefetch:
+                opt.reconstruction_prefetch(rparams, HW, HW, focal_for(HW), upcoming[0][1], upcoming[0][0], images, B, True, losses,
+                                            upcoming[0][2])
             if profile:
                 mark("whole iteration (one library call)", t)
             return

@@ -619,7 +619,7 @@ namespace {
 #define VOXE_RECON_PAIRED 1
 #endif
 inline size_t up256b(size_t x) { return (x + 255) / 256 * 256; }
-struct ReconLayout { size_t subset, rays_o, rays_d, target, out[2], d_colour[2], partial, out2, d_colour2, total; };
+struct ReconLayout { size_t subset, rays_o, rays_d, target, out[2], d_colour[2], partial, out2, d_colour2, batch2, total; };
 ReconLayout recon_layout(int64_t B) {
   ReconLayout l;
   size_t off = 0;
@@ -628,28 +628,166 @@ ReconLayout recon_layout(int64_t B) {
   l.rays_o = off; off += up256b(b * 3 * sizeof(float));
   l.rays_d = off; off += up256b(b * 3 * sizeof(float));
   l.target = off; off += up256b(b * 3 * sizeof(float));
+  l.batch2 = off;   // (the same four buffers again, behind everything else: the batch voxe_recon_prefetch assembles ahead of its iteration)
   for (int i = 0; i < 2; ++i) { l.out[i] = off; off += up256b(b * 5 * sizeof(float)); }        // colour [B,3] | depth [B] | acc [B]
   for (int i = 0; i < 2; ++i) { l.d_colour[i] = off; off += up256b(b * 3 * sizeof(float)); }
   l.partial = off; off += up256b(l1_scratch_bytes());
   // paired render: colour [2B,3] | depth [2B] | acc [2B], d_colour [2B,3]
   l.out2 = off; off += up256b(2 * b * 5 * sizeof(float));
   l.d_colour2 = off; off += up256b(2 * b * 3 * sizeof(float));
+  const size_t batch_bytes = l.batch2;
+  l.batch2 = off; off += batch_bytes;
   l.total = off;
   return l;
 }
-}  // namespace
 
-size_t voxe_recon_scratch_bytes(int64_t batch) { return batch > 0 ? recon_layout(batch).total : 0; }
-
-int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* rs, void* workspace,
-                    size_t workspace_bytes, void* workspace2, size_t workspace2_bytes, void* scratch, size_t scratch_bytes,
-                    void* stream) {
+// ---- voxe_recon_prefetch: the batch and the segment tables of the NEXT iteration, assembled on a side stream ---------------------
+// Batch assembly and binning read the cameras, the images and the jitter streams -- never the grid -- so iteration i + 1's can run
+// while iteration i's backward and grid step occupy the memory system (binning is index arithmetic; the grid step is a pure
+// HBM stream).  Two sets of tables / batch buffers alternate: set 0 = (region scratch of `workspace`, front of `scratch`), set 1 =
+// (the same offsets of `workspace2`, ReconLayout::batch2).  A prefetch is a HINT recorded per workspace: the step that follows
+// uses it iff the arguments that decide the batch and the tables are the ones it was made for (ReconKey, compared field by
+// field); otherwise it waits for the side stream and assembles its own, exactly as without the hint.
+struct ReconKey {
+  FwdStamp fwd;                  // grid geometry, cfg, dispatch, jitter streams, ray buffers of the paired render
+  const void *poses, *image_rows, *images, *workspace2, *scratch;
+  uint64_t subset_offset, ws2bytes, scbytes;
+  int64_t batch;
+  int32_t H, W, K, num_images;
+  float focal;
+};
+struct ReconPending { bool valid = false; int slot = 0; ReconKey key; hipEvent_t done = nullptr; };
+struct ReconSide {
+  hipStream_t side = nullptr;
+  hipEvent_t fork0 = nullptr;    // on the caller's stream, at the start of a step: from here on the idle set of tables / batch buffers may be rewritten
+  hipEvent_t fork = nullptr;     // ... behind the step's forward (fold pass): from here on the segment pass of the hint may run
+  bool forked = false;
+  int last_slot = 0;             // set the last step of this workspace rendered from
+  ReconPending pend;
+};
+std::mutex g_recon_mu;
+std::unordered_map<const void*, ReconSide> g_recon;     // by workspace
+int64_t g_recon_stats[3] = {0, 0, 0};                   // hints issued | taken by the following step | dropped by it (voxe_recon_prefetch_stats)
+#ifndef VOXE_RECON_SIDE_LOW
+#define VOXE_RECON_SIDE_LOW 1
+#endif
+#ifndef VOXE_RECON_FORK
+#define VOXE_RECON_FORK 1        // where a step lets the prefetch of its successor start: 0 at its own start | 1 behind its forward (fold) |
+                                 // 2 batch assembly + clearing of the counters at its start, the segment pass behind its forward.
+                                 // Measured (160^3, 2 x 32768 rays, ms per iteration; profiles/r06_recon_prefetch.txt): no hint 0.805,
+                                 // 1 -> 0.725, 0 -> 0.79, 2 -> 0.78.  The backward's blocks hold every SIMD's registers and 144 of 160 KB
+                                 // of LDS: launched behind it (1) the segment pass (1024-thread blocks, 72 KB) waits until the backward
+                                 // drains and then shares the machine with the grid step -- an HBM stream that leaves the CUs idle;
+                                 // launched in front of it (2) the segment pass runs at once but the column scan behind it starves and the
+                                 // backward loses a quarter of its slots for as long.  Stream priority moves nothing (hi / lo equal).
+#endif
+ReconKey recon_key(const VoxeGridDesc* grid, const VoxeRenderCfg* pc, const VoxeRenderCfg* cfg, const VoxeReconStep* rs, const float* rays_o,
+                   const float* rays_d, size_t workspace_bytes, const void* workspace2, size_t workspace2_bytes, const void* scratch,
+                   size_t scratch_bytes) {
+  ReconKey k;
+  memset(&k, 0, sizeof(k));
+  k.fwd = make_stamp(grid, pc, rays_o, rays_d, 2 * rs->batch, nullptr, workspace_bytes);
+  k.poses = rs->poses; k.image_rows = rs->image_rows; k.images = rs->images; k.workspace2 = workspace2; k.scratch = scratch;
+  k.subset_offset = cfg->rng_offset; k.ws2bytes = workspace2_bytes; k.scbytes = scratch_bytes;
+  k.batch = rs->batch; k.H = rs->H; k.W = rs->W; k.K = rs->K; k.num_images = rs->num_images; k.focal = rs->focal;
+  return k;
+}
+// the paired render's cfg / jitter pair of an iteration whose caller passed `cfg`
+VoxeRenderCfg recon_pair_cfg(const VoxeRenderCfg* cfg) {
+  VoxeRenderCfg pc = *cfg;
+  pc.ray_state_valid = 0;
+  pc.rng_offset = cfg->rng_offset + 1;
+  pc.render_diffuse = 0;
+  pc.linear_grad = 1;
+  pc.reuse_packed_grid = 0;      // (not part of any key; the step sets it itself)
+  return pc;
+}
+struct ReconBatchPtrs { int64_t* subset; float *rays_o, *rays_d, *target; };
+ReconBatchPtrs recon_batch_ptrs(const ReconLayout& l, void* scratch, int slot) {
+  char* sc = (char*)scratch + (slot ? l.batch2 : 0);
+  return ReconBatchPtrs{(int64_t*)(sc + l.subset), (float*)(sc + l.rays_o), (float*)(sc + l.rays_d), (float*)(sc + l.target)};
+}
+int recon_check(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* rs) {
   if (!grid || !cfg || !rs || !rs->poses || !rs->images || !rs->losses) return VOXE_ERR_NULL_POINTER;
   if (grid->feature_kind != VOXE_FEAT_SH) return VOXE_ERR_UNSUPPORTED;
   if (rs->H <= 0 || rs->W <= 0 || rs->K <= 0 || rs->batch <= 0 || rs->batch > (int64_t)rs->K * rs->H * rs->W)
     return VOXE_ERR_BAD_SHAPE;
   if (rs->num_images <= 0 || (!rs->image_rows && rs->K > rs->num_images)) return VOXE_ERR_BAD_SHAPE;
   if (cfg->image_width != 0 || cfg->image_height != 0 || cfg->deterministic) return VOXE_ERR_UNSUPPORTED;   // a random batch has no image order
+  if ((int64_t)rs->K * rs->H * rs->W > (1ll << 31)) return VOXE_ERR_BAD_SHAPE;
+  return VOXE_OK;
+}
+}  // namespace
+
+size_t voxe_recon_scratch_bytes(int64_t batch) { return batch > 0 ? recon_layout(batch).total : 0; }
+
+int voxe_recon_prefetch(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* rs, void* workspace,
+                        size_t workspace_bytes, void* workspace2, size_t workspace2_bytes, void* scratch, size_t scratch_bytes,
+                        void* stream) {
+  const int chk = recon_check(grid, cfg, rs);
+  if (chk) return chk;
+  // only the paired render of SH-0 grids has tables worth assembling ahead; everything else: the hint is dropped
+  if (!(rs->diffuse_regularisation && cfg->sh_degree == 0 && VOXE_RECON_PAIRED) || !workspace || !workspace2 || !scratch) return VOXE_OK;
+  const int64_t B = rs->batch;
+  const ReconLayout l = recon_layout(B);
+  if (scratch_bytes < l.total) return VOXE_ERR_WORKSPACE;
+  const VoxeRenderCfg pc = recon_pair_cfg(cfg);
+  const PairSpec pair{B, cfg->rng_offset + 2};
+  PairScope scope(&pair);
+  const WsLayout wl = ws_layout(grid, &pc, 2 * B);
+  if (!wl.region || workspace_bytes < wl.total_with_src || workspace2_bytes < wl.total_with_src) return VOXE_OK;
+  Variant v;
+  const int st = validate(grid, &pc, 2 * B, &v);
+  if (st) return st;
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g_recon_mu);
+  ReconSide& rsd = g_recon[workspace];
+  if (!rsd.side) {
+    // (lowest priority: the side stream's kernels fill what the iteration's own kernels leave idle, they do not queue in front of them)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&rsd.side, hipStreamNonBlocking, VOXE_RECON_SIDE_LOW ? prio_lo : prio_hi) != hipSuccess) return VOXE_ERR_LAUNCH;
+    if (hipEventCreateWithFlags(&rsd.fork, hipEventDisableTiming) != hipSuccess) return VOXE_ERR_LAUNCH;
+    if (hipEventCreateWithFlags(&rsd.fork0, hipEventDisableTiming) != hipSuccess) return VOXE_ERR_LAUNCH;
+    if (hipEventCreateWithFlags(&rsd.pend.done, hipEventDisableTiming) != hipSuccess) return VOXE_ERR_LAUNCH;
+  }
+  // (a hint that was never consumed: its tables are overwritten below -- in stream order on the side stream)
+  const int slot = 1 - rsd.last_slot;
+  if (!rsd.forked) {     // no step has run on this workspace yet (or the last one took another route): behind whatever is on `stream`
+    (void)hipEventRecord(rsd.fork0, s);
+    (void)hipEventRecord(rsd.fork, s);
+  }
+  const bool early = VOXE_RECON_FORK == 2 || VOXE_RECON_FORK == 0;
+  (void)hipStreamWaitEvent(rsd.side, early ? rsd.fork0 : rsd.fork, 0);
+  const ReconBatchPtrs bp = recon_batch_ptrs(l, scratch, slot);
+  launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
+                     (const long long*)rs->image_rows, rs->num_images, (long long*)bp.subset, bp.rays_o, bp.rays_d, bp.target, rsd.side);
+  DevGrid dg; HostCfg dc;
+  make_dev(grid, &pc, 2 * B, v, &dg, &dc);
+  void* const tables = (char*)(slot ? workspace2 : workspace) + wl.region_off;
+  launch_bin_region(dg, dc, bp.rays_o, bp.rays_d, nullptr, tables, rsd.side, /*phase=*/1);      // counters cleared
+  if (VOXE_RECON_FORK == 2) (void)hipStreamWaitEvent(rsd.side, rsd.fork, 0);
+  launch_bin_region(dg, dc, bp.rays_o, bp.rays_d, nullptr, tables, rsd.side, /*phase=*/2);      // segments -> sorted tables
+  (void)hipEventRecord(rsd.pend.done, rsd.side);
+  rsd.pend.valid = true;
+  rsd.pend.slot = slot;
+  ++g_recon_stats[0];
+  rsd.pend.key = recon_key(grid, &pc, cfg, rs, bp.rays_o, bp.rays_d, workspace_bytes, workspace2, workspace2_bytes, scratch, scratch_bytes);
+  return finish();
+}
+
+int voxe_recon_prefetch_stats(int64_t* out) {
+  if (!out) return VOXE_ERR_NULL_POINTER;
+  std::lock_guard<std::mutex> lock(g_recon_mu);
+  for (int i = 0; i < 3; ++i) out[i] = g_recon_stats[i];
+  return VOXE_OK;
+}
+
+int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const VoxeReconStep* rs, void* workspace,
+                    size_t workspace_bytes, void* workspace2, size_t workspace2_bytes, void* scratch, size_t scratch_bytes,
+                    void* stream) {
+  const int chk = recon_check(grid, cfg, rs);
+  if (chk) return chk;
   const int nrender = rs->diffuse_regularisation ? 2 : 1;
   if (nrender == 2 && !workspace2) return VOXE_ERR_WORKSPACE;
   const ReconLayout l = recon_layout(rs->batch);
@@ -657,40 +795,77 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
   hipStream_t s = (hipStream_t)stream;
   char* sc = (char*)scratch;
   const int64_t B = rs->batch;
-  int64_t* subset = (int64_t*)(sc + l.subset);
-  float* rays_o = (float*)(sc + l.rays_o);
-  float* rays_d = (float*)(sc + l.rays_d);
-  float* target = (float*)(sc + l.target);
-  // batch assembly: keyed subset of the K * H * W pixels -> rays + target pixels (one launch; same streams as voxe_random_subset,
-  // voxe_cast_rays_indexed and the pixel gather)
-  if ((int64_t)rs->K * rs->H * rs->W > (1ll << 31)) return VOXE_ERR_BAD_SHAPE;
   int st = VOXE_OK;
-  launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
-                     (const long long*)rs->image_rows, rs->num_images, (long long*)subset, rays_o, rays_d, target, s);
+  // a prefetch pending on this workspace: the step waits for the side stream whether or not it takes the tables (they may be
+  // the set this call is about to write), and takes them iff they were made for exactly this call
+  bool have_side = false, pending = false;
+  int pend_slot = 0;
+  ReconKey pend_key;
+  {
+    std::lock_guard<std::mutex> lock(g_recon_mu);
+    const auto it = g_recon.find(workspace);
+    if (it != g_recon.end()) {
+      have_side = true;
+      if (it->second.pend.valid) {
+        pending = true; pend_slot = it->second.pend.slot; pend_key = it->second.pend.key;
+        (void)hipStreamWaitEvent(s, it->second.pend.done, 0);
+        it->second.pend.valid = false;
+      }
+      it->second.last_slot = 0;
+      it->second.forked = false;    // (until the paired route below says from where on the idle tables may be rewritten: a hint given
+                                    //  behind a step that took another route is ordered behind everything on the stream)
+    }
+  }
   // SH-0 grids: the diffuse render is the specular kernel with another jitter stream -- both renders as ONE launch of 2 B
   // rays on the space-binned route (one binning pass, one forward, one backward; no second packed grid).  32 768-ray
   // batches leave the chip half empty and the binning / scan / fold passes are launch-latency sized: r04, 160^3,
   // 1.15 -> see profiles/r04_recon_bench.txt.  Needs `workspace` sized for 2 B rays (voxe_workspace_bytes(grid, cfg, 2 B)).
   if (nrender == 2 && cfg->sh_degree == 0 && VOXE_RECON_PAIRED) {
-    VoxeRenderCfg pc = *cfg;
-    pc.ray_state_valid = 0;
-    pc.rng_offset = cfg->rng_offset + 1;
-    pc.render_diffuse = 0;
-    pc.linear_grad = 1;
+    VoxeRenderCfg pc = recon_pair_cfg(cfg);
+    pc.reuse_packed_grid = cfg->reuse_packed_grid;
     const PairSpec pair{B, cfg->rng_offset + 2};
     PairScope scope(&pair);
     const WsLayout wl = ws_layout(grid, &pc, 2 * B);
     if (wl.region && workspace_bytes >= wl.total_with_src) {
+      int slot = 0;
+      if (pending) {
+        const ReconBatchPtrs pp = recon_batch_ptrs(l, scratch, pend_slot);
+        const ReconKey k = recon_key(grid, &pc, cfg, rs, pp.rays_o, pp.rays_d, workspace_bytes, workspace2, workspace2_bytes, scratch, scratch_bytes);
+        if (memcmp(&k, &pend_key, sizeof(k)) == 0) slot = pend_slot; else pending = false;
+        std::lock_guard<std::mutex> lock(g_recon_mu);
+        ++g_recon_stats[pending ? 1 : 2];
+      }
+      const bool prebinned = pending;
+      const ReconBatchPtrs bp = recon_batch_ptrs(l, scratch, slot);
+      if (have_side) {
+        std::lock_guard<std::mutex> lock(g_recon_mu);
+        ReconSide& rsd = g_recon[workspace];
+        (void)hipEventRecord(rsd.fork0, s);
+        if (VOXE_RECON_FORK == 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
+      }
+      // batch assembly: keyed subset of the K * H * W pixels -> rays + target pixels (one launch; same streams as
+      // voxe_random_subset, voxe_cast_rays_indexed and the pixel gather)
+      if (!prebinned)
+        launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
+                           (const long long*)rs->image_rows, rs->num_images, (long long*)bp.subset, bp.rays_o, bp.rays_d, bp.target, s);
+      const RegionBins bins{slot ? (void*)((char*)workspace2 + wl.region_off) : nullptr, prebinned ? 1 : 0};
+      struct BinsScope { explicit BinsScope(const RegionBins* b) { tl_region_bins = b; } ~BinsScope() { tl_region_bins = nullptr; } } bscope(&bins);
       float* colour = (float*)(sc + l.out2);
       float *depth = colour + 6 * B, *acc = depth + 2 * B;
       float* d_colour = (float*)(sc + l.d_colour2);
-      st = voxe_render_fwd(grid, &pc, rays_o, rays_d, 2 * B, nullptr, colour, depth, acc, nullptr, workspace, workspace_bytes, stream);
+      st = voxe_render_fwd(grid, &pc, bp.rays_o, bp.rays_d, 2 * B, nullptr, colour, depth, acc, nullptr, workspace, workspace_bytes, stream);
       if (st) return st;
-      launch_l1_loss_grad_n(colour, target, 3 * B, 2, d_colour, rs->losses, sc + l.partial, s);   // both renders, one launch pair
+      if (have_side) {
+        std::lock_guard<std::mutex> lock(g_recon_mu);
+        ReconSide& rsd = g_recon[workspace];
+        rsd.last_slot = slot;
+        if (VOXE_RECON_FORK != 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
+      }
+      launch_l1_loss_grad_n(colour, bp.target, 3 * B, 2, d_colour, rs->losses, sc + l.partial, s);   // both renders, one launch pair
       pc.ray_state_valid = 1;
       pc.reuse_packed_grid = 1;
       int32_t layout = VOXE_GRAD_ANY;
-      st = voxe_render_bwd_acc_into(grid, &pc, rays_o, rays_d, 2 * B, nullptr, colour, depth, acc, d_colour, nullptr, nullptr,
+      st = voxe_render_bwd_acc_into(grid, &pc, bp.rays_o, bp.rays_d, 2 * B, nullptr, colour, depth, acc, d_colour, nullptr, nullptr,
                                     rs->exp_avg_densities != nullptr, rs->exp_avg_features != nullptr,
                                     rs->zero_gradient_first ? 1 : 0, &layout, workspace, workspace_bytes, nullptr, 0, stream);
       if (st) return st;
@@ -701,6 +876,12 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
                                  stream);
     }
   }
+  int64_t* subset = (int64_t*)(sc + l.subset);
+  float* rays_o = (float*)(sc + l.rays_o);
+  float* rays_d = (float*)(sc + l.rays_d);
+  float* target = (float*)(sc + l.target);
+  launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
+                     (const long long*)rs->image_rows, rs->num_images, (long long*)subset, rays_o, rays_d, target, s);
   VoxeRenderCfg rc[2] = {*cfg, *cfg};
   void* ws[2] = {workspace, workspace2};
   size_t wsb[2] = {workspace_bytes, workspace2_bytes};

@@ -131,6 +131,12 @@ void launch_fwd_region(const DevGrid& g, const HostCfg& c, int deg, int diffuse,
                        hipStream_t st);   // segment tables + forward; leaves the per-segment states in `scratch`
 void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, const BwdArgs& a, void* scratch,
                        hipStream_t st);   // needs the tables / states of launch_fwd_region for the same rays
+// r06: the binning passes of launch_fwd_region on their own, into the tables at `tables` (a buffer of region_scratch_bytes), and
+// the override the region launches read while it is set: tables elsewhere than in `scratch` / already filled for these rays
+struct RegionBins { void* tables; int prebinned; };
+extern thread_local const RegionBins* tl_region_bins;
+void launch_bin_region(const DevGrid& g, const HostCfg& c, const float* rays_o, const float* rays_d, const float* jitter, void* tables,
+                       hipStream_t st, int phase = 3);   // phase 1: clear the counters | 2: the passes behind that | 3: both
 // byte offsets of the segment tables inside the region scratch + their dimensions (test aid: voxe_region_debug_layout)
 void region_debug_layout(int X, int Y, int Z, long long R, int S, long long out[16]);
 

@@ -1262,20 +1262,25 @@ size_t region_scratch_bytes(int X, int Y, int Z, long long R, int S, bool full_s
   if (R <= 0 || S <= 0) return 0;
   return region_layout(X, Y, Z, R, S, full_sh).total;
 }
-static BinScratch bin_scratch(const RegionLayout& l, void* scratch) {
+// The segment TABLES (everything the binning passes write: slots, sorted list, counters, block tables) may live in another
+// buffer than the per-segment partials / states: voxe_recon_prefetch bins the NEXT iteration's batch into a second set of tables
+// while this iteration's backward still reads the first (tl_region_bins, set by voxe_recon_step around its render calls).
+thread_local const RegionBins* tl_region_bins = nullptr;
+static BinScratch bin_scratch(const RegionLayout& l, void* scratch, void* tables = nullptr) {
   char* base = (char*)scratch;
+  char* tb = tables ? (char*)tables : ((tl_region_bins && tl_region_bins->tables) ? (char*)tl_region_bins->tables : base);
   BinScratch bs;
-  bs.slot_region = (unsigned*)(base + l.slot_region);
-  bs.slot_pos = (unsigned*)(base + l.slot_pos);
-  bs.slot_seg = (uint2*)(base + l.slot_seg);
-  bs.sorted = (uint4*)(base + l.sorted);
+  bs.slot_region = (unsigned*)(tb + l.slot_region);
+  bs.slot_pos = (unsigned*)(tb + l.slot_pos);
+  bs.slot_seg = (uint2*)(tb + l.slot_seg);
+  bs.sorted = (uint4*)(tb + l.sorted);
   bs.part = (float4*)(base + l.part);
   bs.state = (float4*)(base + l.state);
-  bs.lane_n = (unsigned*)(base + l.lane_n);
-  bs.count = (unsigned*)(base + l.counters);
+  bs.lane_n = (unsigned*)(tb + l.lane_n);
+  bs.count = (unsigned*)(tb + l.counters);
   bs.start = bs.count + up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)) / sizeof(unsigned);
-  bs.blockhist = l.seg_blocks ? (unsigned long long*)(base + l.blockhist) : nullptr;
-  bs.blockoff = (uint4*)(base + l.blockoff);
+  bs.blockhist = l.seg_blocks ? (unsigned long long*)(tb + l.blockhist) : nullptr;
+  bs.blockoff = (uint4*)(tb + l.blockoff);
   return bs;
 }
 
@@ -1296,11 +1301,13 @@ static size_t full_tex_lds(K kernel, int cm) {
   return bytes;
 }
 
-template <int COUT, int NCM, int NCU>
-static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st, bool lds_ok) {
-  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, NCU > 1);
-  const BinScratch bs = bin_scratch(l, scratch);
-  (void)hipMemsetAsync(bs.count, 0, 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)), st);
+// the binning passes (index math only: they read the rays and the jitter streams, never the grid): segments -> counting sort by
+// (region, length class).  Writes the TABLES of `bs` only.
+static void launch_bin_region_passes(const DevGrid& g, const DevCfg& c, const float* rays_o, const float* rays_d, const float* jitter,
+                                     const RegionLayout& l, const BinScratch& bs, hipStream_t st, bool lds_ok, int phase = 3) {
+  // phase: 1 = clear the counters | 2 = everything behind that | 3 = both
+  if (phase & 1) (void)hipMemsetAsync(bs.count, 0, 2 * up256(((size_t)(l.nreg + 1) * kLenClasses + 4) * sizeof(unsigned)), st);
+  if (!(phase & 2)) return;
   const int nseg = num_segments(c.S, c.seg_len);
   const int nb = (c.image_width > 0 ? blocks_for_tiles(c.map_mode, (c.image_width + 7) / 8, tile_rows_total(c, 8))
                                     : blocks_for_tiles(c.map_mode, 1, (c.R + 63) / 64)) * nseg;
@@ -1312,13 +1319,30 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
     const size_t hist_bytes = (size_t)(l.nreg + 1) * sizeof(unsigned long long);
     if (hist_bytes > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)region_seg_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_bytes);
-    region_seg_lds_kernel<<<l.seg_blocks, kSegLdsThreads, hist_bytes, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg, nb, units_per_wave);
+    region_seg_lds_kernel<<<l.seg_blocks, kSegLdsThreads, hist_bytes, st>>>(g, c, rays_o, rays_d, jitter, bs, l.nreg, nb, units_per_wave);
     region_colscan_kernel<<<(l.nreg + 1 + kColRegions - 1) / kColRegions, kColRegions * kColChunks, 0, st>>>(bs, l.nreg, l.seg_blocks);
   } else {
-    region_seg_kernel<<<nb, 64, 0, st>>>(g, c, a.rays_o, a.rays_d, a.jitter, bs, l.nreg);
+    region_seg_kernel<<<nb, 64, 0, st>>>(g, c, rays_o, rays_d, jitter, bs, l.nreg);
   }
   region_scan_kernel<<<1, 1024, 0, st>>>(bs.count, bs.start, (l.nreg + 1) * kLenClasses + 1);
   region_fill_kernel<<<(int)((l.nlanes + 255) / 256), 256, 0, st>>>(bs, l.nlanes, l.nreg, lds_ranks ? 1 : 0);
+}
+// ... on their own, into the tables at `tables` (a region scratch, or a buffer of the same size): what launch_fwd_region would do
+// first for these rays (voxe_recon_prefetch; the table offsets do not depend on the grid's SH degree)
+void launch_bin_region(const DevGrid& g, const HostCfg& c, const float* rays_o, const float* rays_d, const float* jitter, void* tables,
+                       hipStream_t st, int phase) {
+  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, false);
+  const BinScratch bs = bin_scratch(l, tables, tables);
+  launch_bin_region_passes(g, c, rays_o, rays_d, jitter, l, bs, st, disp_region_lds_ranks(c.disp), phase);
+}
+
+template <int COUT, int NCM, int NCU>
+static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs& a, void* scratch, hipStream_t st, bool lds_ok) {
+  const RegionLayout l = region_layout(g.X, g.Y, g.Z, c.R, c.S, NCU > 1);
+  const BinScratch bs = bin_scratch(l, scratch);
+  if (!(tl_region_bins && tl_region_bins->prebinned))     // (the tables already hold these rays' segments)
+    launch_bin_region_passes(g, c, a.rays_o, a.rays_d, a.jitter, l, bs, st, lds_ok);
+  const int nseg = num_segments(c.S, c.seg_len);
   // degree 3: staging the 151.6 KB of a region's texels leaves one block (4 waves) per CU
   const int stage = (NCU > VOXE_REGION_STAGE_FWD_NCU) ? 0 : 1;
   const size_t lds = (NCU > 1 && stage) ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;

@@ -222,6 +222,19 @@ class FusedGridAdam(torch.optim.Optimizer):
         d.dirty, d.layout = False, _ops.abi.GRAD_ANY
 
     @torch.no_grad()
+    def reconstruction_prefetch(self, render_params, height: int, width: int, focal: float, poses, image_rows, images,
+                                batch: int, diffuse_regularisation: bool, losses, rng) -> None:
+        """Announce the NEXT reconstruction_step (voxe_recon_prefetch): same arguments, `poses` / `image_rows` / `rng` of the
+        iteration to come.  Its batch and segment tables are assembled on a stream of the library's own while the current
+        iteration's backward and Adam step run.  A hint -- results never depend on it; call it right after
+        reconstruction_step, with `poses` / `image_rows` that were COMPUTED before that step was enqueued (the side stream
+        is ordered behind that step's forward, not behind this call)."""
+        if self.kind != "sh" or self.workspace.deferred is None or self.workspace.sibling is None:
+            return
+        _ops.recon_prefetch_(self.spec, render_params, self._dens, self._feat, self.workspace, self.workspace.sibling, height,
+                             width, focal, poses, image_rows, images, batch, diffuse_regularisation, losses, rng)
+
+    @torch.no_grad()
     def attention_refinement_step(self, render_params, rays_o, rays_d, attn_map, tv_weight: float, losses=None, rng=(0, 0),
                                   attn_render=None) -> None:
         """One attention grid's share of a refinement iteration (modules/attn_grid_trainer.py:335-378) in ONE library call

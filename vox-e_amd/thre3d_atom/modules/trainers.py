@@ -56,6 +56,9 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
     fused_grid_step: bool = True,      # addition of this build: FusedGridAdam (gradient stays in the kernels' workspace)
     fused_iteration: bool = True,      # addition of this build: the whole iteration (batch, 2 renders, L1, backward, Adam) as
                                        # ONE library call (voxe_recon_step) -- needs fused_grid_step; same arithmetic
+    prefetch_batches: bool = True,     # addition of this build (fused_iteration only): the next iteration's pixel batch and its
+                                       # segment tables are assembled while this iteration's backward / Adam run
+                                       # (voxe_recon_prefetch); same batches, same arithmetic
 ) -> VolumetricModel:
     if not isinstance(vol_mod.thre3d_repr, VoxelGrid) or vol_mod.render_procedure != render_sh_voxel_grid:
         raise AssertionError("this train procedure needs an SH-based VoxelGrid volumetric model")
@@ -108,21 +111,35 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         one_call = fused_grid_step and fused_iteration and data.images.shape[1] == 3 and data.images.is_contiguous()
         fused_losses = torch.zeros(4, dtype=torch.float32, device=device)
         log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
+
+        def draw_batch():
+            # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
+            # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
+            picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
+            if not one_call:
+                return picks, None, None
+            return picks, data.poses[picks].contiguous(), _next_rng()
+
         try:
+            # (the one-call loop draws an iteration's cameras / streams one iteration AHEAD -- before the previous step is
+            #  enqueued -- whether or not the hint below is given: the batches do not depend on `prefetch_batches`)
+            upcoming = draw_batch()
             for it in range(1, num_iterations_per_stage + 1):
                 t0 = time.perf_counter()
-                # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
-                # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
-                picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
+                picks, poses_it, rng_it = upcoming
+                upcoming = draw_batch() if it < num_iterations_per_stage else None
                 if one_call:
                     # ONE library call: random pixel batch over the picked cameras -> specular (+ diffuse) render -> L1 ->
                     # backward -> Adam with this optimiser's state and learning rate (voxe_recon_step).  The loss values stay
                     # on the device until they are logged.
-                    optimizer.reconstruction_step(
-                        _render_params(vol_mod.thre3d_repr, None, vol_mod.render_config, attn=False), intr.height, intr.width,
-                        float(intr.focal), data.poses[picks].contiguous(), picks, data.images,
-                        min(ray_batch_size, picks.numel() * intr.height * intr.width), apply_diffuse_render_regularization,
-                        fused_losses, _next_rng())
+                    params_it = _render_params(vol_mod.thre3d_repr, None, vol_mod.render_config, attn=False)
+                    batch_it = min(ray_batch_size, picks.numel() * intr.height * intr.width)
+                    optimizer.reconstruction_step(params_it, intr.height, intr.width, float(intr.focal), poses_it, picks, data.images,
+                                                  batch_it, apply_diffuse_render_regularization, fused_losses, rng_it)
+                    if prefetch_batches and upcoming is not None:
+                        optimizer.reconstruction_prefetch(params_it, intr.height, intr.width, float(intr.focal), upcoming[1], upcoming[0],
+                                                          data.images, batch_it, apply_diffuse_render_regularization, fused_losses,
+                                                          upcoming[2])
                 else:
                     rays_batch, pixels_batch = sample_random_rays_and_pixels_from_cameras(
                         intr, data.poses[picks], data.images, ray_batch_size, image_ids=picks,

@@ -7,7 +7,7 @@ shares the same signatures minus (workspace, stream).
 """
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # VoxeStatus
 OK = 0
@@ -201,6 +201,8 @@ HIP_ONLY = {
     "region_debug_layout": (C.c_int, [_GD, _RC, C.c_int64, C.POINTER(C.c_int64)]),
     "recon_scratch_bytes": (C.c_size_t, [C.c_int64]),
     "recon_step": (C.c_int, [_GD, _RC, C.POINTER(VoxeReconStep), _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P]),
+    "recon_prefetch_stats": (C.c_int, [C.POINTER(C.c_int64)]),
+    "recon_prefetch": (C.c_int, [_GD, _RC, C.POINTER(VoxeReconStep), _P, C.c_size_t, _P, C.c_size_t, _P, C.c_size_t, _P]),
     "attn_masked_l1_scratch_bytes": (C.c_size_t, []),
     "attn_masked_l1": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_size_t, _P]),
     "attn_refine_scratch_bytes": (C.c_size_t, [_GD, C.c_int64]),

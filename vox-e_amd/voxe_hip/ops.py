@@ -73,6 +73,19 @@ class Workspace:
         # LEAVE the grid gradient in this workspace's gradient region instead of returning .grad tensors
         self.deferred: Optional["DeferredGrad"] = None
         self.recon_scratch: dict = {}   # device scratch of recon_step_ (rays, targets, outputs of one fused iteration)
+        # recon_prefetch_: the library's side stream may be writing into this buffer (and reading `prefetch_keepalive`) until the
+        # next recon_step_ of the owning workspace has been enqueued
+        self.prefetch_inflight = False
+        self.prefetch_keepalive = None
+        self.recon_cache = None         # descriptors of the last recon_step_ (what a hint for the next one repeats)
+
+    def __del__(self):
+        # a hint in flight (recon_prefetch_) writes this buffer from a stream torch's caching allocator knows nothing about
+        try:
+            if self.prefetch_inflight and self.buf is not None:
+                torch.cuda.synchronize(self.buf.device)
+        except Exception:
+            pass
 
     def for_differentiable_forward(self, version=None) -> "Workspace":
         """the workspace a differentiable forward should run in.  A pending forward whose backward never came (the caller
@@ -90,6 +103,9 @@ class Workspace:
     def ensure(self, nbytes: int, device) -> torch.Tensor:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
             old = self.buf
+            if old is not None and self.prefetch_inflight:
+                torch.cuda.synchronize(old.device)   # (a stream torch's allocator knows nothing about is still using the old buffer)
+                self.prefetch_inflight = False
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             keep = (old is not None and self.deferred is not None and self.deferred.dirty
                     and old.device == self.buf.device)
@@ -805,29 +821,25 @@ def attn_refine_step_(spec: GridSpec, params: RenderParams, densities, attn, ray
 
 
 @torch.no_grad()
-def recon_step_(spec: GridSpec, params: RenderParams, densities, features, workspace: Workspace, workspace2: Workspace,
+def _recon_call(entry: str, spec: GridSpec, params: RenderParams, densities, features, workspace: Workspace, workspace2: Workspace,
                 height: int, width: int, focal: float, poses: torch.Tensor, image_rows: Optional[torch.Tensor],
                 images: torch.Tensor, batch: int, diffuse_regularisation: bool, state_densities, state_features,
                 step_densities: int, step_features: int, lr: float, losses: torch.Tensor, rng: Tuple[int, int],
-                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_gradient_first: bool = True,
-                scratch_holder: Optional[dict] = None) -> None:
-    """voxe_recon_step: one reconstruction iteration (random pixel batch over the K cameras `poses` -> specular
-    [+ diffuse] render -> L1 loss(es) against `images` -> backward -> Adam on both grid tensors) in ONE library call.
-    `losses` [4] float32 on the device receives (L1 specular, MSE specular, L1 diffuse, MSE diffuse).  The jitter /
-    subset streams derive from `rng` (subset: offset, specular: offset + 1, diffuse: offset + 2).  Afterwards
-    `workspace` holds the updated grid packed and a cleared gradient region."""
+                beta1: float, beta2: float, eps: float, zero_gradient_first: bool, scratch_holder: Optional[dict]):
+    """argument marshalling shared by voxe_recon_step and voxe_recon_prefetch (the hint must announce EXACTLY what the step
+    will pass: same descriptors, same buffers, same sizes)"""
     device = densities.device
     ensure_gfx950(device)
     for nm, t in (("densities", densities), ("features", features), ("poses", poses), ("images", images), ("losses", losses)):
-        require_device(t, f"recon_step_ ({nm})")
+        require_device(t, f"{entry} ({nm})")
         if t.dtype != torch.float32 or not t.is_contiguous():
-            raise VoxeError(f"recon_step_: {nm} must be contiguous float32")
+            raise VoxeError(f"{entry}: {nm} must be contiguous float32")
     if images.dim() != 4 or images.shape[1] != 3 or tuple(images.shape[2:]) != (height, width):
-        raise VoxeError(f"recon_step_: images must be [N,3,{height},{width}], got {tuple(images.shape)}")
+        raise VoxeError(f"{entry}: images must be [N,3,{height},{width}], got {tuple(images.shape)}")
     if poses.dim() != 3 or tuple(poses.shape[1:]) != (3, 4) or losses.numel() < 4:
-        raise VoxeError("recon_step_: poses must be [K,3,4] and losses hold 4 floats")
+        raise VoxeError(f"{entry}: poses must be [K,3,4] and losses hold 4 floats")
     if image_rows is not None and (image_rows.dtype != torch.int64 or image_rows.numel() != poses.shape[0] or not image_rows.is_cuda):
-        raise VoxeError("recon_step_: image_rows must be int64 [K] on the device")
+        raise VoxeError(f"{entry}: image_rows must be int64 [K] on the device")
     L = lib()
     key = _pack_key(spec, densities, features)
     p = dataclasses.replace(params, linear_grad=True, image_width=0, image_height=0)
@@ -859,14 +871,46 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
         if diffuse_regularisation:
             # the second workspace runs the DIFFUSE render: for view-dependent grids that render may take another route (and
             # need other scratch) than the specular one -- size it with the diffuse cfg, and never below the first workspace
+            # (SH-0: it holds the second set of segment tables, the one voxe_recon_prefetch fills ahead)
             _, c2 = _descs(spec, dataclasses.replace(p, render_diffuse=True), densities, features, rng[0], rng[1], False)
             ws2 = workspace2.ensure(max(nbytes, L.voxe_workspace_bytes(C.byref(g), C.byref(c2), int(batch))), device)
         need = L.voxe_recon_scratch_bytes(int(batch))
         sc = holder.get("buf")
         if sc is None or sc.numel() < need or sc.device != ws.device:
+            if sc is not None and workspace.prefetch_inflight:
+                torch.cuda.synchronize(device)     # (the library's side stream may still be writing the old buffer)
+                workspace.prefetch_inflight = False
             sc = holder["buf"] = torch.empty(need, dtype=torch.uint8, device=device)
+    return L, g, c, rs, ws, ws2, sc, (m_d, v_d, m_f, v_f)
+
+
+def recon_step_(spec: GridSpec, params: RenderParams, densities, features, workspace: Workspace, workspace2: Workspace,
+                height: int, width: int, focal: float, poses: torch.Tensor, image_rows: Optional[torch.Tensor],
+                images: torch.Tensor, batch: int, diffuse_regularisation: bool, state_densities, state_features,
+                step_densities: int, step_features: int, lr: float, losses: torch.Tensor, rng: Tuple[int, int],
+                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, zero_gradient_first: bool = True,
+                scratch_holder: Optional[dict] = None) -> None:
+    """voxe_recon_step: one reconstruction iteration (random pixel batch over the K cameras `poses` -> specular
+    [+ diffuse] render -> L1 loss(es) against `images` -> backward -> Adam on both grid tensors) in ONE library call.
+    `losses` [4] float32 on the device receives (L1 specular, MSE specular, L1 diffuse, MSE diffuse).  The jitter /
+    subset streams derive from `rng` (subset: offset, specular: offset + 1, diffuse: offset + 2).  Afterwards
+    `workspace` holds the updated grid packed and a cleared gradient region."""
+    device = densities.device
+    L, g, c, rs, ws, ws2, sc, (m_d, v_d, m_f, v_f) = _recon_call(
+        "recon_step_", spec, params, densities, features, workspace, workspace2, height, width, focal, poses, image_rows, images,
+        batch, diffuse_regularisation, state_densities, state_features, step_densities, step_features, lr, losses, rng, beta1,
+        beta2, eps, zero_gradient_first, scratch_holder)
+    with torch.cuda.device(device):
         check(L.voxe_recon_step(C.byref(g), C.byref(c), C.byref(rs), ptr(ws), ws.numel(), ptr(ws2),
                                 0 if ws2 is None else ws2.numel(), ptr(sc), sc.numel(), stream_ptr(device)), "voxe_recon_step")
+    workspace.prefetch_inflight = False                    # (the step waited for the side stream, hint taken or not)
+    workspace2.prefetch_inflight = False
+    # what a hint for the NEXT iteration has to repeat (recon_prefetch_ copies these descriptors instead of building them again:
+    # the hint's host time is on the iteration's critical path once the device work is hidden)
+    workspace.recon_cache = ((spec, params, densities.data_ptr(), features.data_ptr(), int(height), int(width), float(focal),
+                              images.data_ptr(), int(batch), bool(diffuse_regularisation), losses.data_ptr()),
+                             g, c, rs, ws, ws2, sc)
+    workspace.prefetch_keepalive = None
     for t in (densities, features, m_d, v_d, m_f, v_f):
         if t is not None:
             torch.autograd.graph.increment_version(t)
@@ -874,6 +918,44 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
     workspace.state_key = None
     workspace2.key = None                                  # (its packed grid is the previous iteration's)
     workspace2.state_key = None
+
+
+def recon_prefetch_(spec: GridSpec, params: RenderParams, densities, features, workspace: Workspace, workspace2: Workspace,
+                    height: int, width: int, focal: float, poses: torch.Tensor, image_rows: Optional[torch.Tensor],
+                    images: torch.Tensor, batch: int, diffuse_regularisation: bool, losses: torch.Tensor, rng: Tuple[int, int],
+                    scratch_holder: Optional[dict] = None) -> None:
+    """voxe_recon_prefetch: announce the NEXT recon_step_ (same arguments; `poses`, `image_rows` and `rng` are the next
+    iteration's).  The library assembles that iteration's batch and segment tables on a stream of its own while the current
+    iteration's backward and grid step run; the next recon_step_ takes them iff its arguments are the announced ones.  A hint:
+    results never depend on it.  Call it right after recon_step_ (both workspaces and the scratch exist by then and keep
+    their addresses); `poses` / `image_rows` are kept alive until the next recon_step_ of this workspace."""
+    device = densities.device
+    if workspace.buf is None:
+        return                                             # (no step has sized the buffers yet: nothing to announce against)
+    cache = workspace.recon_cache
+    key = (spec, params, densities.data_ptr(), features.data_ptr(), int(height), int(width), float(focal), images.data_ptr(),
+           int(batch), bool(diffuse_regularisation), losses.data_ptr())
+    if (cache is not None and scratch_holder is None and cache[0] == key and cache[4] is workspace.buf and cache[5] is workspace2.buf
+            and poses.is_cuda and poses.dtype == torch.float32 and poses.is_contiguous() and tuple(poses.shape) == (cache[3].K, 3, 4)
+            and (image_rows is None or (image_rows.is_cuda and image_rows.dtype == torch.int64 and image_rows.numel() == cache[3].K))):
+        # the descriptors of the last step with the next iteration's cameras and streams
+        L = lib()
+        _, g, c0, rs0, ws, ws2, sc = cache
+        c = type(c0).from_buffer_copy(c0)
+        rs = type(rs0).from_buffer_copy(rs0)
+        c.seed, c.rng_offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFFFFFFFFFF
+        rs.poses, rs.image_rows = ptr(poses), ptr(image_rows)
+    else:
+        L, g, c, rs, ws, ws2, sc, _ = _recon_call(
+            "recon_prefetch_", spec, params, densities, features, workspace, workspace2, height, width, focal, poses, image_rows,
+            images, batch, diffuse_regularisation, None, None, 0, 0, 0.0, losses, rng, 0.9, 0.999, 1e-8, False, scratch_holder)
+    with torch.cuda.device(device):
+        check(L.voxe_recon_prefetch(C.byref(g), C.byref(c), C.byref(rs), ptr(ws), ws.numel(), ptr(ws2),
+                                    0 if ws2 is None else ws2.numel(), ptr(sc), sc.numel(), stream_ptr(device)), "voxe_recon_prefetch")
+    workspace.prefetch_inflight = True
+    if workspace2 is not None:
+        workspace2.prefetch_inflight = True
+    workspace.prefetch_keepalive = (poses, image_rows, images)
 
 
 @torch.no_grad()
