@@ -196,28 +196,32 @@ def main():
                               exchange="reduce-scatter" if want_exchange == "auto" else want_exchange)
         exp_avg = exp_avg_sq = None   # (the split path's moments; the fused optimiser owns its own)
 
-    def fused_step(prm, ro, rd, outs, gcol, wsx):
+    def fused_step(prm, ro, rd, outs, gcol, wsx, ev=None):
         # the gradient stays in the workspace in the backward kernel's layout; one pass then applies the chain rule of
         # the density pre-activation and Adam to both tensors, writes the packed grid of the next forward and clears
-        # the gradient for the next backward
+        # the gradient for the next backward.  `ev` (timed steps): events behind the forward and behind the backward
         step_no[0] += 1
         rng = (42, step_no[0])
         ops.render_fwd_into(spec, prm, dens, feat, ro, rd, None, *outs, wsx, rng)
+        if ev is not None:
+            ev[0].record()
         layout = ops.render_bwd_acc(spec, prm, dens, feat, ro, rd, None, outs[0], outs[1], outs[2], gcol, None, None,
                                     wsx, rng, zero_first=first[0])
+        if ev is not None:
+            ev[1].record()
         first[0] = False
         opt.step(wsx, layout)
 
     view_of_step = []     # (which view every step() call rendered, in call order)
 
-    def step():
+    def step(ev=None):
         ro_v, rd_v = view_rays[len(view_of_step) % n_views]
         view_of_step.append(len(view_of_step) % n_views)
-        return step_on(ro_v, rd_v)
+        return step_on(ro_v, rd_v, ev)
 
-    def step_on(rays_o, rays_d):
+    def step_on(rays_o, rays_d, ev=None):
         if fused:
-            return fused_step(params, rays_o, rays_d, (colour, depth, acc, disp), g_colour, ws)
+            return fused_step(params, rays_o, rays_d, (colour, depth, acc, disp), g_colour, ws, ev)
         step_no[0] += 1
         rng = (42, step_no[0])
         ops.render_fwd_into(spec, params, dens, feat, rays_o, rays_d, None, colour, depth, acc, disp, ws, rng)
@@ -260,6 +264,13 @@ def main():
     gc.collect()          # like timeit: no interpreter garbage collection inside the timed steps
     gc.disable()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # Kernel times of the timed steps.  A timing event on the launch stream costs ~5.5 us of device time (kernel timeline of this
+    # script, profiles/r06_bench_trace.txt: gaps of 5.9 / 10.6 / 11 us wherever 1 / 2 events sit between two kernels, 0.0 us between
+    # kernels with none).  The fused step therefore carries THREE events: the step mark (= start of the forward), one behind the
+    # forward (= start of the backward), one behind the backward (= start of the grid step) -- the library's per-phase timers
+    # (start + stop per phase: five per step with the mark, 27 us of an 0.82 ms step) stay for the split-optimiser path, whose
+    # pack / memset / unpack phases they separate.
+    phase_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)] if fused else None
     ops.profile_enable(True)    # (creates the library's timing events)
     untimed_steps, untimed_s = 0, 0.0
     if PRE_WARM_MS > 0:
@@ -282,13 +293,13 @@ def main():
     if fused:   # exchange timing of the timed region only (events on the launch stream; 0 for one process)
         opt.read_exchange_ms()
         opt.exchange_ms, opt.exchange_steps = 0.0, 0
-    ops.profile_enable(True)
+    ops.profile_enable(not fused)
     barrier()
     del view_of_step[:]         # (the timed steps start at view 0 whatever the warm-up rendered)
     t0 = time.perf_counter()
     for i in range(args.steps):
         marks[i].record()
-        step()
+        step(phase_ev[i] if fused else None)
     marks[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -301,6 +312,10 @@ def main():
     exchange_ms = opt.read_exchange_ms() if fused else None
     prof = ops.profile_read()
     ops.profile_enable(False)
+    if fused:   # (events of this script, see above: forward = mark -> first event, backward = first -> second)
+        prof = dict(prof)
+        prof.update(ms_fwd=sum(marks[i].elapsed_time(phase_ev[i][0]) for i in range(args.steps)), n_fwd=args.steps,
+                    ms_bwd=sum(phase_ev[i][0].elapsed_time(phase_ev[i][1]) for i in range(args.steps)), n_bwd=args.steps)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

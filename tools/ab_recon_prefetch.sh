@@ -6,5 +6,5 @@ F=$OUT/ab_recon_prefetch.txt; : > $F
 run() { echo "== $1" >> $F; shift; for i in 1 2; do env "$@" python tools/recon_bench.py 80 2>&1 | grep -E 'reconstruction iteration|kernel phases' >> $F; done; }
 run "no hint" RECON_NO_PREFETCH=1
 run "hint: shipped (prefetch forks behind the forward, low-priority side stream)" X=1
-for v in f0 f2; do [ -f variants/libvoxe_hip_$v.so ] && run "hint: variant $v" VOXE_HIP_LIB=variants/libvoxe_hip_$v.so; done
+for v in f0 f2 f3; do [ -f variants/libvoxe_hip_$v.so ] && run "hint: variant $v" VOXE_HIP_LIB=variants/libvoxe_hip_$v.so; done
 cat $F

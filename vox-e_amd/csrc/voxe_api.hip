@@ -673,9 +673,10 @@ int64_t g_recon_stats[3] = {0, 0, 0};                   // hints issued | taken 
 #endif
 #ifndef VOXE_RECON_FORK
 #define VOXE_RECON_FORK 1        // where a step lets the prefetch of its successor start: 0 at its own start | 1 behind its forward (fold) |
-                                 // 2 batch assembly + clearing of the counters at its start, the segment pass behind its forward.
+                                 // 2 batch assembly + clearing of the counters at its start, the segment pass behind its forward |
+                                 // 3 like 2, the segment pass already behind the region forward (beside the fold pass).
                                  // Measured (160^3, 2 x 32768 rays, ms per iteration; profiles/r06_recon_prefetch.txt): no hint 0.805,
-                                 // 1 -> 0.725, 0 -> 0.79, 2 -> 0.78.  The backward's blocks hold every SIMD's registers and 144 of 160 KB
+                                 // 1 -> 0.725, 0 -> 0.79, 2 -> 0.78, 3 -> 0.79.  The backward's blocks hold every SIMD's registers and 144 of 160 KB
                                  // of LDS: launched behind it (1) the segment pass (1024-thread blocks, 72 KB) waits until the backward
                                  // drains and then shares the machine with the grid step -- an HBM stream that leaves the CUs idle;
                                  // launched in front of it (2) the segment pass runs at once but the column scan behind it starves and the
@@ -757,7 +758,7 @@ int voxe_recon_prefetch(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, cons
     (void)hipEventRecord(rsd.fork0, s);
     (void)hipEventRecord(rsd.fork, s);
   }
-  const bool early = VOXE_RECON_FORK == 2 || VOXE_RECON_FORK == 0;
+  const bool early = VOXE_RECON_FORK == 2 || VOXE_RECON_FORK == 3 || VOXE_RECON_FORK == 0;
   (void)hipStreamWaitEvent(rsd.side, early ? rsd.fork0 : rsd.fork, 0);
   const ReconBatchPtrs bp = recon_batch_ptrs(l, scratch, slot);
   launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
@@ -766,7 +767,7 @@ int voxe_recon_prefetch(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, cons
   make_dev(grid, &pc, 2 * B, v, &dg, &dc);
   void* const tables = (char*)(slot ? workspace2 : workspace) + wl.region_off;
   launch_bin_region(dg, dc, bp.rays_o, bp.rays_d, nullptr, tables, rsd.side, /*phase=*/1);      // counters cleared
-  if (VOXE_RECON_FORK == 2) (void)hipStreamWaitEvent(rsd.side, rsd.fork, 0);
+  if (VOXE_RECON_FORK == 2 || VOXE_RECON_FORK == 3) (void)hipStreamWaitEvent(rsd.side, rsd.fork, 0);
   launch_bin_region(dg, dc, bp.rays_o, bp.rays_d, nullptr, tables, rsd.side, /*phase=*/2);      // segments -> sorted tables
   (void)hipEventRecord(rsd.pend.done, rsd.side);
   rsd.pend.valid = true;
@@ -848,7 +849,12 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
       if (!prebinned)
         launch_recon_batch(B, cfg->seed, cfg->rng_offset, rs->H, rs->W, rs->focal, rs->K, rs->poses, rs->images,
                            (const long long*)rs->image_rows, rs->num_images, (long long*)bp.subset, bp.rays_o, bp.rays_d, bp.target, s);
-      const RegionBins bins{slot ? (void*)((char*)workspace2 + wl.region_off) : nullptr, prebinned ? 1 : 0};
+      hipEvent_t mid = nullptr;
+      if (have_side && VOXE_RECON_FORK == 3) {
+        std::lock_guard<std::mutex> lock(g_recon_mu);
+        mid = g_recon[workspace].fork;
+      }
+      const RegionBins bins{slot ? (void*)((char*)workspace2 + wl.region_off) : nullptr, prebinned ? 1 : 0, mid};
       struct BinsScope { explicit BinsScope(const RegionBins* b) { tl_region_bins = b; } ~BinsScope() { tl_region_bins = nullptr; } } bscope(&bins);
       float* colour = (float*)(sc + l.out2);
       float *depth = colour + 6 * B, *acc = depth + 2 * B;
@@ -859,7 +865,8 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
         std::lock_guard<std::mutex> lock(g_recon_mu);
         ReconSide& rsd = g_recon[workspace];
         rsd.last_slot = slot;
-        if (VOXE_RECON_FORK != 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
+        if (VOXE_RECON_FORK == 3) rsd.forked = true;      // (recorded between the region forward and the fold pass: RegionBins::after_fwd)
+        else if (VOXE_RECON_FORK != 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
       }
       launch_l1_loss_grad_n(colour, bp.target, 3 * B, 2, d_colour, rs->losses, sc + l.partial, s);   // both renders, one launch pair
       pc.ray_state_valid = 1;

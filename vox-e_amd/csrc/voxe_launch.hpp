@@ -133,7 +133,7 @@ void launch_bwd_region(const DevGrid& g, const DevCfg& c, int deg, int diffuse, 
                        hipStream_t st);   // needs the tables / states of launch_fwd_region for the same rays
 // r06: the binning passes of launch_fwd_region on their own, into the tables at `tables` (a buffer of region_scratch_bytes), and
 // the override the region launches read while it is set: tables elsewhere than in `scratch` / already filled for these rays
-struct RegionBins { void* tables; int prebinned; };
+struct RegionBins { void* tables; int prebinned; hipEvent_t after_fwd; };   // after_fwd (or null): recorded between the region forward and the fold pass
 extern thread_local const RegionBins* tl_region_bins;
 void launch_bin_region(const DevGrid& g, const HostCfg& c, const float* rays_o, const float* rays_d, const float* jitter, void* tables,
                        hipStream_t st, int phase = 3);   // phase 1: clear the counters | 2: the passes behind that | 3: both

@@ -1348,6 +1348,7 @@ static void launch_fwd_region_t(const DevGrid& g, const DevCfg& c, const FwdArgs
   const size_t lds = (NCU > 1 && stage) ? full_tex_lds(region_fwd_kernel<COUT, NCM, NCU>, COUT * NCM + 1) : 0;
   float4* fwdval = (NCU > 1 && a.keep_samples && VOXE_REGION_FWDVAL) ? (float4*)((char*)scratch + l.fwdval) : nullptr;
   region_fwd_kernel<COUT, NCM, NCU><<<l.nreg + kGenericBlocks, VOXE_REGION_BLOCK, lds, st>>>(g, c, a.packed, a.rays_o, a.rays_d, a.jitter, bs, l.nreg, stage, fwdval);
+  if (tl_region_bins && tl_region_bins->after_fwd) (void)hipEventRecord(tl_region_bins->after_fwd, st);
   const int rays_per_block = 256 / nseg;        // (nseg <= 256: region_bwd_supported)
   region_fold_kernel<COUT><<<(int)((c.R + rays_per_block - 1) / rays_per_block), 256, 0, st>>>(
       c, bs, a.colour, a.depth, a.acc, a.disparity, rays_per_block);
