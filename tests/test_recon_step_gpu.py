@@ -304,3 +304,60 @@ def test_recon_prefetch_is_dropped_where_no_paired_render_runs():
     assert _prefetch_stats() == s0
     ref, *_ = _run_recon(None, 3, batch=3000)
     assert out[0] == ref[0]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_recon_prefetch_random_call_sequences(seed):
+    """hints in every order a caller could produce -- none, right, wrong stream, wrong cameras, two in a row, a batch size that regrows
+    the workspaces (the binding synchronises before it frees a buffer the side stream may still write), a stale hint from a smaller
+    batch -- against the same iterations without any hint: the losses of every iteration agree to the float-atomic noise of the
+    gradient sums and the first iteration exactly."""
+    import random
+
+    rnd = random.Random(100 + seed)
+    side, hw, K, steps = 40, 64, 6, 9
+    plan = []
+    for it in range(steps):
+        plan.append({"batch": rnd.choice([18000, 18000, 18000, 22000]), "hint": rnd.choice(["right", "right", "none", "wrong_rng", "wrong_cams", "twice"])})
+
+    def run(with_hints):
+        dens0, feat0, poses_all, images, spec, params = _setup(side, hw, 10)
+        gen = torch.Generator().manual_seed(7 + seed)
+        d_b, f_b = dens0.clone(), feat0.clone()
+        st_d = (torch.zeros_like(d_b), torch.zeros_like(d_b))
+        st_f = (torch.zeros_like(f_b), torch.zeros_like(f_b))
+        wa, wb = ops.Workspace(), ops.Workspace()
+        losses = torch.zeros(4, device=DEV)
+        cams = [torch.randint(0, 10, (K,), generator=gen).to(DEV) for _ in range(steps + 1)]
+        cam_poses = [poses_all[c].contiguous() for c in cams]
+        other = poses_all[torch.randint(0, 10, (K,), generator=gen).to(DEV)].contiguous()
+        torch.cuda.synchronize()
+        out = []
+        for it in range(steps):
+            ops.recon_step_(spec, params, d_b, f_b, wa, wb, hw, hw, focal_for(hw), cam_poses[it], cams[it], images, plan[it]["batch"], True,
+                            st_d, st_f, it + 1, it + 1, 2e-2, losses, (3, 100 * it), zero_gradient_first=(it == 0))
+            out.append(losses.tolist())
+            if not with_hints or it + 1 >= steps:
+                continue
+            kind, nb = plan[it]["hint"], plan[it + 1]["batch"]
+
+            def hint(poses, rng, batch=nb):
+                ops.recon_prefetch_(spec, params, d_b, f_b, wa, wb, hw, hw, focal_for(hw), poses, cams[it + 1], images, batch, True, losses, rng)
+
+            if kind == "right":
+                hint(cam_poses[it + 1], (3, 100 * (it + 1)))
+            elif kind == "wrong_rng":
+                hint(cam_poses[it + 1], (3, 100 * (it + 1) + 7))
+            elif kind == "wrong_cams":
+                hint(other, (3, 100 * (it + 1)))
+            elif kind == "twice":
+                hint(other, (3, 100 * (it + 1) + 9), batch=plan[it]["batch"])
+                hint(cam_poses[it + 1], (3, 100 * (it + 1)))
+        torch.cuda.synchronize()
+        return out
+
+    plain, hinted = run(False), run(True)
+    assert plain[0] == hinted[0]
+    for it in range(steps):
+        for j in range(4):
+            assert abs(plain[it][j] - hinted[it][j]) < 2e-6 + 5e-5 * abs(plain[it][j]), (it, j, plan[it], plain[it], hinted[it])
