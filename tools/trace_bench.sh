@@ -2,7 +2,7 @@
 # kernel timeline of the headline step (gaps between the kernels of a step):  gpurun -- bash tools/trace_bench.sh <outdir>
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-r06y}; mkdir -p $OUT
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-gpu-baseline --no-secondary --steps 20 --warmup 3 > $OUT/trace_bench.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/trace_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-gpu-baseline --no-secondary --steps 20 --warmup 3 $TRACE_FLAGS > $OUT/trace_bench.log 2>&1)
 python - "$OUT" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/trace_bench/**/bench_kernel_trace.csv", recursive=True)[0]

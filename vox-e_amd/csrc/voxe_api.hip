@@ -667,6 +667,7 @@ struct ReconSide {
 };
 std::mutex g_recon_mu;
 std::unordered_map<const void*, ReconSide> g_recon;     // by workspace
+constexpr size_t kMaxReconSides = 16;
 int64_t g_recon_stats[3] = {0, 0, 0};                   // hints issued | taken by the following step | dropped by it (voxe_recon_prefetch_stats)
 #ifndef VOXE_RECON_SIDE_LOW
 #define VOXE_RECON_SIDE_LOW 1
@@ -742,6 +743,18 @@ int voxe_recon_prefetch(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, cons
   if (st) return st;
   hipStream_t s = (hipStream_t)stream;
   std::lock_guard<std::mutex> lock(g_recon_mu);
+  if (g_recon.size() >= kMaxReconSides && g_recon.find(workspace) == g_recon.end()) {
+    // (workspaces come and go with their trainers: records without a hint in flight give their stream and events back)
+    for (auto it = g_recon.begin(); it != g_recon.end();) {
+      ReconSide& o = it->second;
+      if (o.pend.valid) { ++it; continue; }
+      if (o.side) { (void)hipStreamSynchronize(o.side); (void)hipStreamDestroy(o.side); }
+      if (o.fork) (void)hipEventDestroy(o.fork);
+      if (o.fork0) (void)hipEventDestroy(o.fork0);
+      if (o.pend.done) (void)hipEventDestroy(o.pend.done);
+      it = g_recon.erase(it);
+    }
+  }
   ReconSide& rsd = g_recon[workspace];
   if (!rsd.side) {
     // (lowest priority: the side stream's kernels fill what the iteration's own kernels leave idle, they do not queue in front of them)

@@ -338,6 +338,9 @@ __global__ __launch_bounds__(256) void grid_adam_kernel(float* __restrict__ gpac
 #define VOXE_GA_V5 1
 #endif
 __device__ __forceinline__ void wave_lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// FEATCORR (r06): with the feature-correlation term compiled in, the kernel needs 170 registers -- 2 waves per SIMD instead of the 3
+// that 150 leave -- and the plain step ran 103 instead of 86 us (rocprofv3 averages r05 -> r06): the term is its own instantiation.
+template <bool FEATCORR>
 __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ gpacked, float* __restrict__ dens,
                                                            float4* __restrict__ feat, const float* __restrict__ extra_d,
                                                            const float4* __restrict__ extra_f, float* __restrict__ m_d,
@@ -383,8 +386,8 @@ __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ 
         if (m_f) { m[k * 3 + f] = b1[i]; v[k * 3 + f] = b2[i]; }
       }
     wave_lds_order();
-    float fg[12];
-    if (m_f && dcl.fref) {   // feature-correlation term (r06; weight 0 by default): the reference features through buffer 0
+    float fg[FEATCORR ? 12 : 1];
+    if constexpr (FEATCORR) if (m_f && dcl.fref) {   // feature-correlation term (r06; weight 0 by default): the reference features through buffer 0
       const float4* __restrict__ fr4 = reinterpret_cast<const float4*>(dcl.fref);
 #pragma unroll
       for (int k = 0; k < 3; ++k) buf[0][k * 64 + lane] = fr4[f4 + k * 64 + lane];
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void grid_adam_v5_kernel(float4* __restrict__ 
         for (int f = 0; f < 3; ++f) {
           const float gj = f == 0 ? g[k].x : (f == 1 ? g[k].y : g[k].z);
           float gi = extra_f ? gj + b0[(k * 64 + lane) * 3 + f] : gj;
-          if (dcl.fref) gi += fg[k * 3 + f];
+          if constexpr (FEATCORR) { if (dcl.fref) gi += fg[k * 3 + f]; }
           p[k * 3 + f] = adam_update(p[k * 3 + f], gi, m[k * 3 + f], v[k * 3 + f], h_f);
         }
       wave_lds_order();
@@ -612,11 +615,14 @@ static void launch_grid_adam_t(const VoxeGridDesc* gd, bool bricked, int x_begin
       if ((ve - vb) >= 256) {
         const long long nchunks = (ve - vb) / 256, tail = vb + nchunks * 256;
         const int nb5 = (int)((nchunks + 3) / 4 < VOXE_GA_BLOCKS ? (nchunks + 3) / 4 : VOXE_GA_BLOCKS);
-        grid_adam_v5_kernel<<<nb5, 256, 0, st>>>(
-            reinterpret_cast<float4*>(gpacked), const_cast<float*>(gd->densities),
-            reinterpret_cast<float4*>(const_cast<float*>(gd->features)), extra_d, reinterpret_cast<const float4*>(extra_f), m_d, v_d,
-            reinterpret_cast<float4*>(m_f), reinterpret_cast<float4*>(v_f), reinterpret_cast<float4*>(packed_out), vb, (int)nchunks,
-            gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0, dcl);
+#define VOXE_GA5(FC)                                                                                                              \
+        grid_adam_v5_kernel<FC><<<nb5, 256, 0, st>>>(                                                                             \
+            reinterpret_cast<float4*>(gpacked), const_cast<float*>(gd->densities),                                                \
+            reinterpret_cast<float4*>(const_cast<float*>(gd->features)), extra_d, reinterpret_cast<const float4*>(extra_f), m_d, v_d, \
+            reinterpret_cast<float4*>(m_f), reinterpret_cast<float4*>(v_f), reinterpret_cast<float4*>(packed_out), vb, (int)nchunks, \
+            gd->density_scale, gd->density_pre_act, h_d, h_f, VOXE_GA_FLIP ? flip : 0, dcl)
+        if (dcl.fref && m_f) VOXE_GA5(true); else VOXE_GA5(false);
+#undef VOXE_GA5
         if (tail < ve)   // fewer than 256 voxels left: the per-voxel kernel
           grid_adam_kernel<C><<<1, 256, 0, st>>>(gpacked, const_cast<float*>(gd->densities), const_cast<float*>(gd->features), extra_d,
                                                  extra_f, m_d, v_d, m_f, v_f, packed_out, tail, ve, gd->density_scale,
@@ -913,6 +919,81 @@ __global__ __launch_bounds__(256) void render_fwd_combine_kernel(DevCfg c, const
       sd = fmaf(Ts, segbuf[(base + 2 + COUT) * c.R + r], sd);
       ray_state[ray_state_index(s, 1 + COUT, NC, c.R, r)] = sa;
       ray_state[ray_state_index(s, 2 + COUT, NC, c.R, r)] = sd;
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) {
+    float col = csum[ch];
+    if (c.white) {
+      float bk = 1.0f - asum;
+      if (c.attn) bk = bk * 0.0f;
+      col = col + bk;
+    }
+    if (colour) colour[r * COUT + ch] = col;
+  }
+  if (depth) depth[r] = dsum;
+  if (acc) acc[r] = asum;
+  if (disparity) {
+    const float q = dsum / asum;
+    const float m = (q != q) ? q : (q > kZeroPlus ? q : kZeroPlus);
+    disparity[r] = 1.0f / m;
+  }
+}
+
+// r06: the same pass for at most MAXSEG depth segments with every partial in registers.  The kernel above re-reads, in its
+// back-to-front loop, the transmittances it has just stored (a store -> load round trip through memory per boundary, which the
+// compiler may not reorder: ~13 us for ANY number of rays, launch-latency scale work turned into seven dependent memory trips --
+// kernel timeline, profiles/r06_bench_trace.txt).  Here all loads are issued up front (independent), the boundary transmittances
+// stay in registers, and the stores are fire-and-forget: the same products and sums in the same order, bit-identical outputs.
+template <int COUT, int MAXSEG>
+__global__ __launch_bounds__(256) void render_fwd_combine_reg_kernel(DevCfg c, const float* __restrict__ segbuf,
+                                                                     float* __restrict__ colour, float* __restrict__ depth,
+                                                                     float* __restrict__ acc, float* __restrict__ disparity,
+                                                                     float* __restrict__ ray_state) {
+  constexpr int NC = COUT + 3;
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= c.R) return;
+  const int nseg = num_segments(c.S, c.seg_len);     // <= MAXSEG (host)
+  float part[MAXSEG][NC];
+#pragma unroll
+  for (int s = 0; s < MAXSEG; ++s)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) part[s][q] = (s < nseg) ? segbuf[((long long)s * NC + q) * c.R + r] : 0.0f;
+  float csum[COUT];
+#pragma unroll
+  for (int ch = 0; ch < COUT; ++ch) csum[ch] = 0.0f;
+  float asum = 0.0f, dsum = 0.0f, T = 1.0f;
+  float Tb[MAXSEG];                                   // transmittance BEFORE segment s == boundary s
+#pragma unroll
+  for (int s = 0; s < MAXSEG; ++s) {
+    Tb[s] = T;
+    if (s < nseg) {
+#pragma unroll
+      for (int ch = 0; ch < COUT; ++ch) csum[ch] = fmaf(T, part[s][1 + ch], csum[ch]);
+      asum = fmaf(T, part[s][1 + COUT], asum);
+      dsum = fmaf(T, part[s][2 + COUT], dsum);
+      T = T * part[s][0];
+    }
+  }
+  if (ray_state) {
+    float sc[COUT], sa = 0.0f, sd = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < COUT; ++ch) sc[ch] = 0.0f;
+#pragma unroll
+    for (int s = MAXSEG - 1; s > 0; --s) {
+      if (s < nseg) {
+        const float Ts = Tb[s];
+        ray_state[ray_state_index(s, 0, NC, c.R, r)] = Ts;
+#pragma unroll
+        for (int ch = 0; ch < COUT; ++ch) {
+          sc[ch] = fmaf(Ts, part[s][1 + ch], sc[ch]);
+          ray_state[ray_state_index(s, 1 + ch, NC, c.R, r)] = sc[ch];
+        }
+        sa = fmaf(Ts, part[s][1 + COUT], sa);
+        sd = fmaf(Ts, part[s][2 + COUT], sd);
+        ray_state[ray_state_index(s, 1 + COUT, NC, c.R, r)] = sa;
+        ray_state[ray_state_index(s, 2 + COUT, NC, c.R, r)] = sd;
+      }
     }
   }
 #pragma unroll
@@ -1253,8 +1334,16 @@ static void launch_fwd_t(const DevGrid& g, const HostCfg& c, const FwdArgs& a, h
     else
       render_fwd_seg_kernel<COUT, NCM, NCU><<<nrb64 * ncoarse, 64, 0, st>>>(
           g, c, fseg, a.packed, a.rays_o, a.rays_d, a.jitter, a.segbuf, reinterpret_cast<float4*>(a.sample_fwd));
-    render_fwd_combine_kernel<COUT><<<(int)((c.R + 255) / 256), 256, 0, st>>>(
-        c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
+#ifndef VOXE_COMBINE_REG
+#define VOXE_COMBINE_REG 1
+#endif
+    const int cb = (int)((c.R + 255) / 256);
+    if (VOXE_COMBINE_REG && nseg <= 8)
+      render_fwd_combine_reg_kernel<COUT, 8><<<cb, 256, 0, st>>>(c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
+    else if (VOXE_COMBINE_REG && nseg <= 16)
+      render_fwd_combine_reg_kernel<COUT, 16><<<cb, 256, 0, st>>>(c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
+    else
+      render_fwd_combine_kernel<COUT><<<cb, 256, 0, st>>>(c, a.segbuf, a.colour, a.depth, a.acc, a.disparity, a.ray_state);
     return;
   }
   render_fwd_kernel<COUT, NCM, NCU><<<blocks_for(c), 256, 0, st>>>(

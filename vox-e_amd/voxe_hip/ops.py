@@ -925,9 +925,10 @@ def recon_prefetch_(spec: GridSpec, params: RenderParams, densities, features, w
                     images: torch.Tensor, batch: int, diffuse_regularisation: bool, losses: torch.Tensor, rng: Tuple[int, int],
                     scratch_holder: Optional[dict] = None) -> None:
     """voxe_recon_prefetch: announce the NEXT recon_step_ (same arguments; `poses`, `image_rows` and `rng` are the next
-    iteration's).  The library assembles that iteration's batch and segment tables on a stream of its own while the current
-    iteration's backward and grid step run; the next recon_step_ takes them iff its arguments are the announced ones.  A hint:
-    results never depend on it.  Call it right after recon_step_ (both workspaces and the scratch exist by then and keep
+    iteration's; everything else must equal the last recon_step_ of this workspace, otherwise nothing is announced).  The library
+    assembles that iteration's batch and segment tables on a stream of its own while the current iteration's backward and grid
+    step run; the next recon_step_ takes them iff its arguments are the announced ones.  A hint: results never depend on it, and
+    no buffer is ever allocated, grown or moved by it.  Call it right after recon_step_ (both workspaces and the scratch exist by then and keep
     their addresses); `poses` / `image_rows` are kept alive until the next recon_step_ of this workspace."""
     device = densities.device
     if workspace.buf is None:
@@ -946,9 +947,10 @@ def recon_prefetch_(spec: GridSpec, params: RenderParams, densities, features, w
         c.seed, c.rng_offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFFFFFFFFFF
         rs.poses, rs.image_rows = ptr(poses), ptr(image_rows)
     else:
-        L, g, c, rs, ws, ws2, sc, _ = _recon_call(
-            "recon_prefetch_", spec, params, densities, features, workspace, workspace2, height, width, focal, poses, image_rows,
-            images, batch, diffuse_regularisation, None, None, 0, 0, 0.0, losses, rng, 0.9, 0.999, 1e-8, False, scratch_holder)
+        # Anything else (another batch size, grid, image stack, ... than the last step's) is not announced: marshalling it afresh
+        # could regrow a workspace, and a hint must never move a buffer -- the caller's knowledge of what its workspace holds
+        # (packed grid, cleared gradient region: `zero_gradient_first`) would silently go stale.  The next step bins inline.
+        return
     with torch.cuda.device(device):
         check(L.voxe_recon_prefetch(C.byref(g), C.byref(c), C.byref(rs), ptr(ws), ws.numel(), ptr(ws2),
                                     0 if ws2 is None else ws2.numel(), ptr(sc), sc.numel(), stream_ptr(device)), "voxe_recon_prefetch")
