@@ -115,7 +115,9 @@ typedef struct VoxeDispatch {
   int32_t tile_phases;         /* ABI v11.  SH-0 image-ordered backward, tiles that do not fit the window and run as 2 / 4 parts:
                                   0 = the lanes outside a part take the other SAMPLE PHASES of the part's rays (32 rays x 2
                                   consecutive samples, 16 rays x 4: every wave instruction works on 64 lanes) | -1 = one
-                                  sample per ray and iteration, the other lanes idle (r05)                                    */
+                                  sample per ray and iteration, the other lanes idle (r05).  Applies to the 10-wide window
+                                  kernel (tile_kl = 10, or what the library picks for images below ~0.58 x grid side pixels);
+                                  the 8-wide kernel is built without the phased marches (they cost its one-sample march 8 %). */
 } VoxeDispatch;
 
 typedef struct VoxeRenderCfg {

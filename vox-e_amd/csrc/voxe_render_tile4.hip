@@ -1111,7 +1111,18 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
   // r06: the parts of a split tile with 2 / 4 sample phases per ray -- the lanes outside part q take the other phases of the
   // part's rays (lane bits 2 / 5 say which part a lane's own pixel is in: xor-ing them with q gives the phase, forcing them to q
   // the lane whose ray this lane works on)
-  constexpr bool kPhases = !PREC && !DEP;
+#ifndef VOXE_T4_PHASES_KL8
+#define VOXE_T4_PHASES_KL8 0      // 1: sample phases compiled into the 8-wide kernel too.  They are not: the phased march variants in the same
+                                  // kernel cost the ONE-sample march of the 8-wide window 8 % (400x400, same box, backward 0.448 -> 0.410 ms on
+                                  // camera 3, 0.504 -> 0.466 over the 20 views: code size / register allocation of the shared prologue), and at
+                                  // the image sizes that take the 8-wide window the parts of a split tile split for their march extent, which
+                                  // phases do not help (profiles/r06_phases_kl8.txt).  The 10-wide kernel (images below ~0.58 x grid side pixels
+                                  // per voxel: 100 .. 266 px on 160^3) keeps them.
+#endif
+#ifndef VOXE_T4_PHASES_KL10
+#define VOXE_T4_PHASES_KL10 1
+#endif
+  constexpr bool kPhases = !PREC && !DEP && (KL >= 9 ? VOXE_T4_PHASES_KL10 != 0 : VOXE_T4_PHASES_KL8 != 0);
   if constexpr (kPhases) {
    if (split != 0 && a.phases >= 0 && phases_fit) {
     const int bx = (lane >> 2) & 1, by = (lane >> 5) & 1;
