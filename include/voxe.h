@@ -115,9 +115,10 @@ typedef struct VoxeDispatch {
   int32_t tile_phases;         /* ABI v11.  SH-0 image-ordered backward, tiles that do not fit the window and run as 2 / 4 parts:
                                   0 = the lanes outside a part take the other SAMPLE PHASES of the part's rays (32 rays x 2
                                   consecutive samples, 16 rays x 4: every wave instruction works on 64 lanes) | -1 = one
-                                  sample per ray and iteration, the other lanes idle (r05).  Applies to the 10-wide window
-                                  kernel (tile_kl = 10, or what the library picks for images below ~0.58 x grid side pixels);
-                                  the 8-wide kernel is built without the phased marches (they cost its one-sample march 8 %). */
+                                  sample per ray and iteration, the other lanes idle (r05).  Read only by a library built with
+                                  -DVOXE_T4_PHASES_KL8=1 / -DVOXE_T4_PHASES_KL10=1: the shipped kernels carry no phased march
+                                  (inside one kernel it cost the one-sample march 8 % at 400x400 and won nothing over the
+                                  views at 100 .. 266 px: csrc/voxe_render_tile4.hip, profiles/r06_phases_kl8.txt).          */
 } VoxeDispatch;
 
 typedef struct VoxeRenderCfg {

@@ -206,7 +206,9 @@ def test_skewed_and_phased_march_vs_oracle_and_the_one_sample_march(case, disp):
     """VoxeDispatch::tile_phases (ABI v11): lanes of a wave at DIFFERENT samples of their rays -- shifted by the layers a ray is
     ahead of the pass's reference ray (oblique views), and, in the parts of a tile that does not fit the window, 2 / 4 consecutive
     samples of one ray in 2 / 4 lanes (transmittance and running sum exchanged between them).  Against the oracle (accumulate.py:
-    49-84, the backward of SURVEY 8(a16)) and against the r05 march (tile_phases = -1): same gradients to float summation order."""
+    49-84, the backward of SURVEY 8(a16)) and against the r05 march (tile_phases = -1): same gradients to float summation order.
+    (The shipped library is built WITHOUT the phased marches -- profiles/r06_phases_kl8.txt -- so both settings run the one-sample
+    march there; a library built with -DVOXE_T4_PHASES_KL8=1 -DVOXE_T4_PHASES_KL10=1 and VOXE_HIP_LIB runs them against each other.)"""
     side, hw, cam, S, kl = {"oblique_400px_like": (64, 160, 12, 128, 8), "coarse_image_quadrants": (96, 56, 3, 96, 0),
                             "coarse_image_halves": (72, 72, 58, 96, 8), "z_march_pairs": (64, 160, 0, 128, 8),
                             "term_eps": (64, 120, 88, 96, 8), "depth_and_acc_gradients": (64, 136, 38, 112, 8),

@@ -1117,10 +1117,13 @@ __global__ __launch_bounds__(64, KL >= 9 ? 2 : (PREC ? VOXE_TILE4_LB_PREC : VOXE
                                   // camera 3, 0.504 -> 0.466 over the 20 views: code size / register allocation of the shared prologue), and at
                                   // the image sizes that take the 8-wide window the parts of a split tile split for their march extent, which
                                   // phases do not help (profiles/r06_phases_kl8.txt).  The 10-wide kernel (images below ~0.58 x grid side pixels
-                                  // per voxel: 100 .. 266 px on 160^3) keeps them.
+                                  // per voxel: 100 .. 266 px on 160^3): see VOXE_T4_PHASES_KL10.
 #endif
 #ifndef VOXE_T4_PHASES_KL10
-#define VOXE_T4_PHASES_KL10 1
+#define VOXE_T4_PHASES_KL10 0     // ... nor into the 10-wide one: over the 20 views the backward is 0.255 / 0.341 / 0.393 ms with them and
+                                  // 0.248 / 0.343 / 0.387 ms without at 100 / 200 / 266 px (same box) -- what the phases win on the parts that
+                                  // fit the ring, the one-sample march of all the other passes loses to the shared kernel.  The march variants
+                                  // stay in the source (tests build them: tools/variants.py -DVOXE_T4_PHASES_KL10=1) as a measured alternative.
 #endif
   constexpr bool kPhases = !PREC && !DEP && (KL >= 9 ? VOXE_T4_PHASES_KL10 != 0 : VOXE_T4_PHASES_KL8 != 0);
   if constexpr (kPhases) {
