@@ -63,8 +63,14 @@ def main():
     prefetch = one_call and not os.environ.get("RECON_NO_PREFETCH")
     upcoming = []
 
+    from thre3d_atom.modules.trainers import _PinnedStaging
+    staging = _PinnedStaging(8, dev)
+
     def draw():
-        picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
+        if os.environ.get("RECON_PAGEABLE_PICKS"):   # (the r05 loop: a pageable host-to-device copy per iteration waits for the stream)
+            picks = torch.randint(0, NV, (8,), generator=gen).to(dev)
+        else:
+            picks = staging.to_device(lambda out: torch.randint(0, NV, (out.numel(),), generator=gen, out=out))
         return picks, poses[picks].contiguous(), ops._next_rng()
 
     def iteration(profile):

@@ -28,6 +28,32 @@ from thre3d_atom.utils.misc import compute_thre3d_grid_sizes
 from voxe_hip.ops import _next_rng
 
 
+class _PinnedStaging:
+    """Host -> device copies of the per-iteration camera picks that do not stall the host: a pageable tensor's .to(device) waits for
+    the stream (every kernel of the previous iterations) before it returns, which makes the loop host-paced; a small ring of pinned
+    buffers + non_blocking copies does not.  A buffer is reused only once its copy has completed (event per buffer)."""
+
+    def __init__(self, n: int, device, depth: int = 4):
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.bufs = [torch.empty(n, dtype=torch.int64, pin_memory=self.cuda) for _ in range(depth)]
+        self.events = [None] * depth
+        self.turn = 0
+
+    def to_device(self, fill) -> Tensor:
+        i = self.turn % len(self.bufs)
+        self.turn += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        fill(self.bufs[i])
+        if not self.cuda:
+            return self.bufs[i].clone()
+        out = self.bufs[i].to(self.device, non_blocking=True)
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record()
+        return out
+
+
 def train_sh_vox_grid_vol_mod_with_posed_images(
     vol_mod: VolumetricModel,
     train_dataset: Any,
@@ -112,10 +138,12 @@ def train_sh_vox_grid_vol_mod_with_posed_images(
         fused_losses = torch.zeros(4, dtype=torch.float32, device=device)
         log.info(f"stage {stage}: grid {vol_mod.thre3d_repr.grid_dims}, images [{intr.height} x {intr.width}], lr {lr:.4f}")
 
+        staging = _PinnedStaging(min(image_batch_cache_size, len(data)), device)
+
         def draw_batch():
             # a cache of `image_batch_cache_size` random views; the batch is a random subset of ALL their pixels
             # (cast + collate + randperm of the reference, restricted to the pixels that are kept)
-            picks = torch.randint(0, len(data), (min(image_batch_cache_size, len(data)),), generator=gen).to(device)
+            picks = staging.to_device(lambda out: torch.randint(0, len(data), (out.numel(),), generator=gen, out=out))
             if not one_call:
                 return picks, None, None
             return picks, data.poses[picks].contiguous(), _next_rng()

@@ -884,6 +884,20 @@ def _recon_call(entry: str, spec: GridSpec, params: RenderParams, densities, fea
     return L, g, c, rs, ws, ws2, sc, (m_d, v_d, m_f, v_f)
 
 
+def _recon_key(spec, params, densities, features, height, width, focal, images, batch, diffuse_regularisation, losses):
+    """what has to be unchanged for the descriptors of the last recon_step_ to describe this call too (everything but the cameras,
+    the streams, the optimiser's state / hyper-parameters and the flags)"""
+    return (spec, params, params.dispatch if params.dispatch is not None else _dispatch.current(), densities.data_ptr(),
+            tuple(densities.shape), densities.dtype, densities.is_contiguous(), features.data_ptr(), tuple(features.shape), features.dtype,
+            features.is_contiguous(), int(height), int(width), float(focal), images.data_ptr(), tuple(images.shape), images.dtype,
+            images.is_contiguous(), int(batch), bool(diffuse_regularisation), losses.data_ptr(), losses.dtype, losses.numel())
+
+
+def _recon_cameras_ok(poses, image_rows, K) -> bool:
+    return (poses.is_cuda and poses.dtype == torch.float32 and poses.is_contiguous() and tuple(poses.shape) == (K, 3, 4)
+            and (image_rows is None or (image_rows.is_cuda and image_rows.dtype == torch.int64 and image_rows.numel() == K)))
+
+
 def recon_step_(spec: GridSpec, params: RenderParams, densities, features, workspace: Workspace, workspace2: Workspace,
                 height: int, width: int, focal: float, poses: torch.Tensor, image_rows: Optional[torch.Tensor],
                 images: torch.Tensor, batch: int, diffuse_regularisation: bool, state_densities, state_features,
@@ -896,10 +910,31 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
     subset streams derive from `rng` (subset: offset, specular: offset + 1, diffuse: offset + 2).  Afterwards
     `workspace` holds the updated grid packed and a cleared gradient region."""
     device = densities.device
-    L, g, c, rs, ws, ws2, sc, (m_d, v_d, m_f, v_f) = _recon_call(
-        "recon_step_", spec, params, densities, features, workspace, workspace2, height, width, focal, poses, image_rows, images,
-        batch, diffuse_regularisation, state_densities, state_features, step_densities, step_features, lr, losses, rng, beta1,
-        beta2, eps, zero_gradient_first, scratch_holder)
+    cache = workspace.recon_cache
+    key = _recon_key(spec, params, densities, features, height, width, focal, images, batch, diffuse_regularisation, losses)
+    if (cache is not None and scratch_holder is None and cache[0] == key and cache[4] is workspace.buf and workspace.buf is not None
+            and cache[5] is workspace2.buf and _recon_cameras_ok(poses, image_rows, cache[3].K)):
+        # the same loop as the last call (grid, cameras' shape, images, batch, buffers): its descriptors with this iteration's
+        # cameras, streams, optimiser state and flags -- the trainer's loop is paced by this function's host time
+        L = lib()
+        _, g, c0, rs0, ws, ws2, sc = cache
+        c = type(c0).from_buffer_copy(c0)
+        rs = type(rs0).from_buffer_copy(rs0)
+        c.seed, c.rng_offset = int(rng[0]) & 0xFFFFFFFFFFFFFFFF, int(rng[1]) & 0xFFFFFFFFFFFFFFFF
+        c.reuse_packed_grid = int(workspace.key == _pack_key(spec, densities, features))
+        rs.poses, rs.image_rows = ptr(poses), ptr(image_rows)
+        rs.lr, rs.beta1, rs.beta2, rs.eps = float(lr), float(beta1), float(beta2), float(eps)
+        rs.step_densities, rs.step_features = int(step_densities), int(step_features)
+        m_d, v_d = state_densities if state_densities is not None else (None, None)
+        m_f, v_f = state_features if state_features is not None else (None, None)
+        rs.exp_avg_densities, rs.exp_avg_sq_densities = ptr(m_d), ptr(v_d)
+        rs.exp_avg_features, rs.exp_avg_sq_features = ptr(m_f), ptr(v_f)
+        rs.zero_gradient_first = int(bool(zero_gradient_first))
+    else:
+        L, g, c, rs, ws, ws2, sc, (m_d, v_d, m_f, v_f) = _recon_call(
+            "recon_step_", spec, params, densities, features, workspace, workspace2, height, width, focal, poses, image_rows, images,
+            batch, diffuse_regularisation, state_densities, state_features, step_densities, step_features, lr, losses, rng, beta1,
+            beta2, eps, zero_gradient_first, scratch_holder)
     with torch.cuda.device(device):
         check(L.voxe_recon_step(C.byref(g), C.byref(c), C.byref(rs), ptr(ws), ws.numel(), ptr(ws2),
                                 0 if ws2 is None else ws2.numel(), ptr(sc), sc.numel(), stream_ptr(device)), "voxe_recon_step")
@@ -907,9 +942,7 @@ def recon_step_(spec: GridSpec, params: RenderParams, densities, features, works
     workspace2.prefetch_inflight = False
     # what a hint for the NEXT iteration has to repeat (recon_prefetch_ copies these descriptors instead of building them again:
     # the hint's host time is on the iteration's critical path once the device work is hidden)
-    workspace.recon_cache = ((spec, params, densities.data_ptr(), features.data_ptr(), int(height), int(width), float(focal),
-                              images.data_ptr(), int(batch), bool(diffuse_regularisation), losses.data_ptr()),
-                             g, c, rs, ws, ws2, sc)
+    workspace.recon_cache = (key, g, c, rs, ws, ws2, sc)
     workspace.prefetch_keepalive = None
     for t in (densities, features, m_d, v_d, m_f, v_f):
         if t is not None:
@@ -934,11 +967,9 @@ def recon_prefetch_(spec: GridSpec, params: RenderParams, densities, features, w
     if workspace.buf is None:
         return                                             # (no step has sized the buffers yet: nothing to announce against)
     cache = workspace.recon_cache
-    key = (spec, params, densities.data_ptr(), features.data_ptr(), int(height), int(width), float(focal), images.data_ptr(),
-           int(batch), bool(diffuse_regularisation), losses.data_ptr())
+    key = _recon_key(spec, params, densities, features, height, width, focal, images, batch, diffuse_regularisation, losses)
     if (cache is not None and scratch_holder is None and cache[0] == key and cache[4] is workspace.buf and cache[5] is workspace2.buf
-            and poses.is_cuda and poses.dtype == torch.float32 and poses.is_contiguous() and tuple(poses.shape) == (cache[3].K, 3, 4)
-            and (image_rows is None or (image_rows.is_cuda and image_rows.dtype == torch.int64 and image_rows.numel() == cache[3].K))):
+            and _recon_cameras_ok(poses, image_rows, cache[3].K)):
         # the descriptors of the last step with the next iteration's cameras and streams
         L = lib()
         _, g, c0, rs0, ws, ws2, sc = cache
