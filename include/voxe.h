@@ -495,7 +495,8 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
  *   be called with (same pointers and sizes; only cfg->rng_offset, step->poses / image_rows and the Adam step counters
  *   normally differ -- the Adam fields, `losses` and cfg->reuse_packed_grid / ray_state_valid are not looked at): the library
  *   enqueues that work on a stream of its own, ordered behind iteration i's forward, where it overlaps iteration i's
- *   backward and grid step (160^3, 32768 rays: see DESIGN 4.5).  The following voxe_recon_step waits for it and skips its own
+ *   backward and grid step (what that is worth: ~1 % of a device-paced loop, and all the time a slow host would otherwise
+ *   leave the device idle -- DESIGN 4.5).  The following voxe_recon_step waits for it and skips its own
  *   batch assembly / binning iff every argument that decides them equals the announced one; otherwise it waits and proceeds
  *   exactly as if no hint had been given.  Results do not depend on whether, or with what, this was called.
  *   The tables of the hint live in the region scratch of `workspace2` (which must hold voxe_workspace_bytes(grid, cfg,

@@ -676,8 +676,9 @@ int64_t g_recon_stats[3] = {0, 0, 0};                   // hints issued | taken 
 #define VOXE_RECON_FORK 1        // where a step lets the prefetch of its successor start: 0 at its own start | 1 behind its forward (fold) |
                                  // 2 batch assembly + clearing of the counters at its start, the segment pass behind its forward |
                                  // 3 like 2, the segment pass already behind the region forward (beside the fold pass).
-                                 // Measured (160^3, 2 x 32768 rays, ms per iteration; profiles/r06_recon_prefetch.txt): no hint 0.805,
-                                 // 1 -> 0.725, 0 -> 0.79, 2 -> 0.78, 3 -> 0.79.  The backward's blocks hold every SIMD's registers and 144 of 160 KB
+                                 // Measured (160^3, 2 x 32768 rays, ms per iteration of the trainer's loop, which the host paced at the
+                                 // time; profiles/r06_recon_prefetch.txt): no hint 0.805, 1 -> 0.725, 0 -> 0.79, 2 -> 0.78, 3 -> 0.79.
+                                 // (A device-paced loop gains ~1 % from schedule 1 and loses with the others: device work is conserved.)  The backward's blocks hold every SIMD's registers and 144 of 160 KB
                                  // of LDS: launched behind it (1) the segment pass (1024-thread blocks, 72 KB) waits until the backward
                                  // drains and then shares the machine with the grid step -- an HBM stream that leaves the CUs idle;
                                  // launched in front of it (2) the segment pass runs at once but the column scan behind it starves and the

@@ -113,8 +113,15 @@ template <int COUT, int NCM, int NCU, bool WANT_D, bool WANT_F, int MODE, int KL
 #endif
 // (attention grids with frozen densities -- the refinement loop -- hold a 2-channel window of 6 - 10 KB and need 126 - 130
 //  registers: asked to fit 128, they run 4 waves per SIMD; r05)
+#ifndef VOXE_TILE_SRC_LB
+#define VOXE_TILE_SRC_LB 3        // waves per SIMD the source pass (MODE 1) of view-dependent grids is built for: it holds no window (8 B of
+                                  // LDS), so registers alone bound its residency -- built for 2 it took 177 / 178 of them at SH-1 / SH-3, ten
+                                  // above what 3 waves leave; asked to fit 168 it spills 32 / 24 B and the SH-1 / 2 / 3 backward is
+                                  // 1.91 / 2.97 / 5.29 -> 1.82 / 2.96 / 5.17 ms (400x400, 160^3)
+#endif
 __global__ __launch_bounds__(64, (COUT == 1 && NCU == 1 && !WANT_D && !DET) ? 4
-                                 : (((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE_FROM) ? 2 : VOXE_TILE_LB)) void render_bwd_tile_kernel(
+                                 : ((NCU > 1 && MODE == 1 && KL < VOXE_TILE_WIDE_FROM) ? VOXE_TILE_SRC_LB
+                                 : (((NCU > 1 && MODE != 2) || KL >= VOXE_TILE_WIDE_FROM) ? 2 : VOXE_TILE_LB))) void render_bwd_tile_kernel(
     DevGrid g, DevCfg c, const float* __restrict__ packed, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ jitter,
     const float* __restrict__ colour, const float* __restrict__ depth,
