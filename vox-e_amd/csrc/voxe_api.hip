@@ -748,7 +748,7 @@ int voxe_recon_prefetch(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, cons
     // (workspaces come and go with their trainers: records without a hint in flight give their stream and events back)
     for (auto it = g_recon.begin(); it != g_recon.end();) {
       ReconSide& o = it->second;
-      if (o.pend.valid) { ++it; continue; }
+      if (o.pend.valid) { ++it; continue; }          // (a hint in flight: its events are still waited for)
       if (o.side) { (void)hipStreamSynchronize(o.side); (void)hipStreamDestroy(o.side); }
       if (o.fork) (void)hipEventDestroy(o.fork);
       if (o.fork0) (void)hipEventDestroy(o.fork0);
@@ -854,9 +854,12 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
       const ReconBatchPtrs bp = recon_batch_ptrs(l, scratch, slot);
       if (have_side) {
         std::lock_guard<std::mutex> lock(g_recon_mu);
-        ReconSide& rsd = g_recon[workspace];
-        (void)hipEventRecord(rsd.fork0, s);
-        if (VOXE_RECON_FORK == 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
+        const auto it = g_recon.find(workspace);      // (another thread's voxe_recon_prefetch may have recycled the record since)
+        if (it == g_recon.end() || !it->second.side) have_side = false;
+        else {
+          (void)hipEventRecord(it->second.fork0, s);
+          if (VOXE_RECON_FORK == 0) { (void)hipEventRecord(it->second.fork, s); it->second.forked = true; }
+        }
       }
       // batch assembly: keyed subset of the K * H * W pixels -> rays + target pixels (one launch; same streams as
       // voxe_random_subset, voxe_cast_rays_indexed and the pixel gather)
@@ -866,7 +869,8 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
       hipEvent_t mid = nullptr;
       if (have_side && VOXE_RECON_FORK == 3) {
         std::lock_guard<std::mutex> lock(g_recon_mu);
-        mid = g_recon[workspace].fork;
+        const auto it = g_recon.find(workspace);
+        if (it != g_recon.end()) mid = it->second.fork;
       }
       const RegionBins bins{slot ? (void*)((char*)workspace2 + wl.region_off) : nullptr, prebinned ? 1 : 0, mid};
       struct BinsScope { explicit BinsScope(const RegionBins* b) { tl_region_bins = b; } ~BinsScope() { tl_region_bins = nullptr; } } bscope(&bins);
@@ -877,10 +881,13 @@ int voxe_recon_step(const VoxeGridDesc* grid, const VoxeRenderCfg* cfg, const Vo
       if (st) return st;
       if (have_side) {
         std::lock_guard<std::mutex> lock(g_recon_mu);
-        ReconSide& rsd = g_recon[workspace];
-        rsd.last_slot = slot;
-        if (VOXE_RECON_FORK == 3) rsd.forked = true;      // (recorded between the region forward and the fold pass: RegionBins::after_fwd)
-        else if (VOXE_RECON_FORK != 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
+        const auto it = g_recon.find(workspace);
+        if (it != g_recon.end() && it->second.side) {
+          ReconSide& rsd = it->second;
+          rsd.last_slot = slot;
+          if (VOXE_RECON_FORK == 3) rsd.forked = true;      // (recorded between the region forward and the fold pass: RegionBins::after_fwd)
+          else if (VOXE_RECON_FORK != 0) { (void)hipEventRecord(rsd.fork, s); rsd.forked = true; }
+        }
       }
       launch_l1_loss_grad_n(colour, bp.target, 3 * B, 2, d_colour, rs->losses, sc + l.partial, s);   // both renders, one launch pair
       pc.ray_state_valid = 1;
