@@ -517,3 +517,18 @@ def test_isa_issue_model_prices_instructions_like_the_microbenchmark():
     for key in ("voxe::render_bwd_tile4_kernel<8, false, 0>", "voxe::render_fwd_tile4w_kernel<false>"):
         k = prof["kernels"][key]
         assert 2.15 < k["clk_per_valu"] < 4.3 and k["hot_loops"] and k["occupancy_waves_per_simd"] >= 3
+
+
+def test_pinned_staging_draws_the_generators_stream_and_reuses_its_buffers():
+    """trainers._PinnedStaging (r06): the per-iteration camera picks go through a small ring of staging buffers (pinned on a GPU box, so
+    that the copy does not wait for the stream); the values are exactly the generator's draws, in order, whatever the ring's depth"""
+    import torch
+
+    from thre3d_atom.modules.trainers import _PinnedStaging
+
+    gen, ref = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    st = _PinnedStaging(6, "cpu", depth=2)
+    outs = [st.to_device(lambda out: torch.randint(0, 100, (out.numel(),), generator=gen, out=out)) for _ in range(5)]
+    for o in outs:
+        assert torch.equal(o, torch.randint(0, 100, (6,), generator=ref))
+    assert outs[0].data_ptr() != outs[2].data_ptr()       # (what the caller gets is its own tensor, not the ring's buffer)
