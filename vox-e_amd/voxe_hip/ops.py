@@ -106,6 +106,7 @@ class Workspace:
             if old is not None and self.prefetch_inflight:
                 torch.cuda.synchronize(old.device)   # (a stream torch's allocator knows nothing about is still using the old buffer)
                 self.prefetch_inflight = False
+            self.recon_cache = None                  # (its descriptors point into the old buffer -- and would keep it alive)
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             keep = (old is not None and self.deferred is not None and self.deferred.dirty
                     and old.device == self.buf.device)
